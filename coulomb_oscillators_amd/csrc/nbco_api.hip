@@ -1,0 +1,388 @@
+// nbco_api.hip -- the C ABI of include/nbco.h: context, option handling, the evaluator dispatch
+// of compute_force (integrator.cuh:22-28 over main3.cu:47-69) and the symplectic integrators
+// (integrator.cuh:32-167).
+#include "nbco_internal.hpp"
+#include <cmath>
+#include <new>
+
+int nbco_ctx::reserve(DevBuf &b, size_t bytes)
+{
+	nbco_ctx *c = this;
+	if (bytes <= b.bytes) return NBCO_OK;
+	if (b.ptr)
+	{
+		// earlier launches on the stream may still use the old allocation
+		NBCO_HIP(hipStreamSynchronize(stream));
+		NBCO_HIP(hipFree(b.ptr));
+		b.ptr = nullptr;
+		b.bytes = 0;
+	}
+	size_t want = bytes + bytes / 8 + 256;
+	NBCO_HIP(hipMalloc(&b.ptr, want));
+	b.bytes = want;
+	return NBCO_OK;
+}
+
+void nbco_ctx::phase_begin(int ph)
+{
+	if (!profiling) return;
+	hipEvent_t a, b;
+	if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+	hipEventRecord(a, stream);
+	timers[ph].pending.push_back({a, b});
+}
+
+void nbco_ctx::phase_end(int ph)
+{
+	if (!profiling || timers[ph].pending.empty()) return;
+	hipEventRecord(timers[ph].pending.back().second, stream);
+}
+
+static int check_opts(nbco_ctx *c, const nbco_opts *o)
+{
+	if (o->fmm_order < 1 || o->fmm_order > kMaxOrder) return c->fail(NBCO_ERR_ARG, "fmm_order must be in 1..10");
+	if (!(o->tree_radius > 0)) return c->fail(NBCO_ERR_ARG, "tree_radius must be positive");
+	if (!(o->eps2 > 0)) return c->fail(NBCO_ERR_ARG, "eps2 must be positive");
+	if (!(o->dens_inhom > 0)) return c->fail(NBCO_ERR_ARG, "dens_inhom must be positive");
+	if (o->tree_L < 0 || o->tree_L > 30) return c->fail(NBCO_ERR_ARG, "tree_L must be in 0..30");
+	if (o->tree_steps < 1) return c->fail(NBCO_ERR_ARG, "tree_steps must be >= 1");
+	if (o->list_factor < 1) return c->fail(NBCO_ERR_ARG, "list_factor must be >= 1");
+	return NBCO_OK;
+}
+
+extern "C" {
+
+int nbco_opts_default(nbco_opts *o)
+{
+	if (!o) return NBCO_ERR_ARG;
+	o->fmm_order = 3;        // constants.cuh:42
+	o->tree_radius = 1.f;    // :43
+	o->eps2 = 1.e-18f;       // :39
+	o->coll = 1;             // :48
+	o->unsort = 1;           // :48
+	o->dens_inhom = 1.f;     // :50
+	o->tree_L = 0;           // :44
+	o->tree_steps = 1;
+	o->m2l_first = 0;
+	o->sync = 1;
+	o->list_factor = 48;
+	o->stream = nullptr;
+	return NBCO_OK;
+}
+
+int nbco_create(nbco_ctx **out, const nbco_opts *o)
+{
+	if (!out) return NBCO_ERR_ARG;
+	*out = nullptr;
+	nbco_ctx *c = new (std::nothrow) nbco_ctx();
+	if (!c) return NBCO_ERR_HIP;
+	nbco_opts def;
+	nbco_opts_default(&def);
+	c->o = o ? *o : def;
+	int rc = check_opts(c, &c->o);
+	if (rc != NBCO_OK) { delete c; return rc; }
+	int ndev = 0;
+	hipError_t e = hipGetDeviceCount(&ndev);
+	if (e != hipSuccess || ndev <= 0)
+	{
+		// no CPU fallback: the engine is HIP-only
+		fprintf(stderr, "nbco_create: no usable HIP device (%s)\n", e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+		delete c;
+		return NBCO_ERR_HIP;
+	}
+	if (hipGetDevice(&c->device) != hipSuccess) { delete c; return NBCO_ERR_HIP; }
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+	c->stream = (hipStream_t)c->o.stream;
+	if (hipMalloc(&c->small.ptr, 4096) != hipSuccess) { delete c; return NBCO_ERR_HIP; }
+	c->small.bytes = 4096;
+	*out = c;
+	return NBCO_OK;
+}
+
+int nbco_destroy(nbco_ctx *c)
+{
+	if (!c) return NBCO_OK;
+	hipStreamSynchronize(c->stream);
+	DevBuf *bufs[] = {&c->pos4, &c->pos4_alt, &c->part, &c->small, &c->tmp3, &c->keys, &c->keys_alt, &c->idx, &c->idx_alt,
+	                  &c->unsort, &c->unsort_alt, &c->sort_tmp, &c->treebuf, &c->frontier_a, &c->frontier_b, &c->p2p_list,
+	                  &c->m2l_list, &c->counters, &c->p2p_keys, &c->p2p_keys_alt, &c->m2l_keys, &c->m2l_keys_alt,
+	                  &c->p2p_start, &c->m2l_start, &c->tables};
+	for (DevBuf *b : bufs)
+		if (b->ptr) hipFree(b->ptr);
+	for (auto &t : c->timers)
+		for (auto &ev : t.pending) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+	delete c;
+	return NBCO_OK;
+}
+
+int nbco_set_opts(nbco_ctx *c, const nbco_opts *o)
+{
+	if (!c || !o) return NBCO_ERR_ARG;
+	NBCO_TRY(check_opts(c, o));
+	if ((hipStream_t)o->stream != c->stream) NBCO_HIP(hipStreamSynchronize(c->stream));
+	bool topo = o->fmm_order != c->o.fmm_order || o->dens_inhom != c->o.dens_inhom || o->tree_L != c->o.tree_L
+	            || o->unsort != c->o.unsort;
+	c->o = *o;
+	c->stream = (hipStream_t)o->stream;
+	if (topo) { c->tree_valid = false; c->eval_counter = 0; }
+	return NBCO_OK;
+}
+
+int nbco_get_opts(const nbco_ctx *c, nbco_opts *o)
+{
+	if (!c || !o) return NBCO_ERR_ARG;
+	*o = c->o;
+	return NBCO_OK;
+}
+
+const char *nbco_last_error(const nbco_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int nbco_sync(nbco_ctx *c)
+{
+	if (!c) return NBCO_ERR_ARG;
+	NBCO_HIP(hipStreamSynchronize(c->stream));
+	return NBCO_OK;
+}
+
+static int maybe_sync(nbco_ctx *c)
+{
+	if (c->o.sync) NBCO_HIP(hipStreamSynchronize(c->stream));
+	return NBCO_OK;
+}
+
+// ---- basic kernels -----------------------------------------------------------------------------
+int nbco_step(nbco_ctx *c, float *b, const float *a, float ds, long long n)
+{
+	if (!c || !b || !a || n < 0) return c ? c->fail(NBCO_ERR_ARG, "nbco_step: bad arguments") : NBCO_ERR_ARG;
+	PhaseScope ph(c, NBCO_PH_AXPY);
+	return launch_step(c, b, a, ds, 3 * n);
+}
+int nbco_add_elastic(nbco_ctx *c, const float *p, float *a, long long n, const float *k)
+{
+	if (!c || !p || !a || n < 0) return c ? c->fail(NBCO_ERR_ARG, "nbco_add_elastic: bad arguments") : NBCO_ERR_ARG;
+	PhaseScope ph(c, NBCO_PH_AXPY);
+	return launch_add_elastic(c, p, a, n, k, false);
+}
+int nbco_elastic(nbco_ctx *c, const float *p, float *a, long long n, const float *k)
+{
+	if (!c || !p || !a || n < 0) return c ? c->fail(NBCO_ERR_ARG, "nbco_elastic: bad arguments") : NBCO_ERR_ARG;
+	PhaseScope ph(c, NBCO_PH_AXPY);
+	return launch_add_elastic(c, p, a, n, k, true);
+}
+int nbco_rescale(nbco_ctx *c, float *a, long long n, const float *param)
+{
+	if (!c || !a || !param || n < 0) return c ? c->fail(NBCO_ERR_ARG, "nbco_rescale: bad arguments") : NBCO_ERR_ARG;
+	PhaseScope ph(c, NBCO_PH_AXPY);
+	return launch_rescale(c, a, 3 * n, param);
+}
+int nbco_gather(nbco_ctx *c, float *dst, const float *src, const int *map, long long n)
+{
+	if (!c || !dst || !src || !map || n < 0) return c ? c->fail(NBCO_ERR_ARG, "nbco_gather: bad arguments") : NBCO_ERR_ARG;
+	return launch_gather3(c, dst, src, map, n, false);
+}
+int nbco_gather_inverse(nbco_ctx *c, float *dst, const float *src, const int *map, long long n)
+{
+	if (!c || !dst || !src || !map || n < 0) return c ? c->fail(NBCO_ERR_ARG, "nbco_gather_inverse: bad arguments") : NBCO_ERR_ARG;
+	return launch_gather3(c, dst, src, map, n, true);
+}
+int nbco_copy(nbco_ctx *c, float *dst, const float *src, long long n)
+{
+	if (!c || !dst || !src || n < 0) return c ? c->fail(NBCO_ERR_ARG, "nbco_copy: bad arguments") : NBCO_ERR_ARG;
+	return launch_copy(c, dst, src, 3 * n);
+}
+
+// ---- evaluators --------------------------------------------------------------------------------
+int nbco_direct(nbco_ctx *c, const float *p, float *a, long long n, const float *param)
+{
+	if (!c || !p || !a) return c ? c->fail(NBCO_ERR_ARG, "nbco_direct: null pointer") : NBCO_ERR_ARG;
+	NBCO_TRY(launch_direct(c, p, a, n, param, false));
+	return maybe_sync(c);
+}
+int nbco_direct3(nbco_ctx *c, const float *p, float *a, long long n, const float *param)
+{
+	if (!c || !p || !a) return c ? c->fail(NBCO_ERR_ARG, "nbco_direct3: null pointer") : NBCO_ERR_ARG;
+	NBCO_TRY(launch_direct(c, p, a, n, param, true));
+	return maybe_sync(c);
+}
+int nbco_fmm_kdtree(nbco_ctx *c, float *p, float *a, long long n, const float *param)
+{
+	if (!c || !p || !a) return c ? c->fail(NBCO_ERR_ARG, "nbco_fmm_kdtree: null pointer") : NBCO_ERR_ARG;
+	NBCO_TRY(fmm_kdtree_eval(c, p, a, n, param));
+	return maybe_sync(c);
+}
+int nbco_fmm_traceless(nbco_ctx *c, float *p, float *a, long long n, const float *param)
+{
+	(void)p; (void)a; (void)n; (void)param;
+	return c ? c->fail(NBCO_ERR_UNSUPPORTED, "nbco_fmm_traceless: the octree-traceless evaluator is not built yet") : NBCO_ERR_ARG;
+}
+
+static int eval_kind(nbco_ctx *c, int kind, float *p, float *a, long long n, const float *param)
+{
+	switch (kind)
+	{
+	case NBCO_EVAL_DIRECT: return launch_direct(c, p, a, n, param, false);
+	case NBCO_EVAL_DIRECT_KAHAN: return launch_direct(c, p, a, n, param, true);
+	case NBCO_EVAL_FMM_KDTREE: return fmm_kdtree_eval(c, p, a, n, param);
+	case NBCO_EVAL_FMM_TRACELESS: return nbco_fmm_traceless(c, p, a, n, param);
+	default: return c->fail(NBCO_ERR_ARG, "unknown evaluator kind");
+	}
+}
+
+int nbco_force(nbco_ctx *c, int kind, float *buf, long long n, const float *param, int elastic)
+{
+	if (!c || !buf || !param || n <= 0) return c ? c->fail(NBCO_ERR_ARG, "nbco_force: bad arguments") : NBCO_ERR_ARG;
+	float *x = buf, *a = buf + 6 * n;
+	NBCO_TRY(eval_kind(c, kind, x, a, n, param));
+	if (elastic)
+	{
+		PhaseScope ph(c, NBCO_PH_AXPY);
+		NBCO_TRY(launch_add_elastic(c, x, a, n, param + 3, false));
+	}
+	return maybe_sync(c);
+}
+
+// integrator.cuh:32-167.  K(s): v += a*s, D(s): x += v*s, F: a = f(x) (+ elastic term).  The step
+// coefficients are formed in long double and narrowed to float at the step call, as the
+// reference does at its step_func call sites.
+int nbco_integrate(nbco_ctx *c, int scheme, int kind, float *buf, long long n, const float *param, double dt_, double scale_,
+                   int elastic)
+{
+	if (!c || !buf || !param || n <= 0) return c ? c->fail(NBCO_ERR_ARG, "nbco_integrate: bad arguments") : NBCO_ERR_ARG;
+	float *x = buf, *v = buf + 3 * n, *a = buf + 6 * n;
+	const long long n3 = 3 * n;
+	const long double dt = dt_, scale = scale_;
+	auto K = [&](long double s) { PhaseScope ph(c, NBCO_PH_AXPY); return launch_step(c, v, a, (float)s, n3); };
+	auto D = [&](long double s) { PhaseScope ph(c, NBCO_PH_AXPY); return launch_step(c, x, v, (float)s, n3); };
+	auto F = [&]() {
+		NBCO_TRY(eval_kind(c, kind, x, a, n, param));
+		if (elastic)
+		{
+			PhaseScope ph(c, NBCO_PH_AXPY);
+			NBCO_TRY(launch_add_elastic(c, x, a, n, param + 3, false));
+		}
+		return (int)NBCO_OK;
+	};
+	const long double th = 1.3512071919596576340476878089715L;   // integrator.cuh:98
+	const long double xi = +0.1786178958448091E+00L, la = -0.2123418310626054E+00L, ch = -0.6626458266981849E-01L;  // :130-132
+	switch (scheme)
+	{
+	case NBCO_INTEG_EULER:
+		NBCO_TRY(K(dt * scale)); NBCO_TRY(D(dt)); NBCO_TRY(F());
+		break;
+	case NBCO_INTEG_PRE_EULER:
+		NBCO_TRY(F()); NBCO_TRY(K(dt * scale)); NBCO_TRY(D(dt));
+		break;
+	case NBCO_INTEG_LEAPFROG:
+	{
+		long double ds = dt * scale * 0.5L;
+		{
+			// K(ds) D(dt) fused into one pass over x, v, a
+			PhaseScope ph(c, NBCO_PH_AXPY);
+			NBCO_TRY(launch_kick_drift(c, x, v, a, (float)ds, (float)dt, n3));
+		}
+		NBCO_TRY(F());
+		NBCO_TRY(K(ds));
+		break;
+	}
+	case NBCO_INTEG_FORESTRUTH:
+	{
+		long double ds = dt * scale;
+		NBCO_TRY(D(dt * th / 2)); NBCO_TRY(F());
+		NBCO_TRY(K(ds * th)); NBCO_TRY(D(dt * (1 - th) / 2)); NBCO_TRY(F());
+		NBCO_TRY(K(ds * (1 - 2 * th))); NBCO_TRY(D(dt * (1 - th) / 2)); NBCO_TRY(F());
+		NBCO_TRY(K(ds * th)); NBCO_TRY(D(dt * th / 2));
+		break;
+	}
+	case NBCO_INTEG_PEFRL:
+	{
+		long double ds = dt * scale;
+		NBCO_TRY(D(dt * xi)); NBCO_TRY(F());
+		NBCO_TRY(K(ds * (1 - 2 * la) / 2)); NBCO_TRY(D(dt * ch)); NBCO_TRY(F());
+		NBCO_TRY(K(ds * la)); NBCO_TRY(D(dt * (1 - 2 * (ch + xi)))); NBCO_TRY(F());
+		NBCO_TRY(K(ds * la)); NBCO_TRY(D(dt * ch)); NBCO_TRY(F());
+		NBCO_TRY(K(ds * (1 - 2 * la) / 2)); NBCO_TRY(D(dt * xi));
+		break;
+	}
+	default:
+		return c->fail(NBCO_ERR_ARG, "unknown integrator scheme");
+	}
+	return maybe_sync(c);
+}
+
+// ---- reductions --------------------------------------------------------------------------------
+int nbco_minmax(nbco_ctx *c, const float *p, long long n, float *minmax6_dev)
+{
+	if (!c || !p || !minmax6_dev) return c ? c->fail(NBCO_ERR_ARG, "nbco_minmax: null pointer") : NBCO_ERR_ARG;
+	NBCO_TRY(launch_minmax(c, p, n, minmax6_dev));
+	return maybe_sync(c);
+}
+int nbco_mean_relerr(nbco_ctx *c, const float *x, const float *ref, long long n, float *out_host)
+{
+	if (!c || !x || !ref || !out_host) return c ? c->fail(NBCO_ERR_ARG, "nbco_mean_relerr: null pointer") : NBCO_ERR_ARG;
+	return launch_mean_relerr(c, x, ref, n, out_host);
+}
+int nbco_pow_sum(nbco_ctx *c, const float *x, int expo, long long n, double *out3_host)
+{
+	if (!c || !x || !out3_host) return c ? c->fail(NBCO_ERR_ARG, "nbco_pow_sum: null pointer") : NBCO_ERR_ARG;
+	return launch_pow_sum(c, x, expo, n, out3_host);
+}
+int nbco_energy(nbco_ctx *c, const float *buf, long long n, const float *param, double *out3_host)
+{
+	if (!c || !buf || !param || !out3_host) return c ? c->fail(NBCO_ERR_ARG, "nbco_energy: null pointer") : NBCO_ERR_ARG;
+	return launch_energy(c, buf, n, param, out3_host);
+}
+
+// ---- introspection -----------------------------------------------------------------------------
+int nbco_kd_get_info(nbco_ctx *c, nbco_kd_info *info)
+{
+	if (!c || !info) return NBCO_ERR_ARG;
+	*info = c->info;
+	return NBCO_OK;
+}
+int nbco_kd_copy(nbco_ctx *c, int which, void *host_dst, long long host_bytes)
+{
+	if (!c || !host_dst) return NBCO_ERR_ARG;
+	return kd_copy_out(c, which, host_dst, host_bytes);
+}
+
+// ---- profiling ---------------------------------------------------------------------------------
+int nbco_profile_enable(nbco_ctx *c, int on)
+{
+	if (!c) return NBCO_ERR_ARG;
+	c->profiling = on != 0;
+	return NBCO_OK;
+}
+static int drain_timers(nbco_ctx *c)
+{
+	NBCO_HIP(hipStreamSynchronize(c->stream));
+	for (auto &t : c->timers)
+	{
+		for (auto &ev : t.pending)
+		{
+			float ms = 0.f;
+			if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) { t.total_ms += ms; t.launches += 1; }
+			hipEventDestroy(ev.first);
+			hipEventDestroy(ev.second);
+		}
+		t.pending.clear();
+	}
+	return NBCO_OK;
+}
+int nbco_profile_reset(nbco_ctx *c)
+{
+	if (!c) return NBCO_ERR_ARG;
+	NBCO_TRY(drain_timers(c));
+	for (auto &t : c->timers) { t.total_ms = 0; t.launches = 0; }
+	return NBCO_OK;
+}
+int nbco_profile_get(nbco_ctx *c, int phase, double *total_ms, long long *launches)
+{
+	if (!c || phase < 0 || phase >= NBCO_PH_COUNT) return NBCO_ERR_ARG;
+	NBCO_TRY(drain_timers(c));
+	if (total_ms) *total_ms = c->timers[phase].total_ms;
+	if (launches) *launches = c->timers[phase].launches;
+	return NBCO_OK;
+}
+
+} // extern "C"

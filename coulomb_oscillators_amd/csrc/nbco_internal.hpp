@@ -1,0 +1,135 @@
+// nbco_internal.hpp -- context, error plumbing and launch declarations shared by the HIP
+// translation units of libnbco_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/nbco.h"
+
+#define NBCO_HIP(call)                                                                           \
+	do {                                                                                         \
+		hipError_t e_ = (call);                                                                  \
+		if (e_ != hipSuccess) return c->fail_hip(e_, #call, __FILE__, __LINE__);                 \
+	} while (0)
+
+#define NBCO_TRY(call)                   \
+	do {                                 \
+		int rc_ = (call);                \
+		if (rc_ != NBCO_OK) return rc_;  \
+	} while (0)
+
+// device buffer that only grows (the reference's evaluators keep their scratch in function-local
+// statics that grow monotonically, fmm_cart3_kdtree.cuh:1480-1498)
+struct DevBuf
+{
+	void *ptr = nullptr;
+	size_t bytes = 0;
+	template <class T> T *as() const { return (T *)ptr; }
+};
+
+struct PhaseTimer
+{
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+	double total_ms = 0;
+	long long launches = 0;
+};
+
+constexpr int kMaxOrder = 10;
+
+// kd-tree state in HBM (fmmTree_kd of fmm_cart3_kdtree.cuh:25-31, plus the packed arrays the
+// gfx950 kernels read)
+struct KdTreeDev
+{
+	int L = 0, ntot = 0, order = 0, mlt_max = 0;
+	long long n = 0;
+	float *center = nullptr, *lbound = nullptr, *rbound = nullptr;   // [ntot][3]
+	float4 *csz = nullptr;                                           // [ntot] centre xyz + box diagonal^2
+	float *mpole = nullptr, *local = nullptr;                        // [ntot][offM], [ntot][offL]
+	int *mult = nullptr, *index = nullptr, *splitdim = nullptr;      // [ntot]
+};
+
+struct nbco_ctx
+{
+	nbco_opts o;
+	hipStream_t stream = nullptr;
+	std::string err;
+	int device = 0;
+	int num_cu = 256;
+
+	// generic scratch
+	DevBuf pos4;          // float4[n] packed positions (xyz, 0)
+	DevBuf pos4_alt;      // second buffer for gathers
+	DevBuf part;          // partial results of reductions / direct j-splits
+	DevBuf small;         // a few hundred bytes of device scalars
+	DevBuf tmp3;          // float[3n] scratch for gathers of xyz triplets
+	// kd-tree build
+	DevBuf keys, keys_alt, idx, idx_alt, unsort, unsort_alt, sort_tmp;
+	DevBuf treebuf;
+	KdTreeDev kd;
+	// traversal and interaction lists
+	DevBuf frontier_a, frontier_b, p2p_list, m2l_list, counters;
+	DevBuf p2p_keys, p2p_keys_alt, m2l_keys, m2l_keys_alt, p2p_start, m2l_start;
+	long long list_cap = 0;
+	// operator tables
+	DevBuf tables;
+	int tables_order = 0;
+	std::vector<int> h_tab_off;   // offsets of the sub-tables inside `tables`
+	// bookkeeping of the last evaluation
+	nbco_kd_info info{};
+	long long eval_counter = 0;
+	bool tree_valid = false;
+	long long tree_n = 0;
+	int tree_order = 0;
+	// profiling
+	bool profiling = false;
+	PhaseTimer timers[NBCO_PH_COUNT];
+
+	int fail(int code, const std::string &msg) { err = msg; return code; }
+	int fail_hip(hipError_t e, const char *what, const char *file, int line)
+	{
+		char buf[512];
+		snprintf(buf, sizeof buf, "HIP error: %s (%s) at %s:%d", hipGetErrorString(e), what, file, line);
+		err = buf;
+		return NBCO_ERR_HIP;
+	}
+	int reserve(DevBuf &b, size_t bytes);
+	void phase_begin(int ph);
+	void phase_end(int ph);
+};
+
+struct PhaseScope
+{
+	nbco_ctx *c;
+	int ph;
+	PhaseScope(nbco_ctx *c_, int ph_) : c(c_), ph(ph_) { c->phase_begin(ph); }
+	~PhaseScope() { c->phase_end(ph); }
+};
+
+static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- launchers implemented in the kernel translation units -------------------------------------
+// k_axpy.hip
+int launch_step(nbco_ctx *c, float *b, const float *a, float ds, long long n3);
+int launch_add_elastic(nbco_ctx *c, const float *p, float *a, long long n, const float *k, bool assign);
+int launch_rescale(nbco_ctx *c, float *a, long long n3, const float *param);
+int launch_gather3(nbco_ctx *c, float *dst, const float *src, const int *map, long long n, bool inverse);
+int launch_copy(nbco_ctx *c, float *dst, const float *src, long long n3);
+int launch_pack4(nbco_ctx *c, float4 *dst, const float *src3, long long n);
+// fused integrator pieces
+int launch_kick_drift(nbco_ctx *c, float *x, float *v, const float *a, float ks, float ds, long long n3);
+int launch_finish_kick(nbco_ctx *c, const float *x, float *v, float *a, const float *param, float ks, long long n,
+                       bool elastic);
+// k_direct.hip
+int launch_direct(nbco_ctx *c, const float *p, float *a, long long n, const float *param, bool kahan);
+// k_reduce.hip
+int launch_minmax(nbco_ctx *c, const float *p3, long long n, float *out6_dev);
+int launch_minmax4(nbco_ctx *c, const float4 *p4, long long n, float *out6_dev);
+int launch_mean_relerr(nbco_ctx *c, const float *x, const float *ref, long long n, float *out_host);
+int launch_pow_sum(nbco_ctx *c, const float *x, int expo, long long n, double *out3_host);
+int launch_energy(nbco_ctx *c, const float *buf, long long n, const float *param, double *out3_host);
+// k_fmm_kd.hip
+int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *param);
+int kd_copy_out(nbco_ctx *c, int which, void *host_dst, long long host_bytes);

@@ -1,0 +1,266 @@
+"""ctypes binding of libnbco_hip.so (include/nbco.h).
+
+Host-side mirror of the reference's function-pointer interface for this path:
+
+    evaluator   void f(VEC *p, VEC *a, int n, const SCAL *param)      direct.cuh:233, fmm_cart3_kdtree.cuh:1478
+    step        void step(VEC *b, const VEC *a, SCAL ds, int n)       kernel.cuh:100
+    integrator  void leapfrog(f, SCAL *buf, int n, param, dt, step_func, scale)   integrator.cuh:68
+
+Tensors are PyTorch CUDA(=HIP) tensors; only their device pointers cross the C ABI.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libnbco_hip.so")
+
+EVAL_DIRECT, EVAL_DIRECT_KAHAN, EVAL_FMM_KDTREE, EVAL_FMM_TRACELESS = 0, 1, 2, 3
+INTEG_EULER, INTEG_PRE_EULER, INTEG_LEAPFROG, INTEG_FORESTRUTH, INTEG_PEFRL = 0, 1, 2, 3, 4
+PHASES = ["build", "p2m_m2m", "traverse", "lists", "p2p", "m2l", "l2l", "l2p", "finish", "direct", "axpy"]
+
+KD_FIELDS = {"mult": 0, "index": 1, "splitdim": 2, "center": 3, "lbound": 4, "rbound": 5,
+             "mpole": 6, "local": 7, "p2p": 8, "m2l": 9, "unsort": 10}
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class Opts(C.Structure):
+    _fields_ = [("fmm_order", C.c_int), ("tree_radius", C.c_float), ("eps2", C.c_float), ("coll", C.c_int),
+                ("unsort", C.c_int), ("dens_inhom", C.c_float), ("tree_L", C.c_int), ("tree_steps", C.c_int),
+                ("m2l_first", C.c_int), ("sync", C.c_int), ("list_factor", C.c_int), ("stream", C.c_void_p)]
+
+
+class KdInfo(C.Structure):
+    _fields_ = [("L", C.c_int), ("ntot", C.c_int), ("order", C.c_int), ("mlt_max", C.c_int), ("n", C.c_longlong),
+                ("p2p_pairs", C.c_longlong), ("m2l_pairs", C.c_longlong), ("directed_p2p", C.c_longlong),
+                ("rebuilt", C.c_int)]
+
+
+def lib_path():
+    return _LIB
+
+
+def build_library(force=False):
+    """Compile csrc/*.hip for gfx950 into libnbco_hip.so (hipcc cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    cmd = ["make", "-C", csrc, "-s", "-j8"]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd)
+    return _LIB
+
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB):
+        raise EngineError("libnbco_hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                          "there is no CPU fallback")
+    L = C.CDLL(_LIB)
+    P, LL, I, F, D = C.c_void_p, C.c_longlong, C.c_int, C.c_float, C.c_double
+    sig = {
+        "nbco_opts_default": [C.POINTER(Opts)],
+        "nbco_create": [C.POINTER(P), C.POINTER(Opts)],
+        "nbco_destroy": [P],
+        "nbco_set_opts": [P, C.POINTER(Opts)],
+        "nbco_get_opts": [P, C.POINTER(Opts)],
+        "nbco_sync": [P],
+        "nbco_step": [P, P, P, F, LL],
+        "nbco_add_elastic": [P, P, P, LL, P],
+        "nbco_elastic": [P, P, P, LL, P],
+        "nbco_rescale": [P, P, LL, P],
+        "nbco_gather": [P, P, P, P, LL],
+        "nbco_gather_inverse": [P, P, P, P, LL],
+        "nbco_copy": [P, P, P, LL],
+        "nbco_direct": [P, P, P, LL, P],
+        "nbco_direct3": [P, P, P, LL, P],
+        "nbco_fmm_kdtree": [P, P, P, LL, P],
+        "nbco_fmm_traceless": [P, P, P, LL, P],
+        "nbco_force": [P, I, P, LL, P, I],
+        "nbco_integrate": [P, I, I, P, LL, P, D, D, I],
+        "nbco_minmax": [P, P, LL, P],
+        "nbco_mean_relerr": [P, P, P, LL, C.POINTER(F)],
+        "nbco_pow_sum": [P, P, I, LL, C.POINTER(D)],
+        "nbco_energy": [P, P, LL, P, C.POINTER(D)],
+        "nbco_kd_get_info": [P, C.POINTER(KdInfo)],
+        "nbco_kd_copy": [P, I, P, LL],
+        "nbco_profile_enable": [P, I],
+        "nbco_profile_reset": [P],
+        "nbco_profile_get": [P, I, C.POINTER(D), C.POINTER(LL)],
+    }
+    for name, args in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = I
+    L.nbco_last_error.argtypes = [P]
+    L.nbco_last_error.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def default_opts(**kw):
+    o = Opts()
+    _load().nbco_opts_default(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class Engine:
+    """One nbco context bound to the current torch HIP device and stream."""
+
+    def __init__(self, stream=None, **opts):
+        import torch
+        self.lib = _load()
+        if not torch.cuda.is_available():
+            raise EngineError("no HIP device visible to PyTorch; the engine has no CPU fallback")
+        self.torch = torch
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        o = default_opts(**opts)
+        o.stream = stream
+        self.ctx = C.c_void_p()
+        rc = self.lib.nbco_create(C.byref(self.ctx), C.byref(o))
+        if rc != 0:
+            raise EngineError("nbco_create failed with status %d" % rc)
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.nbco_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise EngineError("nbco status %d: %s" % (rc, self.lib.nbco_last_error(self.ctx).decode()))
+
+    # ---- options --------------------------------------------------------------------------------
+    def opts(self):
+        o = Opts()
+        self._chk(self.lib.nbco_get_opts(self.ctx, C.byref(o)))
+        return o
+
+    def set(self, **kw):
+        o = self.opts()
+        for k, v in kw.items():
+            setattr(o, k, v)
+        self._chk(self.lib.nbco_set_opts(self.ctx, C.byref(o)))
+
+    def sync(self):
+        self._chk(self.lib.nbco_sync(self.ctx))
+
+    # ---- basic kernels --------------------------------------------------------------------------
+    def step(self, b, a, ds, n=None):
+        n = b.numel() // 3 if n is None else n
+        self._chk(self.lib.nbco_step(self.ctx, _ptr(b), _ptr(a), ds, n))
+
+    def add_elastic(self, p, a, n, k=None):
+        self._chk(self.lib.nbco_add_elastic(self.ctx, _ptr(p), _ptr(a), n, _ptr(k)))
+
+    def elastic(self, p, a, n, k=None):
+        self._chk(self.lib.nbco_elastic(self.ctx, _ptr(p), _ptr(a), n, _ptr(k)))
+
+    def rescale(self, a, n, param):
+        self._chk(self.lib.nbco_rescale(self.ctx, _ptr(a), n, _ptr(param)))
+
+    def gather(self, dst, src, idx, n):
+        self._chk(self.lib.nbco_gather(self.ctx, _ptr(dst), _ptr(src), _ptr(idx), n))
+
+    def gather_inverse(self, dst, src, idx, n):
+        self._chk(self.lib.nbco_gather_inverse(self.ctx, _ptr(dst), _ptr(src), _ptr(idx), n))
+
+    def copy(self, dst, src, n):
+        self._chk(self.lib.nbco_copy(self.ctx, _ptr(dst), _ptr(src), n))
+
+    # ---- evaluators: f(p, a, n, param) -----------------------------------------------------------
+    def direct(self, p, a, n, param=None):
+        self._chk(self.lib.nbco_direct(self.ctx, _ptr(p), _ptr(a), n, _ptr(param)))
+
+    def direct3(self, p, a, n, param=None):
+        self._chk(self.lib.nbco_direct3(self.ctx, _ptr(p), _ptr(a), n, _ptr(param)))
+
+    def fmm_cart3_kdtree(self, p, a, n, param=None):
+        self._chk(self.lib.nbco_fmm_kdtree(self.ctx, _ptr(p), _ptr(a), n, _ptr(param)))
+
+    def fmm_cart3_traceless(self, p, a, n, param=None):
+        self._chk(self.lib.nbco_fmm_traceless(self.ctx, _ptr(p), _ptr(a), n, _ptr(param)))
+
+    def compute_force(self, kind, buf, n, param, elastic=True):
+        self._chk(self.lib.nbco_force(self.ctx, kind, _ptr(buf), n, _ptr(param), int(elastic)))
+
+    def integrate(self, scheme, kind, buf, n, param, dt, scale=1.0, elastic=True):
+        self._chk(self.lib.nbco_integrate(self.ctx, scheme, kind, _ptr(buf), n, _ptr(param), dt, scale, int(elastic)))
+
+    # ---- reductions -----------------------------------------------------------------------------
+    def minmax(self, p, n):
+        out = self.torch.empty(6, dtype=self.torch.float32, device=p.device)
+        self._chk(self.lib.nbco_minmax(self.ctx, _ptr(p), n, _ptr(out)))
+        return out.view(2, 3)
+
+    def mean_relerr(self, x, ref, n):
+        out = C.c_float()
+        self._chk(self.lib.nbco_mean_relerr(self.ctx, _ptr(x), _ptr(ref), n, C.byref(out)))
+        return out.value
+
+    def pow_sum(self, x, expo, n):
+        out = (C.c_double * 3)()
+        self._chk(self.lib.nbco_pow_sum(self.ctx, _ptr(x), expo, n, out))
+        return list(out)
+
+    def energy(self, buf, n, param):
+        out = (C.c_double * 3)()
+        self._chk(self.lib.nbco_energy(self.ctx, _ptr(buf), n, _ptr(param), out))
+        return list(out)
+
+    # ---- kd-tree introspection ------------------------------------------------------------------
+    def kd_info(self):
+        info = KdInfo()
+        self._chk(self.lib.nbco_kd_get_info(self.ctx, C.byref(info)))
+        return info
+
+    def kd_array(self, name):
+        import numpy as np
+        info = self.kd_info()
+        p = info.order
+        offM, offL = p * (p + 1) * (p + 2) // 6, (p + 1) ** 2
+        shapes = {"mult": ((info.ntot,), np.int32), "index": ((info.ntot,), np.int32), "splitdim": ((info.ntot,), np.int32),
+                  "center": ((info.ntot, 3), np.float32), "lbound": ((info.ntot, 3), np.float32),
+                  "rbound": ((info.ntot, 3), np.float32), "mpole": ((info.ntot, offM), np.float32),
+                  "local": ((info.ntot, offL), np.float32), "p2p": ((info.p2p_pairs, 2), np.int32),
+                  "m2l": ((info.m2l_pairs, 2), np.int32), "unsort": ((info.n,), np.int32)}
+        shape, dt = shapes[name]
+        out = np.empty(shape, dtype=dt)
+        if out.size:
+            self._chk(self.lib.nbco_kd_copy(self.ctx, KD_FIELDS[name], out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
+
+    # ---- profiling ------------------------------------------------------------------------------
+    def profile(self, on=True):
+        self._chk(self.lib.nbco_profile_enable(self.ctx, int(on)))
+
+    def profile_reset(self):
+        self._chk(self.lib.nbco_profile_reset(self.ctx))
+
+    def profile_get(self):
+        out = {}
+        for i, name in enumerate(PHASES):
+            ms, cnt = C.c_double(), C.c_longlong()
+            self._chk(self.lib.nbco_profile_get(self.ctx, i, C.byref(ms), C.byref(cnt)))
+            out[name] = (ms.value, cnt.value)
+        return out

@@ -1,0 +1,154 @@
+/* nbco.h -- C ABI of libnbco_hip.so, the MI355X (gfx950) force / integrate engine that drops in
+ * behind the reference's evaluator / step / integrator function-pointer interface
+ * (locuoco/coulomb_oscillators @ 2024_08_07, Simulation/).
+ *
+ * Conventions (they mirror the reference's GPU path):
+ *   - every `p`, `a`, `b`, `buf`, `param` argument is a DEVICE pointer (main3.cu:699-704);
+ *   - positions / velocities / accelerations are fp32 xyz triplets with a 12-byte stride, and a
+ *     state buffer is [pos n | vel n | acc n] (kernel.cuh:67, integrator.cuh:24, main3.cu:655-657);
+ *   - `param` is the 6-float array {xi/N, 0, 0, kx, ky, kz} of main3.cu:685-692; evaluators use
+ *     param[0], the elastic term uses param+3;
+ *   - evaluators overwrite `a`; tree evaluators may permute `p` (and then `p + 3n`, the
+ *     velocities) unless opts.unsort is set (fmm_cart3_kdtree.cuh:1746-1760);
+ *   - the reference's mutable globals (constants.cuh:36-52) become the explicit nbco_opts;
+ *   - instead of gpuErrchk's exit() (kernel.cuh:52-65) every entry point returns an int status
+ *     (0 = success) and nbco_last_error() gives the message;
+ *   - work is enqueued on opts.stream; with opts.sync != 0 an evaluator returns after the stream
+ *     has drained, as the reference's evaluators do (direct.cuh:243-244,
+ *     fmm_cart3_kdtree.cuh:1762-1763).
+ * There is no CPU fallback: every entry point fails with NBCO_ERR_HIP when no HIP device is usable.
+ */
+#ifndef NBCO_H
+#define NBCO_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nbco_ctx nbco_ctx;
+
+enum {
+	NBCO_OK = 0,
+	NBCO_ERR_HIP = 1,        /* a HIP runtime call failed (message in nbco_last_error) */
+	NBCO_ERR_ARG = 2,        /* invalid argument */
+	NBCO_ERR_CAPACITY = 3,   /* interaction-list / traversal-frontier capacity exceeded
+	                            (reference: printf + clamp, fmm_cart3_kdtree.cuh:552-566) */
+	NBCO_ERR_UNSUPPORTED = 4
+};
+
+/* force evaluators: which f(p, a, n, param) an integrator or nbco_force drives */
+enum {
+	NBCO_EVAL_DIRECT = 0,         /* direct.cuh:104 `direct` / :171 `direct2` (LDS-tiled all pairs) */
+	NBCO_EVAL_DIRECT_KAHAN = 1,   /* direct.cuh:233 `direct3` (compensated accumulation) */
+	NBCO_EVAL_FMM_KDTREE = 2,     /* fmm_cart3_kdtree.cuh:1478 `fmm_cart3_kdtree` */
+	NBCO_EVAL_FMM_TRACELESS = 3   /* fmm_cart3_traceless.cuh:282 `fmm_cart3_traceless` */
+};
+
+/* integrators of integrator.cuh:32-167 */
+enum {
+	NBCO_INTEG_EULER = 0,       /* symplectic_euler      :32 */
+	NBCO_INTEG_PRE_EULER = 1,   /* pre_symplectic_euler  :50 */
+	NBCO_INTEG_LEAPFROG = 2,    /* leapfrog              :68 */
+	NBCO_INTEG_FORESTRUTH = 3,  /* forestruth            :100 */
+	NBCO_INTEG_PEFRL = 4        /* pefrl                 :134 */
+};
+
+typedef struct nbco_opts {
+	int   fmm_order;    /* constants.cuh:42 fmm_order, 1..10 */
+	float tree_radius;  /* constants.cuh:43 tree_radius (used as given; the reference's CPU driver
+	                       truncates it to int, fmm_cart3_kdtree.cuh:1775 -- callers that want that
+	                       behaviour pass an integer value) */
+	float eps2;         /* constants.cuh:39 EPS2 (softening squared) */
+	int   coll;         /* constants.cuh:48 coll: 0 skips the P2P pass */
+	int   unsort;       /* constants.cuh:48 b_unsort: restore the caller's particle order */
+	float dens_inhom;   /* constants.cuh:50 dens_inhom */
+	int   tree_L;       /* constants.cuh:44 tree_L (0 = derive from n and order) */
+	int   tree_steps;   /* constants.cuh:45 tree_steps: rebuild the kd-tree every this many
+	                       evaluations when unsort == 0.  1 = every evaluation, which is what the
+	                       reference's CPU driver does (fmm_cart3_kdtree.cuh:1773-1929). */
+	int   m2l_first;    /* 0: leaf-leaf pairs go to P2P before the admissibility test (reference CPU
+	                       traversal, fmm_cart3_kdtree.cuh:586-598); 1: admissibility first
+	                       (reference GPU traversal <true>, :520-534) */
+	int   sync;         /* != 0: evaluators return after the stream has drained */
+	int   list_factor;  /* capacity of the P2P / M2L lists and of the traversal frontier, in units
+	                       of the node count (reference: 1000, fmm_cart3_kdtree.cuh:1584-1586) */
+	void *stream;       /* hipStream_t; NULL = the null stream */
+} nbco_opts;
+
+/* reference defaults (constants.cuh:36-52), tree_steps = 1, m2l_first = 0, sync = 1 */
+int nbco_opts_default(nbco_opts *o);
+
+int nbco_create(nbco_ctx **out, const nbco_opts *o);   /* owns all scratch, like the reference's
+                                                           function-local statics */
+int nbco_destroy(nbco_ctx *c);
+int nbco_set_opts(nbco_ctx *c, const nbco_opts *o);
+int nbco_get_opts(const nbco_ctx *c, nbco_opts *o);
+const char *nbco_last_error(const nbco_ctx *c);
+int nbco_sync(nbco_ctx *c);
+
+/* ---- basic kernels (kernel.cuh, appel.cuh) -------------------------------------------------- */
+int nbco_step(nbco_ctx *c, float *b, const float *a, float ds, long long n);              /* kernel.cuh:100 step: b += a*ds */
+int nbco_add_elastic(nbco_ctx *c, const float *p, float *a, long long n, const float *k);  /* kernel.cuh:145 add_elastic: a -= k o p (k == NULL: a -= p) */
+int nbco_elastic(nbco_ctx *c, const float *p, float *a, long long n, const float *k);      /* kernel.cuh:198 elastic: a = -k o p */
+int nbco_rescale(nbco_ctx *c, float *a, long long n, const float *param);                  /* appel.cuh:514 rescale: a *= param[0] */
+int nbco_gather(nbco_ctx *c, float *dst, const float *src, const int *map, long long n);          /* kernel.cuh:229 dst[i] = src[map[i]] (xyz triplets) */
+int nbco_gather_inverse(nbco_ctx *c, float *dst, const float *src, const int *map, long long n);  /* kernel.cuh:255 dst[map[i]] = src[i] */
+int nbco_copy(nbco_ctx *c, float *dst, const float *src, long long n);                            /* kernel.cuh:281 */
+
+/* ---- force evaluators: void f(VEC *p, VEC *a, int n, const SCAL *param) --------------------- */
+int nbco_direct(nbco_ctx *c, const float *p, float *a, long long n, const float *param);   /* direct.cuh:104,171 */
+int nbco_direct3(nbco_ctx *c, const float *p, float *a, long long n, const float *param);  /* direct.cuh:233 */
+int nbco_fmm_kdtree(nbco_ctx *c, float *p, float *a, long long n, const float *param);     /* fmm_cart3_kdtree.cuh:1478 */
+int nbco_fmm_traceless(nbco_ctx *c, float *p, float *a, long long n, const float *param);  /* fmm_cart3_traceless.cuh:282 */
+
+/* evaluator `kind` on buf = [pos|vel|acc], followed by add_elastic(param+3) when elastic != 0:
+ * compute_force (integrator.cuh:22) over the coulombOscillator* wrappers of main3.cu:47-69 */
+int nbco_force(nbco_ctx *c, int kind, float *buf, long long n, const float *param, int elastic);
+
+/* one step of integrator `scheme` with evaluator `kind` (+ elastic term), integrator.cuh:32-167.
+ * dt and scale are the reference's long double arguments narrowed to double. */
+int nbco_integrate(nbco_ctx *c, int scheme, int kind, float *buf, long long n, const float *param,
+                   double dt, double scale, int elastic);
+
+/* ---- reductions (reductions.cuh) -------------------------------------------------------------- */
+int nbco_minmax(nbco_ctx *c, const float *p, long long n, float *minmax6_dev);           /* reductions.cuh:67 minmaxReduce2 */
+int nbco_mean_relerr(nbco_ctx *c, const float *x, const float *ref, long long n, float *out_host);  /* reductions.cuh:99 relerrReduce2 (intent) */
+int nbco_pow_sum(nbco_ctx *c, const float *x, int expo, long long n, double *out3_host);  /* reductions.cuh:590 powReduce */
+/* total energy {kinetic, elastic, coulomb}; no reference counterpart */
+int nbco_energy(nbco_ctx *c, const float *buf, long long n, const float *param, double *out3_host);
+
+/* ---- introspection of the last kd-tree evaluation (parity tests, benchmarks) ----------------- */
+typedef struct nbco_kd_info {
+	int L, ntot, order, mlt_max;
+	long long n;
+	long long p2p_pairs;        /* unordered leaf pairs in the P2P list */
+	long long m2l_pairs;        /* unordered node pairs in the M2L list */
+	long long directed_p2p;     /* sum 2*m1*m2 over the list + sum m^2 over leaves */
+	int rebuilt;                /* the last evaluation rebuilt the tree */
+} nbco_kd_info;
+int nbco_kd_get_info(nbco_ctx *c, nbco_kd_info *info);
+
+enum {
+	NBCO_KD_MULT = 0, NBCO_KD_INDEX = 1, NBCO_KD_SPLITDIM = 2,   /* int[ntot] */
+	NBCO_KD_CENTER = 3, NBCO_KD_LBOUND = 4, NBCO_KD_RBOUND = 5,  /* float[ntot][3] */
+	NBCO_KD_MPOLE = 6,   /* float[ntot][offM], offM = p(p+1)(p+2)/6 */
+	NBCO_KD_LOCAL = 7,   /* float[ntot][offL], offL = (p+1)^2 */
+	NBCO_KD_P2P_LIST = 8, NBCO_KD_M2L_LIST = 9,                  /* int[pairs][2], unordered */
+	NBCO_KD_UNSORT = 10  /* int[n]: tree position -> caller's index */
+};
+int nbco_kd_copy(nbco_ctx *c, int which, void *host_dst, long long host_bytes);
+
+/* ---- per-phase device timing (HIP events on the context's stream) ---------------------------- */
+enum {
+	NBCO_PH_BUILD = 0, NBCO_PH_P2M_M2M = 1, NBCO_PH_TRAVERSE = 2, NBCO_PH_LISTS = 3, NBCO_PH_P2P = 4,
+	NBCO_PH_M2L = 5, NBCO_PH_L2L = 6, NBCO_PH_L2P = 7, NBCO_PH_FINISH = 8, NBCO_PH_DIRECT = 9,
+	NBCO_PH_AXPY = 10, NBCO_PH_COUNT = 11
+};
+int nbco_profile_enable(nbco_ctx *c, int on);       /* records a pair of events around each phase */
+int nbco_profile_reset(nbco_ctx *c);
+int nbco_profile_get(nbco_ctx *c, int phase, double *total_ms, long long *launches);  /* syncs */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBCO_H */
