@@ -11,7 +11,7 @@ def force_err(a, ref):
     a = np.asarray(a, dtype=np.float64).reshape(-1, 3)
     ref = np.asarray(ref, dtype=np.float64).reshape(-1, 3)
     mag = np.linalg.norm(ref, axis=1)
-    return float((np.linalg.norm(a - ref, axis=1) / (mag + mag.mean())).max())
+    return float((np.linalg.norm(a - ref, axis=1) / (mag + mag.mean() + 1e-300)).max())
 
 
 def directed_pairs(mult, p2p, L):
