@@ -4,6 +4,7 @@
 #include "nbco_internal.hpp"
 #include <cmath>
 #include <new>
+#include "fmm_tables.hpp"
 
 int nbco_ctx::reserve(DevBuf &b, size_t bytes)
 {
@@ -382,6 +383,26 @@ int nbco_profile_get(nbco_ctx *c, int phase, double *total_ms, long long *launch
 	NBCO_TRY(drain_timers(c));
 	if (total_ms) *total_ms = c->timers[phase].total_ms;
 	if (launches) *launches = c->timers[phase].launches;
+	return NBCO_OK;
+}
+
+int nbco_debug_table(int order, const char *name, void *out, long long cap, long long *count)
+{
+	if (order < 1 || order > kMaxOrder || !name || !count) return NBCO_ERR_ARG;
+	fmmtab::Tables t = fmmtab::build(order);
+	std::string s(name);
+	const void *src = nullptr;
+	long long n = 0;
+	bool found = false;
+#define NBCO_TAB(field) if (s == #field) { src = t.field.data(); n = (long long)t.field.size(); found = true; }
+	NBCO_TAB(sym_xyz) NBCO_TAB(mono_rec) NBCO_TAB(p2m_coef) NBCO_TAB(m2m_start) NBCO_TAB(m2m_idx) NBCO_TAB(m2m_coef)
+	NBCO_TAB(tl2full) NBCO_TAB(tl_order) NBCO_TAB(gp_start) NBCO_TAB(gp_exp) NBCO_TAB(gp_coef) NBCO_TAB(rf_start)
+	NBCO_TAB(rf_dst) NBCO_TAB(rf_a) NBCO_TAB(rf_b) NBCO_TAB(m2l_start) NBCO_TAB(m2l_idx) NBCO_TAB(m2l_coef)
+	NBCO_TAB(m_order) NBCO_TAB(l2l_start) NBCO_TAB(l2l_idx) NBCO_TAB(l2l_coef) NBCO_TAB(l2p_coef) NBCO_TAB(l2p_idx)
+#undef NBCO_TAB
+	if (!found) return NBCO_ERR_ARG;
+	*count = n;
+	if (out && src && n > 0) memcpy(out, src, (size_t)(n < cap ? n : cap) * 4);
 	return NBCO_OK;
 }
 

@@ -148,6 +148,12 @@ int nbco_profile_enable(nbco_ctx *c, int on);       /* records a pair of events 
 int nbco_profile_reset(nbco_ctx *c);
 int nbco_profile_get(nbco_ctx *c, int phase, double *total_ms, long long *launches);  /* syncs */
 
+/* ---- operator tables (host only, no GPU needed) ------------------------------------------------
+ * Copies the flattened coefficient / index table `name` for expansion order `order` into `out`
+ * (int32 or float32 elements, at most `cap` of them) and stores the element count in *count.
+ * Lets the table-driven FMM operators be checked against the oracle on a machine without a GPU. */
+int nbco_debug_table(int order, const char *name, void *out, long long cap, long long *count);
+
 #ifdef __cplusplus
 }
 #endif
