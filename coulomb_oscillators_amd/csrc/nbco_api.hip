@@ -338,6 +338,13 @@ int nbco_energy(nbco_ctx *c, const float *buf, long long n, const float *param, 
 int nbco_kd_get_info(nbco_ctx *c, nbco_kd_info *info)
 {
 	if (!c || !info) return NBCO_ERR_ARG;
+	if (c->info.directed_p2p < 0 && c->counters.ptr && c->tree_valid)
+	{
+		unsigned long long v = 0;
+		NBCO_HIP(hipStreamSynchronize(c->stream));
+		NBCO_HIP(hipMemcpy(&v, c->counters.as<int>() + 100, sizeof v, hipMemcpyDeviceToHost));
+		c->info.directed_p2p = (long long)v;
+	}
 	*info = c->info;
 	return NBCO_OK;
 }
