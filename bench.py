@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X N-body Coulomb-oscillator engine.
+
+Metric (BASELINE.json): particle-steps/sec (+ Gpair-interactions/sec), N = 1M FMM-3D p = 6.
+
+A "step" is one leapfrog step (integrator.cuh:68-96) of the whole particle set with the kd-tree FMM
+evaluator + elastic term (coulombOscillatorFMMKD3, main3.cu:59-63), i.e. K(dt/2) D(dt) F K(dt/2),
+with the tree rebuilt on every evaluation (the reference CPU driver's behaviour) unless --tree-steps
+says otherwise.  Inputs are the reference's synthetic Gaussian ball (main3.cu:662-664) resident in
+HBM before the timed region.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_VECTOR_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (vector)"
+FLOP_PER_PAIR = 20                   # one directed pair interaction = 20 flop
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=1048576, help="particles per GPU")
+    ap.add_argument("--order", type=int, default=6)
+    ap.add_argument("--tree-steps", type=int, default=1)
+    ap.add_argument("--workload", default="fmm_kd", choices=["fmm_kd", "direct"])
+    ap.add_argument("--dt", type=float, default=5e-4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--profile-all", action="store_true", help="record HIP events around every phase (perturbs value)")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, n):
+    """The oracle (a port of the reference's multithreaded CPU path) on a bounded sample of the same workload."""
+    from oracle import pyoracle as po
+    o = po.Oracle(np.float32)
+    cores = min(os.cpu_count() or 1, 16)
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    buf = o.init_reference(n)
+    par = o.params(n)
+    if args.workload == "fmm_kd":
+        kind, kw = po.KIND_FMM_KD, dict(p=args.order, unsort=False, threads=cores)
+        steps = args.cpu_steps
+        sample = "%d leapfrog steps of N=%d kd-tree FMM p=%d (+1 warm-up), %d std::threads" % (steps, n, args.order, cores)
+        o.compute_force(kind, buf, par, **kw)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            o.integrate(po.SCHEME_LEAPFROG, kind, buf, par, args.dt, **kw)
+        dt = time.perf_counter() - t0
+        return {"value": n * steps / dt, "unit": "particle-steps/s", "cores": cores, "kind": "port", "sample": sample}
+    # direct: rows are independent, time a slice of the targets against all sources
+    ns = min(n, 32768)
+    sub = buf[:, :ns].copy()
+    t0 = time.perf_counter()
+    o.direct3(sub[0], par, threads=cores)
+    dt = time.perf_counter() - t0
+    rate = ns * ns / dt                     # pair interactions / s
+    return {"value": rate / n, "unit": "particle-steps/s", "cores": cores, "kind": "port",
+            "sample": "direct3 on N=%d (pair rate %.3g/s scaled to N=%d), %d std::threads" % (ns, rate, n, cores)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from coulomb_oscillators_amd import Engine, EVAL_DIRECT, EVAL_FMM_KDTREE, INTEG_LEAPFROG
+    from oracle import pyoracle as po          # initial conditions only (reference RNG stream) + cpu_baseline
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    n = args.n
+    o = po.Oracle(np.float32)
+    # every rank owns an independent shard of n particles: same distribution, different seed stream
+    buf = o.init_reference(n, discard=po.REF_DISCARD + 7919 * rank)
+    par = o.params(n)
+    d = torch.from_numpy(buf).cuda()
+    prm = torch.from_numpy(par).cuda()
+
+    kind = EVAL_FMM_KDTREE if args.workload == "fmm_kd" else EVAL_DIRECT
+    eng = Engine(fmm_order=args.order, unsort=0, tree_steps=args.tree_steps, sync=0)
+    dom = "p2p" if args.workload == "fmm_kd" else "direct"
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    eng.compute_force(kind, d, n, prm)          # precompute accelerations (main3.cu:836-839)
+    for _ in range(args.warmup):
+        eng.integrate(INTEG_LEAPFROG, kind, d, n, prm, args.dt)
+    eng.profile(True if args.profile_all else [dom])
+    eng.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.integrate(INTEG_LEAPFROG, kind, d, n, prm, args.dt)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = eng.profile_get()
+    eng.profile(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if args.workload == "fmm_kd":
+        info = eng.kd_info()
+        pairs_per_eval = int(info.directed_p2p)
+        extra = {"L": info.L, "p2p_pairs": int(info.p2p_pairs), "m2l_pairs": int(info.m2l_pairs)}
+    else:
+        pairs_per_eval = n * n
+        extra = {}
+    assert torch.isfinite(d).all(), "non-finite state after the timed steps"
+
+    value = world * n * args.steps / elapsed
+    out = {
+        "metric": "particle-steps/sec (+ Gpair-interactions/sec), N=1M FMM-3D p=6",
+        "value": value,
+        "unit": "particle-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "gpair_per_s": world * pairs_per_eval * args.steps / elapsed / 1e9,
+        "config": {"workload": ("FMM-3D kd-tree p=%d, N=%d per GPU, leapfrog, Gaussian ball, tree rebuilt every %d step(s)"
+                                % (args.order, n, args.tree_steps)) if args.workload == "fmm_kd"
+                   else "direct O(N^2) 3D, N=%d per GPU, leapfrog" % n,
+                   "n_per_gpu": n, "order": args.order, "dt": args.dt, "parallelism": "kd-domain shards x%d" % world, **extra},
+    }
+    if rank == 0:
+        ms, launches = prof[dom]
+        if launches:
+            avg_s = ms * 1e-3 / launches
+            ach = pairs_per_eval * FLOP_PER_PAIR / avg_s / 1e12
+            out["roofline"] = {"bound": "valu_fp32", "kernel": "p2p_kernel" if dom == "p2p" else "direct_tiles",
+                               "achieved": ach, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / FP32_VECTOR_PEAK_TFLOPS, "traffic": None,
+                               "pairs_per_launch": pairs_per_eval, "avg_launch_ms": avg_s * 1e3, "flop_per_pair": FLOP_PER_PAIR}
+        if args.profile_all:
+            out["phase_ms_per_step"] = {k: v[0] / args.steps for k, v in prof.items() if v[1]}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, n)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -26,7 +26,7 @@ int nbco_ctx::reserve(DevBuf &b, size_t bytes)
 
 void nbco_ctx::phase_begin(int ph)
 {
-	if (!profiling) return;
+	if (!(profiling & (1u << ph))) return;
 	hipEvent_t a, b;
 	if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
 	hipEventRecord(a, stream);
@@ -35,7 +35,7 @@ void nbco_ctx::phase_begin(int ph)
 
 void nbco_ctx::phase_end(int ph)
 {
-	if (!profiling || timers[ph].pending.empty()) return;
+	if (!(profiling & (1u << ph)) || timers[ph].pending.empty()) return;
 	hipEventRecord(timers[ph].pending.back().second, stream);
 }
 
@@ -358,7 +358,7 @@ int nbco_kd_copy(nbco_ctx *c, int which, void *host_dst, long long host_bytes)
 int nbco_profile_enable(nbco_ctx *c, int on)
 {
 	if (!c) return NBCO_ERR_ARG;
-	c->profiling = on != 0;
+	c->profiling = on < 0 ? 0xFFFFFFFFu : (unsigned)on;
 	return NBCO_OK;
 }
 static int drain_timers(nbco_ctx *c)

@@ -84,7 +84,7 @@ struct nbco_ctx
 	long long tree_n = 0;
 	int tree_order = 0;
 	// profiling
-	bool profiling = false;
+	unsigned profiling = 0;   // bit i set: record events around phase i
 	PhaseTimer timers[NBCO_PH_COUNT];
 
 	int fail(int code, const std::string &msg) { err = msg; return code; }

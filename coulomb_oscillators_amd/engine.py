@@ -251,8 +251,17 @@ class Engine:
         return out
 
     # ---- profiling ------------------------------------------------------------------------------
-    def profile(self, on=True):
-        self._chk(self.lib.nbco_profile_enable(self.ctx, int(on)))
+    def profile(self, phases=True):
+        """phases: True = all, False = off, or an iterable of phase names (see PHASES)."""
+        if phases is True:
+            mask = -1
+        elif not phases:
+            mask = 0
+        else:
+            mask = 0
+            for name in phases:
+                mask |= 1 << PHASES.index(name)
+        self._chk(self.lib.nbco_profile_enable(self.ctx, mask))
 
     def profile_reset(self):
         self._chk(self.lib.nbco_profile_reset(self.ctx))

@@ -144,7 +144,7 @@ enum {
 	NBCO_PH_M2L = 5, NBCO_PH_L2L = 6, NBCO_PH_L2P = 7, NBCO_PH_FINISH = 8, NBCO_PH_DIRECT = 9,
 	NBCO_PH_AXPY = 10, NBCO_PH_COUNT = 11
 };
-int nbco_profile_enable(nbco_ctx *c, int on);       /* records a pair of events around each phase */
+int nbco_profile_enable(nbco_ctx *c, int mask);     /* bit i: record a pair of events around phase i; -1 = all, 0 = off */
 int nbco_profile_reset(nbco_ctx *c);
 int nbco_profile_get(nbco_ctx *c, int phase, double *total_ms, long long *launches);  /* syncs */
 
