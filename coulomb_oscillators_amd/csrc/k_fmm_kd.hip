@@ -996,8 +996,16 @@ int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 	// ---- M2L, L2L ---------------------------------------------------------------------------------------
 	{
 		PhaseScope ph(c, NBCO_PH_M2L);
-		hipLaunchKernelGGL(m2l_kernel, dim3(ntot), dim3(64), 0, st, tv, tb, (const uint64_t *)c->m2l_keys_alt.as<uint64_t>(),
-		                   (const int *)c->m2l_start.as<int>(), shift, c->o.eps2);
+		if (P <= 8)
+		{
+			// register-resident generated bodies, one interaction per lane (k_m2l.hip)
+			NBCO_HIP(hipMemsetAsync(tv.local, 0, sizeof(float) * (size_t)ntot * offL, st));
+			if (dm2l > 0)
+				NBCO_TRY(launch_m2l_lanes(c, P, tv.csz, tv.mpole, tv.local, c->m2l_keys_alt.as<uint64_t>(), c->m2l_start.as<int>(), shift, ntot));
+		}
+		else
+			hipLaunchKernelGGL(m2l_kernel, dim3(ntot), dim3(64), 0, st, tv, tb, (const uint64_t *)c->m2l_keys_alt.as<uint64_t>(),
+			                   (const int *)c->m2l_start.as<int>(), shift, c->o.eps2);
 		NBCO_HIP(hipGetLastError());
 	}
 	{

@@ -1,0 +1,131 @@
+// k_m2l.hip -- register-resident M2L for the kd-tree FMM (reference: fmm_c2c3_kdtree_krnl host
+// branch, fmm_cart3_kdtree.cuh:613-671; operator fmm_cart_base3.cuh:1181-1208).
+//
+// Mapping: the directed (target, source) list is sorted by target, so a wave owns kTargets consecutive
+// target nodes = one contiguous slice of the list.  Each LANE evaluates one whole interaction with the
+// generated straight-line body (m2l_gen.inc: ~650 fma at p = 6, everything in VGPRs), the 64
+// contributions are transposed through LDS, and lane c walks the rows in list order accumulating
+// component c of the current target; a target's local expansion is stored exactly once, by one lane
+// per component, in a fixed order: no atomics, bit-reproducible.
+#include "nbco_internal.hpp"
+
+namespace {
+
+template <int P>
+__device__ __forceinline__ void m2l_body(const float *__restrict__ Mp, float ux, float uy, float uz, float rinv,
+                                         float (&L)[(P + 1) * (P + 1) - 1]);
+
+#include "m2l_gen.inc"
+
+constexpr int kTargets = 8;   // target nodes per wave
+
+template <int P>
+__global__ __launch_bounds__(64) void m2l_lane_kernel(const float4 *__restrict__ csz, const float *__restrict__ mpole,
+                                                      float *__restrict__ local, const uint64_t *__restrict__ keys,
+                                                      const int *__restrict__ start, int shift, int ntot, float eps2)
+{
+	constexpr int offM = P * (P + 1) * (P + 2) / 6, offL = (P + 1) * (P + 1), NOUT = offL - 1;
+	constexpr int CPL = (NOUT + 63) / 64;   // components per lane in the reduction walk
+	__shared__ float buf[64][NOUT + 1 + (NOUT % 2)];   // odd row stride: conflict-free column writes
+	__shared__ int tg[64];
+	const int lane = threadIdx.x;
+	const int t0 = blockIdx.x * kTargets, t1 = min(t0 + kTargets, ntot);
+	const int i0 = start[t0], i1 = start[t1];
+	const uint64_t mask = (1ull << shift) - 1;
+	float acc[CPL];
+#pragma unroll
+	for (int q = 0; q < CPL; ++q) acc[q] = 0.f;
+	int cur = -1;
+	for (int base = i0; base < i1; base += 64)
+	{
+		const int i = base + lane;
+		int tgt = -1;
+		float L[NOUT];
+		if (i < i1)
+		{
+			const uint64_t key = keys[i];
+			tgt = (int)(key >> shift);
+			const int src = (int)(key & mask);
+			const float4 ct = csz[tgt], cs = csz[src];
+			float dx = ct.x - cs.x, dy = ct.y - cs.y, dz = ct.z - cs.z;
+			const float r = sqrtf(dx * dx + dy * dy + dz * dz + eps2);
+			const float rinv = 1.f / r;
+			m2l_body<P>(mpole + (size_t)src * offM, dx * rinv, dy * rinv, dz * rinv, rinv, L);
+		}
+		else
+		{
+#pragma unroll
+			for (int c = 0; c < NOUT; ++c) L[c] = 0.f;
+		}
+#pragma unroll
+		for (int c = 0; c < NOUT; ++c) buf[lane][c] = L[c];
+		tg[lane] = tgt;
+		__syncthreads();
+		const int rows = min(64, i1 - base);
+		for (int r = 0; r < rows; ++r)
+		{
+			const int t = tg[r];
+			if (t != cur)
+			{
+				if (cur >= 0)
+				{
+#pragma unroll
+					for (int q = 0; q < CPL; ++q)
+					{
+						const int c = lane + 64 * q;
+						if (c < NOUT) local[(size_t)cur * offL + 1 + c] = acc[q];
+					}
+				}
+#pragma unroll
+				for (int q = 0; q < CPL; ++q) acc[q] = 0.f;
+				cur = t;
+			}
+#pragma unroll
+			for (int q = 0; q < CPL; ++q)
+			{
+				const int c = lane + 64 * q;
+				if (c < NOUT) acc[q] += buf[r][c];
+			}
+		}
+		__syncthreads();
+	}
+	if (cur >= 0)
+	{
+#pragma unroll
+		for (int q = 0; q < CPL; ++q)
+		{
+			const int c = lane + 64 * q;
+			if (c < NOUT) local[(size_t)cur * offL + 1 + c] = acc[q];
+		}
+	}
+}
+
+template <int P>
+static void launch(nbco_ctx *c, const float4 *csz, const float *mpole, float *local, const uint64_t *keys, const int *start, int shift,
+                   int ntot)
+{
+	const int grid = (ntot + kTargets - 1) / kTargets;
+	hipLaunchKernelGGL(m2l_lane_kernel<P>, dim3(grid), dim3(64), 0, c->stream, csz, mpole, local, keys, start, shift, ntot, c->o.eps2);
+}
+
+} // namespace
+
+// targets without sources are never visited: `local` must be zero-filled by the caller.
+int launch_m2l_lanes(nbco_ctx *c, int P, const float4 *csz, const float *mpole, float *local, const uint64_t *keys, const int *start,
+                     int shift, int ntot)
+{
+	switch (P)
+	{
+	case 1: launch<1>(c, csz, mpole, local, keys, start, shift, ntot); break;
+	case 2: launch<2>(c, csz, mpole, local, keys, start, shift, ntot); break;
+	case 3: launch<3>(c, csz, mpole, local, keys, start, shift, ntot); break;
+	case 4: launch<4>(c, csz, mpole, local, keys, start, shift, ntot); break;
+	case 5: launch<5>(c, csz, mpole, local, keys, start, shift, ntot); break;
+	case 6: launch<6>(c, csz, mpole, local, keys, start, shift, ntot); break;
+	case 7: launch<7>(c, csz, mpole, local, keys, start, shift, ntot); break;
+	case 8: launch<8>(c, csz, mpole, local, keys, start, shift, ntot); break;
+	default: return c->fail(NBCO_ERR_UNSUPPORTED, "launch_m2l_lanes: order not generated");
+	}
+	NBCO_HIP(hipGetLastError());
+	return NBCO_OK;
+}

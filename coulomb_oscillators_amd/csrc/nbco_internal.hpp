@@ -133,3 +133,6 @@ int launch_energy(nbco_ctx *c, const float *buf, long long n, const float *param
 // k_fmm_kd.hip
 int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *param);
 int kd_copy_out(nbco_ctx *c, int which, void *host_dst, long long host_bytes);
+// k_m2l.hip
+int launch_m2l_lanes(nbco_ctx *c, int P, const float4 *csz, const float *mpole, float *local, const uint64_t *keys, const int *start,
+                     int shift, int ntot);
