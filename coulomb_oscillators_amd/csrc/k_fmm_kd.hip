@@ -490,58 +490,131 @@ __global__ __launch_bounds__(kBlock) void pair_count_kernel(TreeView t, const ui
 }
 
 // ---- P2P ---------------------------------------------------------------------------------------------
-// One wave per target leaf.  TPL lanes cover the leaf's targets, the 64/TPL lane groups walk different
-// source leaves of the sorted list concurrently; each group stages its source leaf in LDS and reads
-// it back as a group-uniform ds_read_b128 broadcast.  Result is stored (not accumulated): no atomics.
+// source descriptors of the sorted directed list: first particle and multiplicity of every source leaf,
+// so the pair kernel does no dependent index -> mult -> position loads
+__global__ __launch_bounds__(kBlock) void p2p_srcdesc_kernel(TreeView t, const uint64_t *__restrict__ keys, long long count, int shift,
+                                                             int2 *__restrict__ desc)
+{
+	const uint64_t mask = (1ull << shift) - 1;
+	const int beg = kd_beg(t.L);
+	for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < count; i += (long long)gridDim.x * kBlock)
+	{
+		const int src = beg + (int)(keys[i] & mask);
+		desc[i] = make_int2(t.index[src], t.mult[src]);
+	}
+}
+
+// Work units.  The number of source leaves per target leaf is very uneven (Gaussian ball, N = 1M: mean 17,
+// max > 250), so one wave per target leaf leaves a tail as long as the rest of the kernel.  Every
+// target leaf's sorted source range is therefore cut into chunks of at most kP2PChunk entries; a wave
+// evaluates one chunk and stores the partial sums of its 32 targets, and the L2P kernel adds a leaf's
+// chunks in list order (fixed order: still bit-reproducible, still no atomics).
+constexpr int kP2PChunk = 16;
+
+__global__ __launch_bounds__(kBlock) void p2p_chunk_count_kernel(const int *__restrict__ start, int nleaf, int *__restrict__ cnt)
+{
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i <= nleaf; i += gridDim.x * kBlock)
+		cnt[i] = i < nleaf ? max(1, (start[i + 1] - start[i] + kP2PChunk - 1) / kP2PChunk) : 0;
+}
+
+__global__ __launch_bounds__(kBlock) void p2p_chunk_fill_kernel(const int *__restrict__ start, const int *__restrict__ off, int nleaf,
+                                                                int4 *__restrict__ chunk)
+{
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < nleaf; i += gridDim.x * kBlock)
+	{
+		const int b = start[i], e = start[i + 1], o = off[i], n = off[i + 1] - o;
+		for (int k = 0; k < n; ++k) chunk[o + k] = make_int4(i, min(b + k * kP2PChunk, e), min(b + (k + 1) * kP2PChunk, e), 0);
+	}
+}
+
+// One wave per chunk.  TPL lanes cover the leaf's targets, the 64/TPL lane groups walk different source
+// leaves of the chunk concurrently.  Source descriptors are fetched once (one per lane) and handed out
+// with shuffles; each group's source tile is prefetched into registers while the previous tile is being
+// consumed, staged in a double-buffered LDS tile and read back as group-uniform ds_read_b128
+// broadcasts.  Slots beyond a source leaf hold a far point whose r^-3 underflows to exactly 0 (3e36 <
+// FLT_MAX, (3e36)^-3/2 ~ 2e-55 -> 0): the pair loop needs no predicate.
+// LDS hand-off between lanes of ONE wave: DS operations of a wave execute in order, so only the compiler
+// has to be kept from reordering them (no s_barrier: the waves of a block work on different chunks; a
+// fence or __syncthreads here would also drain vmcnt and with it the prefetched tile).
+__device__ __forceinline__ void wave_lds_sync()
+{
+	asm volatile("" ::: "memory");
+	__builtin_amdgcn_wave_barrier();
+	asm volatile("" ::: "memory");
+}
+
+#define P2P_PAIR(PX, PY, PZ)                                               \
+	{                                                                      \
+		float dx = pi.x - (PX), dy = pi.y - (PY), dz = pi.z - (PZ);        \
+		float r2 = fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, eps2)));         \
+		float ri = __builtin_amdgcn_rsqf(r2);                              \
+		float ri3 = ri * ri * ri;                                          \
+		ax = fmaf(dx, ri3, ax);                                            \
+		ay = fmaf(dy, ri3, ay);                                            \
+		az = fmaf(dz, ri3, az);                                            \
+	}
+
+constexpr int kP2PWaves = 4;   // waves (= chunks) per 256-thread block; 64-thread blocks would cap a CU at 8 waves
+
 template <int TPL>
-__global__ __launch_bounds__(64) void p2p_kernel(TreeView t, const float4 *__restrict__ pos, const uint64_t *__restrict__ keys,
-                                                 const int *__restrict__ start, int shift, float eps2, int mlt_max,
-                                                 float4 *__restrict__ acc_out)
+__global__ __launch_bounds__(64 * kP2PWaves) void p2p_kernel(TreeView t, const float4 *__restrict__ pos, const int2 *__restrict__ desc,
+                                                             const int4 *__restrict__ chunk, const int *__restrict__ nchunks_total,
+                                                             float eps2, int mlt_max, float4 *__restrict__ partial)
 {
 	constexpr int G = 64 / TPL;
-	__shared__ float4 tile[G][TPL];
-	const int leaf = blockIdx.x, lane = threadIdx.x, g = lane / TPL, li = lane % TPL;
-	const int node = kd_beg(t.L) + leaf;
+	// source tiles as packed xyz triplets: four sources are read with three ds_read_b128 and every loaded
+	// dword is used (a float4-per-source tile is narrowed to ds_read_b96 by hipcc, twice the LDS cycles)
+	__shared__ __attribute__((aligned(16))) float tile_all[kP2PWaves][2][G][3 * TPL];
+	const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane / TPL, li = lane % TPL;
+	const int cid = blockIdx.x * kP2PWaves + wv;
+	if (cid >= *nchunks_total) return;
+	float(*tile)[G][3 * TPL] = tile_all[wv];
+	const int4 ck = chunk[cid];
+	const int node = kd_beg(t.L) + ck.x;
 	const int it = t.index[node], mt = t.mult[node];
-	const int s_beg = start[leaf], s_end = start[leaf + 1];
-	const uint64_t mask = (1ull << shift) - 1;
+	const int nent = ck.z - ck.y;
+	const int nchunk = (mlt_max + TPL - 1) / TPL;
+	const float4 far = make_float4(1.e18f, 1.e18f, 1.e18f, 0.f);
+	const int2 mine = (lane < nent) ? desc[ck.y + lane] : make_int2(0, 0);
+	const int ntile = (nent + G - 1) / G;
+	// tile (et, jc) covers entry et * G + g, source particles jc * TPL + li
+	auto fetch = [&](int et, int jc) -> float4 {
+		const int ent = et * G + g;
+		const int is = __shfl(mine.x, ent), ms = __shfl(mine.y, ent);
+		const int j = jc * TPL + li;
+		return (ent < nent && j < ms) ? pos[is + j] : far;
+	};
 
 	for (int tb = 0; tb < mt; tb += TPL)
 	{
 		const int ti = tb + li;
 		const float4 pi = pos[it + (ti < mt ? ti : mt - 1)];
 		float ax = 0.f, ay = 0.f, az = 0.f;
-		for (int s0 = s_beg; s0 < s_end; s0 += G)
+		if (ntile > 0)
 		{
-			const int s = s0 + g;
-			int is = 0, ms = 0;
-			if (s < s_end)
-			{
-				int src = kd_beg(t.L) + (int)(keys[s] & mask);
-				is = t.index[src];
-				ms = t.mult[src];
-			}
-			for (int jb = 0; jb < mlt_max; jb += TPL)
-			{
-				__syncthreads();
-				// slots beyond the source leaf are padded with a far point: r^-3 underflows to exactly 0
-				// there (1e18^2 * 3 < FLT_MAX, (3e36)^-3/2 ~ 2e-55 -> 0), so the pair loop needs no predicate
-				tile[g][li] = (jb + li < ms) ? pos[is + jb + li] : make_float4(1.e18f, 1.e18f, 1.e18f, 0.f);
-				__syncthreads();
-#pragma unroll 4
-				for (int j = 0; j < TPL; ++j)
+			float4 cur = fetch(0, 0);
+			int b = 0;
+			for (int et = 0; et < ntile; ++et)
+				for (int jc = 0; jc < nchunk; ++jc)
 				{
-					const float4 pj = tile[g][j];
-					asm volatile("" ::"v"(pj.w));   // keep .w live: ds_read_b128 instead of ds_read_b96
-					float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-					float r2 = fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, eps2)));
-					float ri = __builtin_amdgcn_rsqf(r2);
-					float ri3 = ri * ri * ri;
-					ax = fmaf(dx, ri3, ax);
-					ay = fmaf(dy, ri3, ay);
-					az = fmaf(dz, ri3, az);
+					tile[b][g][3 * li] = cur.x; tile[b][g][3 * li + 1] = cur.y; tile[b][g][3 * li + 2] = cur.z;
+					int jn = jc + 1, en = et;
+					if (jn == nchunk) { jn = 0; ++en; }
+					if (en < ntile) cur = fetch(en, jn);
+					wave_lds_sync();
+					const float4 *t4 = reinterpret_cast<const float4 *>(tile[b][g]);
+#pragma unroll 2
+					for (int q4 = 0; q4 < TPL / 4; ++q4)
+					{
+						const float4 A = t4[3 * q4], B = t4[3 * q4 + 1], C = t4[3 * q4 + 2];
+						P2P_PAIR(A.x, A.y, A.z)
+						P2P_PAIR(A.w, B.x, B.y)
+						P2P_PAIR(B.z, B.w, C.x)
+						P2P_PAIR(C.y, C.z, C.w)
+					}
+					wave_lds_sync();
+					b ^= 1;
 				}
-			}
 		}
 #pragma unroll
 		for (int o = TPL; o < 64; o <<= 1)
@@ -550,7 +623,7 @@ __global__ __launch_bounds__(64) void p2p_kernel(TreeView t, const float4 *__res
 			ay += __shfl_xor(ay, o);
 			az += __shfl_xor(az, o);
 		}
-		if (g == 0 && ti < mt) acc_out[it + ti] = make_float4(ax, ay, az, 0.f);
+		if (g == 0 && ti < mt) partial[(size_t)cid * mlt_max + ti] = make_float4(ax, ay, az, 0.f);
 	}
 }
 
@@ -660,8 +733,8 @@ __global__ __launch_bounds__(64) void l2l_kernel(TreeView t, DevTables tb, int l
 // fmm_cart_base3.cuh:1511-1529); adds the near-field sum, applies rescale (appel.cuh:506-512) and writes
 // either in tree order or scattered back to the caller's order (fmm_cart3_kdtree.cuh:1746-1754)
 __global__ __launch_bounds__(64) void l2p_kernel(TreeView t, DevTables tb, const float4 *__restrict__ pos, const float4 *__restrict__ near,
-                                                 const int *__restrict__ unsort, int scatter, const float *__restrict__ param,
-                                                 float *__restrict__ a_out, int have_near)
+                                                 const int *__restrict__ chunk_off, int mlt_max, const int *__restrict__ unsort,
+                                                 int scatter, const float *__restrict__ param, float *__restrict__ a_out, int have_near)
 {
 	extern __shared__ float lds[];
 	float *F = lds;                       // nfull
@@ -705,8 +778,14 @@ __global__ __launch_bounds__(64) void l2p_kernel(TreeView t, DevTables tb, const
 			}
 			if (have_near)
 			{
-				const float4 nr = near[ind + j];
-				fx += nr.x; fy += nr.y; fz += nr.z;
+				// near field: the leaf's P2P chunks in list order
+				float nx = 0.f, ny = 0.f, nz = 0.f;
+				for (int ck = chunk_off[blockIdx.x]; ck < chunk_off[blockIdx.x + 1]; ++ck)
+				{
+					const float4 nr = near[(size_t)ck * mlt_max + j];
+					nx += nr.x; ny += nr.y; nz += nr.z;
+				}
+				fx += nx; fy += ny; fz += nz;
 			}
 			const long long o = scatter ? (long long)unsort[ind + j] : (long long)(ind + j);
 			a_out[3 * o] = fx * scale; a_out[3 * o + 1] = fy * scale; a_out[3 * o + 2] = fz * scale;
@@ -815,10 +894,12 @@ static int sort_keys_u64(nbco_ctx *c, uint64_t *kin, uint64_t *kout, long long n
 }
 
 template <int TPL>
-static void launch_p2p(nbco_ctx *c, const TreeView &tv, const float4 *pos, const uint64_t *keys, const int *start, int shift, int mlt_max,
-                       float4 *acc)
+static void launch_p2p(nbco_ctx *c, const TreeView &tv, const float4 *pos, const int2 *desc, const int4 *chunk, const int *ntotal,
+                       long long max_chunks, int mlt_max, float4 *partial)
 {
-	hipLaunchKernelGGL(p2p_kernel<TPL>, dim3(kd_cnt(tv.L)), dim3(64), 0, c->stream, tv, pos, keys, start, shift, c->o.eps2, mlt_max, acc);
+	int grid = (int)((max_chunks + kP2PWaves - 1) / kP2PWaves);
+	hipLaunchKernelGGL(p2p_kernel<TPL>, dim3(grid), dim3(64 * kP2PWaves), 0, c->stream, tv, pos, desc, chunk, ntotal, c->o.eps2, mlt_max,
+	                   partial);
 }
 
 } // namespace
@@ -857,7 +938,6 @@ int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 	}
 	NBCO_TRY(c->reserve(c->pos4, sizeof(float4) * (size_t)n));
 	NBCO_TRY(c->reserve(c->pos4_alt, sizeof(float4) * (size_t)n));
-	NBCO_TRY(c->reserve(c->part, sizeof(float4) * (size_t)n));
 	NBCO_TRY(c->reserve(c->unsort, sizeof(int) * (size_t)n));
 	NBCO_TRY(c->reserve(c->unsort_alt, sizeof(int) * (size_t)n));
 	NBCO_TRY(c->reserve(c->keys, sizeof(uint64_t) * (size_t)n));
@@ -949,6 +1029,7 @@ int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 	const long long np2p = h_cnt[0], nm2l = h_cnt[1];
 	const int shift = L + 1;
 	const long long dp2p = c->o.coll ? 2 * np2p + nleaf : 0, dm2l = 2 * nm2l;
+	long long max_chunks = 0;
 	// ---- directed sorted lists --------------------------------------------------------------------------
 	{
 		PhaseScope ph(c, NBCO_PH_LISTS);
@@ -967,6 +1048,26 @@ int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 			                   c->p2p_start.as<int>());
 			hipLaunchKernelGGL(pair_count_kernel, dim3(grid1d(dp2p, 256)), dim3(kBlock), 0, st, tv, (const uint64_t *)c->p2p_keys_alt.as<uint64_t>(),
 			                   dp2p, shift, (unsigned long long *)(c->counters.as<int>() + 100));
+			hipLaunchKernelGGL(p2p_srcdesc_kernel, dim3(grid1d(dp2p)), dim3(kBlock), 0, st, tv, (const uint64_t *)c->p2p_keys_alt.as<uint64_t>(), dp2p,
+			                   shift, c->p2p_keys.as<int2>());
+			// chunked work units: counts -> exclusive scan -> descriptors
+			max_chunks = dp2p / kP2PChunk + nleaf;
+			NBCO_TRY(c->reserve(c->p2p_chunk_cnt, sizeof(int) * (size_t)(nleaf + 2)));
+			NBCO_TRY(c->reserve(c->p2p_chunk_off, sizeof(int) * (size_t)(nleaf + 2)));
+			NBCO_TRY(c->reserve(c->p2p_chunks, sizeof(int4) * (size_t)max_chunks));
+			hipLaunchKernelGGL(p2p_chunk_count_kernel, dim3(grid1d(nleaf + 1)), dim3(kBlock), 0, st, (const int *)c->p2p_start.as<int>(), nleaf,
+			                   c->p2p_chunk_cnt.as<int>());
+			{
+				size_t bytes = 0;
+				NBCO_HIP(rocprim::exclusive_scan(nullptr, bytes, c->p2p_chunk_cnt.as<int>(), c->p2p_chunk_off.as<int>(), 0, (size_t)(nleaf + 1),
+				                                 rocprim::plus<int>(), st));
+				NBCO_TRY(c->reserve(c->sort_tmp, bytes));
+				bytes = c->sort_tmp.bytes;
+				NBCO_HIP(rocprim::exclusive_scan(c->sort_tmp.ptr, bytes, c->p2p_chunk_cnt.as<int>(), c->p2p_chunk_off.as<int>(), 0,
+				                                 (size_t)(nleaf + 1), rocprim::plus<int>(), st));
+			}
+			hipLaunchKernelGGL(p2p_chunk_fill_kernel, dim3(grid1d(nleaf)), dim3(kBlock), 0, st, (const int *)c->p2p_start.as<int>(),
+			                   (const int *)c->p2p_chunk_off.as<int>(), nleaf, c->p2p_chunks.as<int4>());
 		}
 		if (dm2l > 0)
 		{
@@ -981,16 +1082,18 @@ int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 		NBCO_HIP(hipGetLastError());
 	}
 	// ---- P2P --------------------------------------------------------------------------------------------
+	if (dp2p > 0) NBCO_TRY(c->reserve(c->part, sizeof(float4) * (size_t)max_chunks * (size_t)mlt_max));
 	float4 *near = c->part.as<float4>();
 	if (dp2p > 0)
 	{
 		PhaseScope ph(c, NBCO_PH_P2P);
-		const uint64_t *pk = c->p2p_keys_alt.as<uint64_t>();
-		const int *ps = c->p2p_start.as<int>();
-		if (mlt_max <= 8) launch_p2p<8>(c, tv, pos, pk, ps, shift, mlt_max, near);
-		else if (mlt_max <= 16) launch_p2p<16>(c, tv, pos, pk, ps, shift, mlt_max, near);
-		else if (mlt_max <= 32) launch_p2p<32>(c, tv, pos, pk, ps, shift, mlt_max, near);
-		else launch_p2p<64>(c, tv, pos, pk, ps, shift, mlt_max, near);
+		const int2 *pd = c->p2p_keys.as<int2>();   // the unsorted key buffer is reused for the descriptors
+		const int4 *pc = c->p2p_chunks.as<int4>();
+		const int *pt = c->p2p_chunk_off.as<int>() + nleaf;   // total number of chunks
+		if (mlt_max <= 8) launch_p2p<8>(c, tv, pos, pd, pc, pt, max_chunks, mlt_max, near);
+		else if (mlt_max <= 16) launch_p2p<16>(c, tv, pos, pd, pc, pt, max_chunks, mlt_max, near);
+		else if (mlt_max <= 32) launch_p2p<32>(c, tv, pos, pd, pc, pt, max_chunks, mlt_max, near);
+		else launch_p2p<64>(c, tv, pos, pd, pc, pt, max_chunks, mlt_max, near);
 		NBCO_HIP(hipGetLastError());
 	}
 	// ---- M2L, L2L ---------------------------------------------------------------------------------------
@@ -1017,8 +1120,8 @@ int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 	{
 		PhaseScope ph(c, NBCO_PH_L2P);
 		size_t lds = (288 + (size_t)std::max(offM, 1) * 64) * sizeof(float);
-		hipLaunchKernelGGL(l2p_kernel, dim3(nleaf), dim3(64), lds, st, tv, tb, (const float4 *)pos, (const float4 *)near, (const int *)unsort,
-		                   c->o.unsort ? 1 : 0, param, a, dp2p > 0 ? 1 : 0);
+		hipLaunchKernelGGL(l2p_kernel, dim3(nleaf), dim3(64), lds, st, tv, tb, (const float4 *)pos, (const float4 *)near,
+		                   (const int *)c->p2p_chunk_off.as<int>(), mlt_max, (const int *)unsort, c->o.unsort ? 1 : 0, param, a, dp2p > 0 ? 1 : 0);
 		NBCO_HIP(hipGetLastError());
 	}
 	{
