@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""gen_ops.py -- emits fmm_ops_gen.inc: straight-line, register-resident P2M / M2M / L2L / L2P bodies for
+orders 1..PMAX (companion of gen_m2l.py).
+
+Reference operators: fmm_cart_base3.cuh P2M :908-918, M2M :1042-1076, L2L :1348-1363, L2P :1511-1529
+(same term lists as csrc/fmm_tables.cpp, which tests/test_tables.py checks against the oracle).  With the
+normalisations
+
+    D~[K] = d^K / K!            M~[X] = M[X] |X|! / X!            L~[X] = L[X] |X|!      (X! = x! y! z!)
+
+every operator is a coefficient-free correlation / convolution, i.e. plain v_fma_f32 chains:
+
+    P2M   M~_q[X]  = (-1)^q sum_particles D~[X]
+    M2M   M~'[X]   = sum_{K <= X} D~[K] M~[X-K]                  (d = new centre - old centre)
+    L2L   L~'_n[X] = sum_{m >= n} sum_{|K| = m-n} D~[K] L~_m[X+K] (d = child - parent)
+    L2P   a_c      = - sum_{K} D~[K] L~_{|K|+1}[e_c + K]          (d = particle - leaf centre)
+
+Arrays in HBM keep the reference's normalisation; the scale factors are literals at load / store.
+Usage: gen_ops.py <out.inc> [PMAX]
+"""
+import sys
+from math import factorial as fact
+
+
+def sym_off(p):
+    return p * (p + 1) * (p + 2) // 6
+
+
+def sym_idx(x, z, n):
+    return (n * (n + 1) - (n - z) * (n - z + 1)) // 2 + n - x
+
+
+def tl_off(p):
+    return p * p
+
+
+def tl_idx(x, z, n):
+    return (z + 1) * n - x
+
+
+def comps(n):
+    """(x, y, z) of every component of a rank-n symmetric tensor in storage order"""
+    return [(x, n - x - z, z) for z in range(n + 1) for x in range(n - z, -1, -1)]
+
+
+def lit(v):
+    return repr(float(v)) + "f"
+
+
+def full(x, y, z):
+    n = x + y + z
+    return sym_off(n) + sym_idx(x, z, n)
+
+
+def emit_monomials(w, pmax_order):
+    """D{i} = d^K / K! for all |K| <= pmax_order (needs dx, dy, dz)"""
+    for a in "xyz":
+        for k in range(2, pmax_order + 1):
+            w("\tconst float d%s_%d = d%s * %s;" % (a, k, a, lit(1.0 / k)))
+    w("\tconst float D0 = 1.0f;")
+    for n in range(1, pmax_order + 1):
+        for (x, y, z) in comps(n):
+            i = full(x, y, z)
+            if x > 0:
+                par, a, k = full(x - 1, y, z), "x", x
+            elif y > 0:
+                par, a, k = full(x, y - 1, z), "y", y
+            else:
+                par, a, k = full(x, y, z - 1), "z", z
+            fac = "d%s" % a if k == 1 else "d%s_%d" % (a, k)
+            w("\tconst float D%d = %s;" % (i, fac) if par == 0 else "\tconst float D%d = D%d * %s;" % (i, par, fac))
+
+
+def emit_expand_local(w, P, src):
+    """F{i} = L~ in the full layout from the traceless tuple `src` (orders 1..P)"""
+    for n in range(1, P + 1):
+        g = {}
+        for z in range(0, min(1, n) + 1):
+            for x in range(n - z, -1, -1):
+                y = n - x - z
+                w("\tconst float F%d = %s[%d] * %s;" % (full(x, y, z), src, tl_off(n) + tl_idx(x, z, n), lit(fact(n))))
+        for z in range(2, n + 1):
+            for x in range(n - z, -1, -1):
+                y = n - x - z
+                w("\tconst float F%d = -(F%d + F%d);" % (full(x, y, z), full(x + 2, y, z - 2), full(x, y + 2, z - 2)))
+
+
+def gen(P, out):
+    w = out.append
+    offM = sym_off(P)
+    offL = tl_off(P + 1)
+    # ---------------------------------------------------------------- P2M
+    w("template <> __device__ __forceinline__ void p2m_accum<%d>(float dx, float dy, float dz, float (&A)[%d])" % (P, max(offM, 1)))
+    w("{")
+    if P >= 3:
+        emit_monomials(w, P - 1)
+        for q in range(2, P):
+            for (x, y, z) in comps(q):
+                i = full(x, y, z)
+                w("\tA[%d] += D%d;" % (i, i))
+    else:
+        w("\t(void)dx; (void)dy; (void)dz; (void)A;")
+    w("}")
+    w("template <> __device__ __forceinline__ void p2m_store<%d>(const float (&A)[%d], float *__restrict__ M)" % (P, max(offM, 1)))
+    w("{")
+    for q in range(2, P):
+        for (x, y, z) in comps(q):
+            i = full(x, y, z)
+            w("\tM[%d] = A[%d] * %s;" % (i, i, lit((-1) ** q * fact(x) * fact(y) * fact(z) / fact(q))))
+    if P < 3:
+        w("\t(void)A; (void)M;")
+    w("}")
+    # ---------------------------------------------------------------- M2M
+    w("template <> __device__ __forceinline__ void m2m_accum<%d>(const float *__restrict__ Mc, float dx, float dy, float dz,"
+      " float (&A)[%d])" % (P, max(offM, 1)))
+    w("{")
+    if P >= 3:
+        emit_monomials(w, P - 1)
+        for k in range(0, P):
+            if k == 1:
+                continue
+            for (x, y, z) in comps(k):
+                i = full(x, y, z)
+                c = fact(k) / (fact(x) * fact(y) * fact(z))
+                w("\tconst float T%d = Mc[%d]%s;" % (i, i, "" if c == 1 else " * " + lit(c)))
+        for n in range(2, P):
+            for (x, y, z) in comps(n):
+                o = full(x, y, z)
+                expr = "A[%d]" % o
+                for k1 in range(x + 1):
+                    for k2 in range(y + 1):
+                        for k3 in range(z + 1):
+                            m = k1 + k2 + k3
+                            if n - m == 1:
+                                continue
+                            expr = "fmaf(D%d, T%d, %s)" % (full(k1, k2, k3), full(x - k1, y - k2, z - k3), expr)
+                w("\tA[%d] = %s;" % (o, expr))
+    else:
+        w("\t(void)Mc; (void)dx; (void)dy; (void)dz; (void)A;")
+    w("}")
+    w("template <> __device__ __forceinline__ void m2m_store<%d>(const float (&A)[%d], float *__restrict__ M)" % (P, max(offM, 1)))
+    w("{")
+    for n in range(2, P):
+        for (x, y, z) in comps(n):
+            o = full(x, y, z)
+            w("\tM[%d] = A[%d] * %s;" % (o, o, lit(fact(x) * fact(y) * fact(z) / fact(n))))
+    if P < 3:
+        w("\t(void)A; (void)M;")
+    w("}")
+    # ---------------------------------------------------------------- L2L
+    w("template <> __device__ __forceinline__ void l2l_body<%d>(const float (&Lp)[%d], float dx, float dy, float dz, float (&O)[%d])"
+      % (P, offL, offL))
+    w("{")
+    emit_monomials(w, P - 1)
+    emit_expand_local(w, P, "Lp")
+    w("\tO[0] = 0.0f;")
+    for n in range(1, P + 1):
+        for z in range(0, min(1, n) + 1):
+            for x in range(n - z, -1, -1):
+                y = n - x - z
+                expr = None
+                for m in range(n, P + 1):
+                    k = m - n
+                    for (kx, ky, kz) in comps(k):
+                        t = "D%d * F%d" % (full(kx, ky, kz), full(x + kx, y + ky, z + kz)) if full(kx, ky, kz) != 0 else "F%d" % full(x, y, z)
+                        if expr is None:
+                            expr = t
+                        else:
+                            expr = "fmaf(D%d, F%d, %s)" % (full(kx, ky, kz), full(x + kx, y + ky, z + kz), expr)
+                w("\tO[%d] = (%s) * %s;" % (tl_off(n) + tl_idx(x, z, n), expr, lit(1.0 / fact(n))))
+    w("}")
+    # ---------------------------------------------------------------- L2P
+    w("template <> __device__ __forceinline__ void l2p_body<%d>(const float (&Lp)[%d], float dx, float dy, float dz, float &fx, float &fy,"
+      " float &fz)" % (P, offL))
+    w("{")
+    emit_monomials(w, P - 1)
+    emit_expand_local(w, P, "Lp")
+    ex = ey = ez = None
+    for q in range(0, P):
+        for (kx, ky, kz) in comps(q):
+            d = full(kx, ky, kz)
+            ix, iy, iz = full(kx + 1, ky, kz), full(kx, ky + 1, kz), full(kx, ky, kz + 1)
+            if d == 0:
+                ex, ey, ez = "F%d" % ix, "F%d" % iy, "F%d" % iz
+            else:
+                ex = "fmaf(D%d, F%d, %s)" % (d, ix, ex)
+                ey = "fmaf(D%d, F%d, %s)" % (d, iy, ey)
+                ez = "fmaf(D%d, F%d, %s)" % (d, iz, ez)
+        # flush per order to keep expressions short
+        w("\tconst float ex%d = %s;" % (q, ex))
+        w("\tconst float ey%d = %s;" % (q, ey))
+        w("\tconst float ez%d = %s;" % (q, ez))
+        ex, ey, ez = "ex%d" % q, "ey%d" % q, "ez%d" % q
+    w("\tfx = -%s; fy = -%s; fz = -%s;" % (ex, ey, ez))
+    w("}")
+    w("")
+
+
+def main():
+    path = sys.argv[1]
+    pmax = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    out = ["// GENERATED by gen_ops.py -- do not edit.  Straight-line P2M / M2M / L2L / L2P bodies, orders 1..%d." % pmax, ""]
+    for P in range(1, pmax + 1):
+        gen(P, out)
+    with open(path, "w") as f:
+        f.write("\n".join(out) + "\n")
+
+
+if __name__ == "__main__":
+    main()

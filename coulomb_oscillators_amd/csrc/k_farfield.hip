@@ -1,0 +1,265 @@
+// k_farfield.hip -- register-resident P2M / M2M / L2L / L2P for the kd-tree FMM, orders 1..8.
+// Reference drivers: fmm_multipoleLeaves3_kdtree (fmm_cart3_kdtree.cuh:231-250), fmm_buildTree3_kdtree2
+// (:328-368), fmm_pushl3_kdtree (:1134-1194), fmm_pushLeaves3_kdtree (:1227-1275).  One THREAD per leaf /
+// node / particle runs a generated straight-line body (fmm_ops_gen.inc, see gen_ops.py): all tensor
+// components live in VGPRs, no LDS, no tables, no index arithmetic.
+//
+// The top of the tree has too few nodes to fill a launch, and every level would cost a kernel boundary:
+// levels with at most kTopNodes nodes are processed by ONE workgroup that walks the levels with
+// __syncthreads(); data it wrote at the previous level is re-read past the L1 (agent-scope loads).
+#include "nbco_internal.hpp"
+
+namespace {
+
+template <int P> __device__ __forceinline__ void p2m_accum(float dx, float dy, float dz, float (&A)[(P * (P + 1) * (P + 2) / 6) > 0 ? (P * (P + 1) * (P + 2) / 6) : 1]);
+template <int P> __device__ __forceinline__ void p2m_store(const float (&A)[(P * (P + 1) * (P + 2) / 6) > 0 ? (P * (P + 1) * (P + 2) / 6) : 1], float *__restrict__ M);
+template <int P> __device__ __forceinline__ void m2m_accum(const float *__restrict__ Mc, float dx, float dy, float dz, float (&A)[(P * (P + 1) * (P + 2) / 6) > 0 ? (P * (P + 1) * (P + 2) / 6) : 1]);
+template <int P> __device__ __forceinline__ void m2m_store(const float (&A)[(P * (P + 1) * (P + 2) / 6) > 0 ? (P * (P + 1) * (P + 2) / 6) : 1], float *__restrict__ M);
+template <int P> __device__ __forceinline__ void l2l_body(const float (&Lp)[(P + 1) * (P + 1)], float dx, float dy, float dz, float (&O)[(P + 1) * (P + 1)]);
+template <int P> __device__ __forceinline__ void l2p_body(const float (&Lp)[(P + 1) * (P + 1)], float dx, float dy, float dz, float &fx, float &fy, float &fz);
+
+#include "fmm_ops_gen.inc"
+
+constexpr int kBlock = 256;
+constexpr int kTopNodes = 256;   // levels with <= this many nodes are fused into one workgroup
+
+__device__ inline float ld_agent(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline int ld_agent(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// ---- P2M: one thread per leaf ----------------------------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(kBlock) void p2m_gen_kernel(const float4 *__restrict__ pos, const float *__restrict__ center,
+                                                         const int *__restrict__ mult, const int *__restrict__ index, float *__restrict__ mpole,
+                                                         int beg, int nleaf)
+{
+	constexpr int offM = P * (P + 1) * (P + 2) / 6;
+	const int i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= nleaf) return;
+	const int leaf = beg + i, mlt = mult[leaf], ind = index[leaf];
+	const float cx = center[3 * leaf], cy = center[3 * leaf + 1], cz = center[3 * leaf + 2];
+	float A[offM > 0 ? offM : 1];
+#pragma unroll
+	for (int k = 0; k < (offM > 0 ? offM : 1); ++k) A[k] = 0.f;
+	for (int j = 0; j < mlt; ++j)
+	{
+		const float4 p = pos[ind + j];
+		p2m_accum<P>(p.x - cx, p.y - cy, p.z - cz, A);
+	}
+	float *M = mpole + (size_t)leaf * offM;
+	if (offM > 0) M[0] = (float)mlt;
+	if (offM > 1) { M[1] = 0.f; M[2] = 0.f; M[3] = 0.f; }
+	p2m_store<P>(A, M);
+}
+
+// ---- M2M ---------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+// centre of charge of a parent, rounded like the oracle (fmm_cart3_kdtree.cuh:339-348)
+template <bool AGENT>
+__device__ inline void parent_centre(const float *center, const int *mult, int k, float c[3], int &mlt)
+{
+	const int c0 = 2 * k + 1, c1 = 2 * k + 2;
+	const int m0 = AGENT ? ld_agent(&mult[c0]) : mult[c0], m1 = AGENT ? ld_agent(&mult[c1]) : mult[c1];
+	mlt = m0 + m1;
+	const float f0 = (float)m0, f1 = (float)m1, ft = (float)mlt;
+	for (int a = 0; a < 3; ++a)
+	{
+		const float a0 = AGENT ? ld_agent(&center[3 * c0 + a]) : center[3 * c0 + a];
+		const float a1 = AGENT ? ld_agent(&center[3 * c1 + a]) : center[3 * c1 + a];
+		float s = f0 * a0;
+		s = s + f1 * a1;
+		c[a] = s / ft;
+	}
+}
+#pragma clang fp contract(on)
+
+template <int P, bool AGENT>
+__device__ inline void m2m_node(float *center, float *mpole, int *mult, int k)
+{
+	constexpr int offM = P * (P + 1) * (P + 2) / 6;
+	float c[3];
+	int mlt;
+	parent_centre<AGENT>(center, mult, k, c, mlt);
+	float A[offM > 0 ? offM : 1];
+#pragma unroll
+	for (int q = 0; q < (offM > 0 ? offM : 1); ++q) A[q] = 0.f;
+	if (P >= 3)
+	{
+		for (int ch = 0; ch < 2; ++ch)
+		{
+			const int child = 2 * k + 1 + ch;
+			float Mc[offM > 0 ? offM : 1];
+#pragma unroll
+			for (int q = 0; q < offM; ++q) Mc[q] = AGENT ? ld_agent(&mpole[(size_t)child * offM + q]) : mpole[(size_t)child * offM + q];
+			const float ccx = AGENT ? ld_agent(&center[3 * child]) : center[3 * child];
+			const float ccy = AGENT ? ld_agent(&center[3 * child + 1]) : center[3 * child + 1];
+			const float ccz = AGENT ? ld_agent(&center[3 * child + 2]) : center[3 * child + 2];
+			m2m_accum<P>(Mc, c[0] - ccx, c[1] - ccy, c[2] - ccz, A);
+		}
+	}
+	float *M = mpole + (size_t)k * offM;
+	if (offM > 0) M[0] = (float)mlt;
+	if (offM > 1) { M[1] = 0.f; M[2] = 0.f; M[3] = 0.f; }
+	m2m_store<P>(A, M);
+	center[3 * k] = c[0]; center[3 * k + 1] = c[1]; center[3 * k + 2] = c[2];
+	mult[k] = mlt;
+}
+
+template <int P>
+__global__ __launch_bounds__(kBlock) void m2m_gen_kernel(float *center, float *mpole, int *mult, int l)
+{
+	const int i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= (1 << l)) return;
+	m2m_node<P, false>(center, mpole, mult, (1 << l) - 1 + i);
+}
+
+// levels ltop .. 0 in one workgroup
+template <int P>
+__global__ __launch_bounds__(kTopNodes) void m2m_top_kernel(float *center, float *mpole, int *mult, int ltop)
+{
+	for (int l = ltop; l >= 0; --l)
+	{
+		if ((int)threadIdx.x < (1 << l)) m2m_node<P, true>(center, mpole, mult, (1 << l) - 1 + threadIdx.x);
+		__threadfence();
+		__syncthreads();
+	}
+}
+
+// ---- L2L ---------------------------------------------------------------------------------------------
+template <int P, bool AGENT>
+__device__ inline void l2l_node(const float *center, float *local, int c)
+{
+	constexpr int offL = (P + 1) * (P + 1);
+	const int p = (c - 1) >> 1;
+	float Lp[offL], O[offL];
+#pragma unroll
+	for (int q = 0; q < offL; ++q) Lp[q] = AGENT ? ld_agent(&local[(size_t)p * offL + q]) : local[(size_t)p * offL + q];
+	l2l_body<P>(Lp, center[3 * c] - center[3 * p], center[3 * c + 1] - center[3 * p + 1], center[3 * c + 2] - center[3 * p + 2], O);
+	float *Lc = local + (size_t)c * offL;
+#pragma unroll
+	for (int q = 1; q < offL; ++q) Lc[q] += O[q];
+}
+
+template <int P>
+__global__ __launch_bounds__(kBlock) void l2l_gen_kernel(const float *__restrict__ center, float *local, int lchild)
+{
+	const int i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= (1 << lchild)) return;
+	l2l_node<P, false>(center, local, (1 << lchild) - 1 + i);
+}
+
+// child levels 2 .. ltop in one workgroup
+template <int P>
+__global__ __launch_bounds__(kTopNodes) void l2l_top_kernel(const float *__restrict__ center, float *local, int ltop)
+{
+	for (int lc = 2; lc <= ltop; ++lc)
+	{
+		if ((int)threadIdx.x < (1 << lc)) l2l_node<P, true>(center, local, (1 << lc) - 1 + threadIdx.x);
+		__threadfence();
+		__syncthreads();
+	}
+}
+
+// ---- L2P + near field + rescale + (un)sort -------------------------------------------------------------
+// one thread per particle in tree order; its leaf is floor(2^L i / n) (the inverse of evalBox's ranges)
+template <int P>
+__global__ __launch_bounds__(kBlock) void l2p_gen_kernel(const float4 *__restrict__ pos, const float *__restrict__ center,
+                                                         const float *__restrict__ local, const float4 *__restrict__ near,
+                                                         const int *__restrict__ chunk_off, const int *__restrict__ index, int mlt_max,
+                                                         const int *__restrict__ unsort, int scatter, const float *__restrict__ param,
+                                                         float *__restrict__ a_out, int have_near, long long n, int L)
+{
+	constexpr int offL = (P + 1) * (P + 1);
+	const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+	if (i >= n) return;
+	const int lf = (int)(((1LL << L) * i) / n), leaf = (1 << L) - 1 + lf;
+	const float4 p = pos[i];
+	float Lp[offL];
+#pragma unroll
+	for (int q = 0; q < offL; ++q) Lp[q] = local[(size_t)leaf * offL + q];
+	float fx, fy, fz;
+	l2p_body<P>(Lp, p.x - center[3 * leaf], p.y - center[3 * leaf + 1], p.z - center[3 * leaf + 2], fx, fy, fz);
+	if (have_near)
+	{
+		const int j = (int)(i - index[leaf]);
+		float nx = 0.f, ny = 0.f, nz = 0.f;
+		for (int ck = chunk_off[lf]; ck < chunk_off[lf + 1]; ++ck)
+		{
+			const float4 nr = near[(size_t)ck * mlt_max + j];
+			nx += nr.x; ny += nr.y; nz += nr.z;
+		}
+		fx += nx; fy += ny; fz += nz;
+	}
+	const float scale = param ? param[0] : 1.f;
+	const long long o = scatter ? (long long)unsort[i] : i;
+	a_out[3 * o] = fx * scale; a_out[3 * o + 1] = fy * scale; a_out[3 * o + 2] = fz * scale;
+}
+
+static int grid_for(long long n) { return (int)((n + kBlock - 1) / kBlock); }
+
+template <int P>
+static int run_upward(nbco_ctx *c, const float4 *pos, float *center, float *mpole, int *mult, const int *index, int L)
+{
+	const int nleaf = 1 << L, beg = nleaf - 1;
+	hipLaunchKernelGGL(p2m_gen_kernel<P>, dim3(grid_for(nleaf)), dim3(kBlock), 0, c->stream, pos, (const float *)center, (const int *)mult, index,
+	                   mpole, beg, nleaf);
+	int l = L - 1;
+	for (; l >= 0 && (1 << l) > kTopNodes; --l)
+		hipLaunchKernelGGL(m2m_gen_kernel<P>, dim3(grid_for(1 << l)), dim3(kBlock), 0, c->stream, center, mpole, mult, l);
+	if (l >= 0) hipLaunchKernelGGL(m2m_top_kernel<P>, dim3(1), dim3(kTopNodes), 0, c->stream, center, mpole, mult, l);
+	NBCO_HIP(hipGetLastError());
+	return NBCO_OK;
+}
+
+template <int P>
+static int run_downward(nbco_ctx *c, const float *center, float *local, int L)
+{
+	int ltop = 1;
+	while (ltop + 1 <= L && (1 << (ltop + 1)) <= kTopNodes) ++ltop;
+	if (ltop >= 2) hipLaunchKernelGGL(l2l_top_kernel<P>, dim3(1), dim3(kTopNodes), 0, c->stream, center, local, ltop);
+	for (int lc = ltop + 1; lc <= L; ++lc)
+		hipLaunchKernelGGL(l2l_gen_kernel<P>, dim3(grid_for(1 << lc)), dim3(kBlock), 0, c->stream, center, local, lc);
+	NBCO_HIP(hipGetLastError());
+	return NBCO_OK;
+}
+
+template <int P>
+static int run_l2p(nbco_ctx *c, const float4 *pos, const float *center, const float *local, const float4 *near, const int *chunk_off,
+                   const int *index, int mlt_max, const int *unsort, int scatter, const float *param, float *a, int have_near, long long n, int L)
+{
+	hipLaunchKernelGGL(l2p_gen_kernel<P>, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, pos, center, local, near, chunk_off, index, mlt_max,
+	                   unsort, scatter, param, a, have_near, n, L);
+	NBCO_HIP(hipGetLastError());
+	return NBCO_OK;
+}
+
+} // namespace
+
+#define NBCO_DISPATCH_P(P, CALL)                                                       \
+	switch (P)                                                                         \
+	{                                                                                  \
+	case 1: return CALL(1); case 2: return CALL(2); case 3: return CALL(3); case 4: return CALL(4); \
+	case 5: return CALL(5); case 6: return CALL(6); case 7: return CALL(7); case 8: return CALL(8); \
+	default: return c->fail(NBCO_ERR_UNSUPPORTED, "generated far-field operators exist for orders 1..8"); \
+	}
+
+int launch_upward_gen(nbco_ctx *c, int P, const float4 *pos, float *center, float *mpole, int *mult, const int *index, int L)
+{
+#define CALL(PP) run_upward<PP>(c, pos, center, mpole, mult, index, L)
+	NBCO_DISPATCH_P(P, CALL)
+#undef CALL
+}
+
+int launch_downward_gen(nbco_ctx *c, int P, const float *center, float *local, int L)
+{
+#define CALL(PP) run_downward<PP>(c, center, local, L)
+	NBCO_DISPATCH_P(P, CALL)
+#undef CALL
+}
+
+int launch_l2p_gen(nbco_ctx *c, int P, const float4 *pos, const float *center, const float *local, const float4 *near, const int *chunk_off,
+                   const int *index, int mlt_max, const int *unsort, int scatter, const float *param, float *a, int have_near, long long n, int L)
+{
+#define CALL(PP) run_l2p<PP>(c, pos, center, local, near, chunk_off, index, mlt_max, unsort, scatter, param, a, have_near, n, L)
+	NBCO_DISPATCH_P(P, CALL)
+#undef CALL
+}

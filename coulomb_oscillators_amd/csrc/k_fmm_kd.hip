@@ -239,6 +239,137 @@ __device__ inline bool kd_admissible(const float4 c1, const float4 c2, int n1, i
 	return parM * parM * sz < dist2;
 }
 
+// ---- in-LDS subtree build ---------------------------------------------------------------------------
+// Once a node holds at most kSubS particles the rest of its subtree is built by ONE workgroup without
+// leaving the CU: positions and the cumulative permutation are loaded into LDS once, every remaining
+// level is one bitonic sort of 64-bit composites [local node | ordered float key | current position]
+// over the whole slice (all nodes of the level at once; the position field makes it the stable sort the
+// oracle performs), followed by an in-place permutation through registers and evalBox for the children.
+// HBM traffic: one read and one write of the slice instead of ~15 radix passes per level.
+constexpr int kSubS = 4096;      // particles per subtree slice (LDS: 32 KB keys + 48 KB xyz + 16 KB permutation + 4 KB split dims)
+constexpr int kSubT = 1024;      // threads per workgroup
+constexpr int kSubE = kSubS / kSubT;
+
+__device__ inline float ld_agent(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void st_agent(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const float4 *__restrict__ pos_in, const int *__restrict__ unsort_in,
+                                                           float4 *__restrict__ pos_out, int *__restrict__ unsort_out, long long n, int l0)
+{
+	__shared__ uint64_t keys[kSubS];
+	__shared__ float px[kSubS], py[kSubS], pz[kSubS];
+	__shared__ int orig[kSubS];
+	__shared__ unsigned char sdl[kSubS];   // split dimension of the current level's nodes of this subtree
+	const int tid = threadIdx.x;
+	const long long j0 = blockIdx.x, m0 = 1LL << l0;
+	const long long s0 = (j0 == 0) ? 0 : (n * j0 - 1) / m0 + 1;
+	const long long e0 = (n * (j0 + 1) - 1) / m0 + 1;
+	const int cnt = (int)(e0 - s0);
+	int P2 = 1;
+	while (P2 < cnt) P2 <<= 1;
+	for (int i = tid; i < cnt; i += kSubT)
+	{
+		const float4 q = pos_in[s0 + i];
+		px[i] = q.x; py[i] = q.y; pz[i] = q.z;
+		orig[i] = unsort_in[s0 + i];
+	}
+	if (tid == 0) sdl[0] = (unsigned char)t.splitdim[kd_beg(l0) + (int)j0];
+	__syncthreads();
+
+	for (int l = l0; l < t.L; ++l)
+	{
+		const int s = l - l0;                     // sub-level
+		const long long m = 1LL << l;
+		const long long jbase = j0 << s;          // first node of this subtree at level l
+		// (a) composite keys (fmm_cart3_kdtree.cuh:167-187): node = floor(2^l i / n)
+		for (int i = tid; i < P2; i += kSubT)
+		{
+			uint64_t k = ~0ull;
+			if (i < cnt)
+			{
+				const long long jl = (m * (s0 + i)) / n - jbase;
+				const int sd = sdl[jl];
+				const float v = sd == 0 ? px[i] : (sd == 1 ? py[i] : pz[i]);
+				k = ((uint64_t)jl << 44) | ((uint64_t)ordered_bits(v) << 12) | (uint64_t)i;
+			}
+			keys[i] = k;
+		}
+		__syncthreads();
+		// (b) bitonic sort, ascending
+		for (int k = 2; k <= P2; k <<= 1)
+			for (int j = k >> 1; j > 0; j >>= 1)
+			{
+				for (int q = tid; q < (P2 >> 1); q += kSubT)
+				{
+					const int i = ((q & ~(j - 1)) << 1) | (q & (j - 1));
+					const int ixj = i | j;
+					const uint64_t a = keys[i], b = keys[ixj];
+					const bool up = (i & k) == 0;
+					if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+				}
+				__syncthreads();
+			}
+		// (c) permute positions and the cumulative permutation in place, through registers
+		float rx[kSubE], ry[kSubE], rz[kSubE];
+		int ro[kSubE];
+#pragma unroll
+		for (int e = 0; e < kSubE; ++e)
+		{
+			const int i = tid + e * kSubT;
+			if (i < cnt)
+			{
+				const int src = (int)(keys[i] & 0xFFF);
+				rx[e] = px[src]; ry[e] = py[src]; rz[e] = pz[src]; ro[e] = orig[src];
+			}
+		}
+		__syncthreads();
+#pragma unroll
+		for (int e = 0; e < kSubE; ++e)
+		{
+			const int i = tid + e * kSubT;
+			if (i < cnt) { px[i] = rx[e]; py[i] = ry[e]; pz[i] = rz[e]; orig[i] = ro[e]; }
+		}
+		__syncthreads();
+		// (d) evalBox for the children (fmm_cart3_kdtree.cuh:109-137); parents' boxes were written by this
+		// workgroup (or by the global pass for l = l0): read them past the L1
+		const long long mc = m << 1;
+		const int nchild = 2 << s;
+		for (int cidx = tid; cidx < nchild; cidx += kSubT)
+		{
+			const long long jc = (jbase << 1) + cidx;
+			const long long start = (jc == 0) ? 0 : (n * jc - 1) / mc + 1;
+			const long long end = (n * (jc + 1) - 1) / mc + 1;
+			const int node = kd_beg(l + 1) + (int)jc, parent = (node - 1) >> 1, split = sdl[cidx >> 1];
+			float lb[3], rb[3];
+			for (int a = 0; a < 3; ++a) { lb[a] = ld_agent(&t.lbound[3 * parent + a]); rb[a] = ld_agent(&t.rbound[3 * parent + a]); }
+			if (cidx & 1)
+			{
+				const int i = (int)(start - s0);
+				lb[split] = split == 0 ? px[i] : (split == 1 ? py[i] : pz[i]);
+			}
+			else
+			{
+				const int i = (int)(end - 1 - s0);
+				rb[split] = split == 0 ? px[i] : (split == 1 ? py[i] : pz[i]);
+			}
+			for (int a = 0; a < 3; ++a) { st_agent(&t.lbound[3 * node + a], lb[a]); st_agent(&t.rbound[3 * node + a], rb[a]); }
+			const int sdc = longest_axis(rb[0] - lb[0], rb[1] - lb[1], rb[2] - lb[2]);
+			t.splitdim[node] = sdc;
+			t.index[node] = (int)start;
+			// the split dims of the next level are consumed by this workgroup only; stage them after the barrier
+			keys[cidx] = (uint64_t)sdc;
+		}
+		__syncthreads();
+		for (int cidx = tid; cidx < nchild; cidx += kSubT) sdl[cidx] = (unsigned char)keys[cidx];
+		__syncthreads();
+	}
+	for (int i = tid; i < cnt; i += kSubT)
+	{
+		pos_out[s0 + i] = make_float4(px[i], py[i], pz[i], 0.f);
+		unsort_out[s0 + i] = orig[i];
+	}
+}
+
 #pragma clang fp contract(fast)
 
 // ---- P2M / M2M -------------------------------------------------------------------------------------
@@ -968,7 +1099,10 @@ int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 			NBCO_TRY(launch_minmax4(c, pos, n, mm));
 			hipLaunchKernelGGL(kd_root_kernel, dim3(1), dim3(64), 0, st, tv, mm);
 			hipLaunchKernelGGL(iota_kernel, dim3(grid1d(n)), dim3(kBlock), 0, st, unsort, n);
-			for (int l = 0; l <= L - 1; ++l)
+			// levels whose nodes exceed the LDS slice: global stable radix sort per level
+			int l0 = 0;
+			while (l0 < L && (n + (1LL << l0) - 1) / (1LL << l0) > kSubS) ++l0;
+			for (int l = 0; l < l0; ++l)
 			{
 				if (l > 0) hipLaunchKernelGGL(kd_box_kernel, dim3(grid1d(kd_cnt(l))), dim3(kBlock), 0, st, tv, pos, n, l);
 				hipLaunchKernelGGL(kd_keys_kernel, dim3(grid1d(n)), dim3(kBlock), 0, st, pos, tv.splitdim + kd_beg(l), n, l,
@@ -978,7 +1112,11 @@ int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 				std::swap(pos, pos_alt);
 				std::swap(unsort, unsort_alt);
 			}
-			hipLaunchKernelGGL(kd_box_kernel, dim3(grid1d(nleaf)), dim3(kBlock), 0, st, tv, pos, n, L);
+			if (l0 > 0) hipLaunchKernelGGL(kd_box_kernel, dim3(grid1d(kd_cnt(l0))), dim3(kBlock), 0, st, tv, pos, n, l0);
+			// the rest of every level-l0 subtree inside one workgroup's LDS
+			hipLaunchKernelGGL(kd_subtree_kernel, dim3(kd_cnt(l0)), dim3(kSubT), 0, st, tv, (const float4 *)pos, (const int *)unsort, pos_alt, unsort_alt, n, l0);
+			std::swap(pos, pos_alt);
+			std::swap(unsort, unsort_alt);
 			NBCO_HIP(hipGetLastError());
 			// keep the "current" buffers in the primary slots
 			if (pos != c->pos4.as<float4>()) { std::swap(c->pos4, c->pos4_alt); std::swap(c->unsort, c->unsort_alt); }
@@ -991,8 +1129,13 @@ int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 	// ---- P2M, M2M ---------------------------------------------------------------------------------------
 	{
 		PhaseScope ph(c, NBCO_PH_P2M_M2M);
-		hipLaunchKernelGGL(p2m_kernel, dim3(nleaf), dim3(64), 0, st, tv, tb, pos);
-		for (int l = L - 1; l >= 0; --l) hipLaunchKernelGGL(m2m_kernel, dim3(kd_cnt(l)), dim3(64), 0, st, tv, tb, l);
+		if (P <= 8)
+			NBCO_TRY(launch_upward_gen(c, P, pos, tv.center, tv.mpole, tv.mult, tv.index, L));   // generated register-resident bodies (k_farfield.hip)
+		else
+		{
+			hipLaunchKernelGGL(p2m_kernel, dim3(nleaf), dim3(64), 0, st, tv, tb, pos);
+			for (int l = L - 1; l >= 0; --l) hipLaunchKernelGGL(m2m_kernel, dim3(kd_cnt(l)), dim3(64), 0, st, tv, tb, l);
+		}
 		hipLaunchKernelGGL(kd_csz_kernel, dim3(grid1d(ntot)), dim3(kBlock), 0, st, tv);
 		NBCO_HIP(hipGetLastError());
 	}
@@ -1113,13 +1256,19 @@ int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 	}
 	{
 		PhaseScope ph(c, NBCO_PH_L2L);
-		for (int lc = 2; lc <= L; ++lc) hipLaunchKernelGGL(l2l_kernel, dim3(kd_cnt(lc)), dim3(64), 0, st, tv, tb, lc);
+		if (P <= 8) NBCO_TRY(launch_downward_gen(c, P, tv.center, tv.local, L));
+		else
+			for (int lc = 2; lc <= L; ++lc) hipLaunchKernelGGL(l2l_kernel, dim3(kd_cnt(lc)), dim3(64), 0, st, tv, tb, lc);
 		NBCO_HIP(hipGetLastError());
 	}
 	// ---- L2P + rescale + (un)sort -------------------------------------------------------------------------
 	{
 		PhaseScope ph(c, NBCO_PH_L2P);
 		size_t lds = (288 + (size_t)std::max(offM, 1) * 64) * sizeof(float);
+		if (P <= 8)
+			NBCO_TRY(launch_l2p_gen(c, P, pos, tv.center, tv.local, near, c->p2p_chunk_off.as<int>(), tv.index, mlt_max, unsort, c->o.unsort ? 1 : 0,
+			                        param, a, dp2p > 0 ? 1 : 0, n, L));
+		else
 		hipLaunchKernelGGL(l2p_kernel, dim3(nleaf), dim3(64), lds, st, tv, tb, (const float4 *)pos, (const float4 *)near,
 		                   (const int *)c->p2p_chunk_off.as<int>(), mlt_max, (const int *)unsort, c->o.unsort ? 1 : 0, param, a, dp2p > 0 ? 1 : 0);
 		NBCO_HIP(hipGetLastError());

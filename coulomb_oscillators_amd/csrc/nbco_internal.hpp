@@ -134,6 +134,11 @@ int launch_energy(nbco_ctx *c, const float *buf, long long n, const float *param
 // k_fmm_kd.hip
 int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *param);
 int kd_copy_out(nbco_ctx *c, int which, void *host_dst, long long host_bytes);
+// k_farfield.hip
+int launch_upward_gen(nbco_ctx *c, int P, const float4 *pos, float *center, float *mpole, int *mult, const int *index, int L);
+int launch_downward_gen(nbco_ctx *c, int P, const float *center, float *local, int L);
+int launch_l2p_gen(nbco_ctx *c, int P, const float4 *pos, const float *center, const float *local, const float4 *near, const int *chunk_off,
+                   const int *index, int mlt_max, const int *unsort, int scatter, const float *param, float *a, int have_near, long long n, int L);
 // k_m2l.hip
 int launch_m2l_lanes(nbco_ctx *c, int P, const float4 *csz, const float *mpole, float *local, const uint64_t *keys, const int *start,
                      int shift, int ntot);
