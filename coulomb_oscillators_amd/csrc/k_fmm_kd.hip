@@ -254,9 +254,11 @@ __device__ inline float ld_agent(const float *p) { return __hip_atomic_load(p, _
 __device__ inline void st_agent(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const float4 *__restrict__ pos_in, const int *__restrict__ unsort_in,
-                                                           float4 *__restrict__ pos_out, int *__restrict__ unsort_out, long long n, int l0)
+                                                           float4 *__restrict__ pos_out, int *__restrict__ unsort_out, long long n, int l0,
+                                                           int canon)
 {
 	__shared__ uint64_t keys[kSubS];
+	__shared__ int prio[3];
 	__shared__ float px[kSubS], py[kSubS], pz[kSubS];
 	__shared__ int orig[kSubS];
 	__shared__ unsigned char sdl[kSubS];   // split dimension of the current level's nodes of this subtree
@@ -273,29 +275,22 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 		px[i] = q.x; py[i] = q.y; pz[i] = q.z;
 		orig[i] = unsort_in[s0 + i];
 	}
-	if (tid == 0) sdl[0] = (unsigned char)t.splitdim[kd_beg(l0) + (int)j0];
+	if (tid == 0)
+	{
+		sdl[0] = (unsigned char)t.splitdim[kd_beg(l0) + (int)j0];
+		// distinct split axes of the ancestors, most recent first (keys of the stable-sort chain)
+		int b[3] = {-1, -1, -1}, nb = 0;
+		for (int anc = kd_beg(l0) + (int)j0; anc > 0 && nb < 3;)
+		{
+			anc = (anc - 1) >> 1;
+			const int a = t.splitdim[anc];
+			if (a != b[0] && a != b[1]) b[nb++] = a;
+		}
+		prio[0] = b[0]; prio[1] = b[1]; prio[2] = b[2];
+	}
 	__syncthreads();
 
-	for (int l = l0; l < t.L; ++l)
-	{
-		const int s = l - l0;                     // sub-level
-		const long long m = 1LL << l;
-		const long long jbase = j0 << s;          // first node of this subtree at level l
-		// (a) composite keys (fmm_cart3_kdtree.cuh:167-187): node = floor(2^l i / n)
-		for (int i = tid; i < P2; i += kSubT)
-		{
-			uint64_t k = ~0ull;
-			if (i < cnt)
-			{
-				const long long jl = (m * (s0 + i)) / n - jbase;
-				const int sd = sdl[jl];
-				const float v = sd == 0 ? px[i] : (sd == 1 ? py[i] : pz[i]);
-				k = ((uint64_t)jl << 44) | ((uint64_t)ordered_bits(v) << 12) | (uint64_t)i;
-			}
-			keys[i] = k;
-		}
-		__syncthreads();
-		// (b) bitonic sort, ascending
+	auto bitonic = [&]() {
 		for (int k = 2; k <= P2; k <<= 1)
 			for (int j = k >> 1; j > 0; j >>= 1)
 			{
@@ -309,7 +304,9 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 				}
 				__syncthreads();
 			}
-		// (c) permute positions and the cumulative permutation in place, through registers
+	};
+	// permute positions and the cumulative permutation in place, through registers
+	auto permute = [&]() {
 		float rx[kSubE], ry[kSubE], rz[kSubE];
 		int ro[kSubE];
 #pragma unroll
@@ -330,6 +327,67 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 			if (i < cnt) { px[i] = rx[e]; py[i] = ry[e]; pz[i] = rz[e]; orig[i] = ro[e]; }
 		}
 		__syncthreads();
+	};
+	auto coord = [&](int i, int a) { return a == 0 ? px[i] : (a == 1 ? py[i] : pz[i]); };
+
+	if (canon && l0 > 0)
+	{
+		// The selection passes above this level deliver the right particle SET in arbitrary order.  Put it
+		// into the order the reference's stable-sort chain would have left it in: by the parent's split
+		// coordinate, ties by the next distinct ancestor axes, then by original index.
+		const int b1 = prio[0], b2 = prio[1], b3 = prio[2];
+		for (int i = tid; i < P2; i += kSubT)
+			keys[i] = i < cnt ? (((uint64_t)ordered_bits(coord(i, b1)) << 12) | (uint64_t)i) : ~0ull;
+		__syncthreads();
+		bitonic();
+		permute();
+		for (int i = tid; i + 1 < cnt; i += kSubT)
+		{
+			const uint32_t k = ordered_bits(coord(i, b1));
+			if (ordered_bits(coord(i + 1, b1)) != k || (i > 0 && ordered_bits(coord(i - 1, b1)) == k)) continue;
+			int e = i + 1;   // run [i, e] of equal first keys: insertion sort by (b2, b3, original index)
+			while (e + 1 < cnt && ordered_bits(coord(e + 1, b1)) == k) ++e;
+			auto less = [&](int u, int v) {
+				const uint32_t u2 = b2 >= 0 ? ordered_bits(coord(u, b2)) : 0, v2 = b2 >= 0 ? ordered_bits(coord(v, b2)) : 0;
+				if (u2 != v2) return u2 < v2;
+				const uint32_t u3 = b3 >= 0 ? ordered_bits(coord(u, b3)) : 0, v3 = b3 >= 0 ? ordered_bits(coord(v, b3)) : 0;
+				if (u3 != v3) return u3 < v3;
+				return orig[u] < orig[v];
+			};
+			for (int u = i + 1; u <= e; ++u)
+				for (int v = u; v > i && less(v, v - 1); --v)
+				{
+					float tx = px[v], ty = py[v], tz = pz[v];
+					int to = orig[v];
+					px[v] = px[v - 1]; py[v] = py[v - 1]; pz[v] = pz[v - 1]; orig[v] = orig[v - 1];
+					px[v - 1] = tx; py[v - 1] = ty; pz[v - 1] = tz; orig[v - 1] = to;
+				}
+		}
+		__syncthreads();
+	}
+
+	for (int l = l0; l < t.L; ++l)
+	{
+		const int s = l - l0;                     // sub-level
+		const long long m = 1LL << l;
+		const long long jbase = j0 << s;          // first node of this subtree at level l
+		// (a) composite keys (fmm_cart3_kdtree.cuh:167-187): node = floor(2^l i / n)
+		for (int i = tid; i < P2; i += kSubT)
+		{
+			uint64_t k = ~0ull;
+			if (i < cnt)
+			{
+				const long long jl = (m * (s0 + i)) / n - jbase;
+				const int sd = sdl[jl];
+				const float v = sd == 0 ? px[i] : (sd == 1 ? py[i] : pz[i]);
+				k = ((uint64_t)jl << 44) | ((uint64_t)ordered_bits(v) << 12) | (uint64_t)i;
+			}
+			keys[i] = k;
+		}
+		__syncthreads();
+		// (b) bitonic sort, ascending; (c) apply the permutation
+		bitonic();
+		permute();
 		// (d) evalBox for the children (fmm_cart3_kdtree.cuh:109-137); parents' boxes were written by this
 		// workgroup (or by the global pass for l = l0): read them past the L1
 		const long long mc = m << 1;
@@ -1093,28 +1151,38 @@ int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 	{
 		PhaseScope ph(c, NBCO_PH_BUILD);
 		NBCO_TRY(launch_pack4(c, pos, p, n));
+		NBCO_HIP(hipMemsetAsync(c->counters.as<int>() + 110, 0, sizeof(int), st));
 		if (rebuild)
 		{
 			float *mm = c->small.as<float>() + 64;
 			NBCO_TRY(launch_minmax4(c, pos, n, mm));
 			hipLaunchKernelGGL(kd_root_kernel, dim3(1), dim3(64), 0, st, tv, mm);
 			hipLaunchKernelGGL(iota_kernel, dim3(grid1d(n)), dim3(kBlock), 0, st, unsort, n);
-			// levels whose nodes exceed the LDS slice: global stable radix sort per level
+			// levels whose nodes exceed the LDS slice: exact median selection + partition (k_kdselect.hip), or,
+			// after a tie overflow, the global stable radix sort per level
 			int l0 = 0;
 			while (l0 < L && (n + (1LL << l0) - 1) / (1LL << l0) > kSubS) ++l0;
+			const bool use_select = !c->force_sort_build;
 			for (int l = 0; l < l0; ++l)
 			{
-				if (l > 0) hipLaunchKernelGGL(kd_box_kernel, dim3(grid1d(kd_cnt(l))), dim3(kBlock), 0, st, tv, pos, n, l);
-				hipLaunchKernelGGL(kd_keys_kernel, dim3(grid1d(n)), dim3(kBlock), 0, st, pos, tv.splitdim + kd_beg(l), n, l,
-				                   c->keys.as<uint64_t>(), c->idx.as<uint32_t>());
-				NBCO_TRY(sort_pairs_u64(c, c->keys.as<uint64_t>(), c->keys_alt.as<uint64_t>(), c->idx.as<uint32_t>(), c->idx_alt.as<uint32_t>(), n, 32 + l));
-				hipLaunchKernelGGL(kd_permute_kernel, dim3(grid1d(n)), dim3(kBlock), 0, st, pos, unsort, c->idx_alt.as<uint32_t>(), pos_alt, unsort_alt, n);
+				if (use_select)
+					NBCO_TRY(kd_select_level(c, l, n, pos, unsort, pos_alt, unsort_alt, tv.lbound, tv.rbound, tv.splitdim, tv.index,
+					                         c->counters.as<int>() + 110));
+				else
+				{
+					if (l > 0) hipLaunchKernelGGL(kd_box_kernel, dim3(grid1d(kd_cnt(l))), dim3(kBlock), 0, st, tv, pos, n, l);
+					hipLaunchKernelGGL(kd_keys_kernel, dim3(grid1d(n)), dim3(kBlock), 0, st, pos, tv.splitdim + kd_beg(l), n, l,
+					                   c->keys.as<uint64_t>(), c->idx.as<uint32_t>());
+					NBCO_TRY(sort_pairs_u64(c, c->keys.as<uint64_t>(), c->keys_alt.as<uint64_t>(), c->idx.as<uint32_t>(), c->idx_alt.as<uint32_t>(), n, 32 + l));
+					hipLaunchKernelGGL(kd_permute_kernel, dim3(grid1d(n)), dim3(kBlock), 0, st, pos, unsort, c->idx_alt.as<uint32_t>(), pos_alt, unsort_alt, n);
+				}
 				std::swap(pos, pos_alt);
 				std::swap(unsort, unsort_alt);
 			}
-			if (l0 > 0) hipLaunchKernelGGL(kd_box_kernel, dim3(grid1d(kd_cnt(l0))), dim3(kBlock), 0, st, tv, pos, n, l0);
+			if (l0 > 0 && !use_select) hipLaunchKernelGGL(kd_box_kernel, dim3(grid1d(kd_cnt(l0))), dim3(kBlock), 0, st, tv, pos, n, l0);
 			// the rest of every level-l0 subtree inside one workgroup's LDS
-			hipLaunchKernelGGL(kd_subtree_kernel, dim3(kd_cnt(l0)), dim3(kSubT), 0, st, tv, (const float4 *)pos, (const int *)unsort, pos_alt, unsort_alt, n, l0);
+			hipLaunchKernelGGL(kd_subtree_kernel, dim3(kd_cnt(l0)), dim3(kSubT), 0, st, tv, (const float4 *)pos, (const int *)unsort, pos_alt, unsort_alt, n, l0,
+			                   use_select ? 1 : 0);
 			std::swap(pos, pos_alt);
 			std::swap(unsort, unsort_alt);
 			NBCO_HIP(hipGetLastError());
@@ -1155,7 +1223,7 @@ int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 		}
 		int *ctr = c->counters.as<int>();
 		int2 *fa = c->frontier_a.as<int2>(), *fb = c->frontier_b.as<int2>();
-		hipLaunchKernelGGL(traverse_init_kernel, dim3(1), dim3(128), 0, st, fa, ctr, 128);
+		hipLaunchKernelGGL(traverse_init_kernel, dim3(1), dim3(128), 0, st, fa, ctr, 104);   // [110] is the selection-build flag
 		const int iters = 2 * L + 2;
 		for (int it = 0; it < iters; ++it)
 		{
@@ -1165,7 +1233,16 @@ int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 		}
 		NBCO_HIP(hipGetLastError());
 		NBCO_HIP(hipMemcpyAsync(h_cnt, ctr, sizeof(int) * 3, hipMemcpyDeviceToHost, st));
+		NBCO_HIP(hipMemcpyAsync(&h_cnt[3], ctr + 110, sizeof(int), hipMemcpyDeviceToHost, st));
 		NBCO_HIP(hipStreamSynchronize(st));
+		if (h_cnt[3] != 0 && !c->force_sort_build)
+		{
+			// a node had more pivot ties than the selection build resolves (degenerate coordinates): nothing has
+			// been written to p or a yet, so redo the evaluation with the sorting build
+			c->force_sort_build = true;
+			c->tree_valid = false;
+			return fmm_kdtree_eval(c, p, a, n, param);
+		}
 		if (h_cnt[2] != 0)
 			return c->fail(NBCO_ERR_CAPACITY, "dual tree traversal exceeded the list capacity (raise opts.list_factor)");
 	}

@@ -73,6 +73,8 @@ struct nbco_ctx
 	DevBuf frontier_a, frontier_b, p2p_list, m2l_list, counters;
 	DevBuf p2p_keys, p2p_keys_alt, m2l_keys, m2l_keys_alt, p2p_start, m2l_start;
 	DevBuf p2p_chunk_cnt, p2p_chunk_off, p2p_chunks;
+	DevBuf sel_hist, sel_nodes, sel_ties;   // selection build (k_kdselect.hip)
+	bool force_sort_build = false;          // set after a tie overflow: use the sorting build from then on
 	long long list_cap = 0;
 	// operator tables
 	DevBuf tables;
@@ -134,6 +136,9 @@ int launch_energy(nbco_ctx *c, const float *buf, long long n, const float *param
 // k_fmm_kd.hip
 int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *param);
 int kd_copy_out(nbco_ctx *c, int which, void *host_dst, long long host_bytes);
+// k_kdselect.hip
+int kd_select_level(nbco_ctx *c, int l, long long n, const float4 *pos_in, const int *unsort_in, float4 *pos_out, int *unsort_out,
+                    float *lbound, float *rbound, int *splitdim, int *index, int *flag);
 // k_farfield.hip
 int launch_upward_gen(nbco_ctx *c, int P, const float4 *pos, float *center, float *mpole, int *mult, const int *index, int L);
 int launch_downward_gen(nbco_ctx *c, int P, const float *center, float *local, int L);

@@ -217,3 +217,27 @@ def test_million_particles_properties(engine, oracle32):
     a2 = torch.zeros_like(a)
     engine.fmm_cart3_kdtree(d, a2, n, dev(par))
     assert torch.equal(a, a2)
+
+
+@pytest.mark.parametrize("n,p,quant", [(262144, 6, 0), (100000, 4, 0), (65536, 5, 2e-5), (65536, 3, 4e-4)])
+def test_large_tree_bit_exact_selection_build(engine, oracle32, n, p, quant):
+    """Sizes where the top levels are built by median selection (k_kdselect.hip) and the rest in LDS: the whole
+    tree, the permutation and the lists still equal the oracle's stable-sort build bit for bit.  `quant` snaps the
+    coordinates to a grid: thousands of exactly tied keys exercise the tie resolver (2e-5: a few ties per pivot)
+    and its overflow fallback to the sorting build (4e-4: hundreds of ties per pivot)."""
+    o = oracle32
+    buf = o.init_reference(n)
+    if quant:
+        buf[0] = (np.round(buf[0] / quant) * quant).astype(np.float32)
+    par = o.params(n)
+    _, a_ref = o.fmm_kd(buf[:2], par, p=p, threads=8, unsort=True)
+    want = o.kd_tree()
+    _, a = run_gpu(engine, buf, par, n, fmm_order=p, unsort=1)
+    info = engine.kd_info()
+    assert (info.L, info.ntot) == (want["L"], want["ntot"])
+    for name in ("index", "mult", "splitdim", "lbound", "rbound", "center"):
+        np.testing.assert_array_equal(engine.kd_array(name), want[name], err_msg=name)
+    np.testing.assert_array_equal(engine.kd_array("unsort"), o.kd_unsort(n))
+    for name in ("p2p", "m2l"):
+        np.testing.assert_array_equal(canon_pairs(engine.kd_array(name)), canon_pairs(want[name]), err_msg=name)
+    assert force_err(a, a_ref) < 1e-5
