@@ -506,114 +506,131 @@ __global__ __launch_bounds__(64) void m2m_kernel(TreeView t, DevTables tb, int l
 
 // ---- dual tree traversal -----------------------------------------------------------------------------
 // counters: [0] p2p count, [1] m2l count, [2] overflow flag, [4 + it] frontier size of iteration it
-constexpr int kItems = 8;   // pairs per thread per block pass
 
-__device__ inline int block_exclusive_scan(int v, int *sh_wave, int &total)
+// exclusive scan of a packed 3-field counter over the 256 threads of a block (fields: bits 0-19,
+// 20-39, 40-59; every block total stays far below 2^20)
+__device__ inline uint64_t block_exclusive_scan3(uint64_t v, uint64_t *sh_wave, uint64_t &total)
 {
-	// exclusive scan over 256 threads (4 waves)
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-	int incl = v;
+	uint64_t incl = v;
 	for (int o = 1; o < 64; o <<= 1)
 	{
-		int y = __shfl_up(incl, o);
+		uint64_t y = __shfl_up(incl, o);
 		if (lane >= o) incl += y;
 	}
 	if (lane == 63) sh_wave[w] = incl;
 	__syncthreads();
-	int base = 0, tot = 0;
+	uint64_t base = 0, tot = 0;
 	for (int k = 0; k < 4; ++k)
 	{
-		int s = sh_wave[k];
+		uint64_t s = sh_wave[k];
 		if (k < w) base += s;
 		tot += s;
 	}
-	__syncthreads();
 	total = tot;
 	return base + incl - v;
 }
 
+// classification of one node pair (fmm_cart3_kdtree.cuh:586-609 CPU order, :504-542 GPU order):
+// 0 nothing, 1 P2P, 2 M2L, 3 self pair -> 3 children, 4 split the second node, 5 split the first node
+__device__ inline int classify_pair(const TreeView &t, const AdmTab &tab, int2 np, float par, int m2l_first)
+{
+	const int ntot = t.ntot;
+	const bool leaf1 = 2 * np.x + 1 >= ntot, leaf2 = 2 * np.y + 1 >= ntot;
+	if (!m2l_first && leaf1 && leaf2) return (np.x != np.y) ? 1 : 0;
+	if (np.x == np.y) return leaf1 ? 0 : 3;
+	const float4 c1 = t.csz[np.x], c2 = t.csz[np.y];
+	if (kd_admissible(c1, c2, np.x, np.y, t.mult, tab, par)) return 2;
+	if (leaf1 && leaf2) return 1;
+	return (leaf1 || (!leaf2 && c1.w <= c2.w)) ? 4 : 5;
+}
+
+__device__ inline int pair_children(int kd, int2 np, int2 ch[3])
+{
+	if (kd == 3)
+	{
+		ch[0] = make_int2(2 * np.x + 1, 2 * np.x + 1);
+		ch[1] = make_int2(2 * np.x + 1, 2 * np.x + 2);
+		ch[2] = make_int2(2 * np.x + 2, 2 * np.x + 2);
+		return 3;
+	}
+	if (kd == 4) { ch[0] = make_int2(np.x, 2 * np.y + 1); ch[1] = make_int2(np.x, 2 * np.y + 2); return 2; }
+	if (kd == 5) { ch[0] = make_int2(2 * np.x + 1, np.y); ch[1] = make_int2(2 * np.x + 2, np.y); return 2; }
+	return 0;
+}
+
+// One launch advances the pair frontier by TWO traversal steps: every thread classifies its pair and,
+// if it splits, classifies the (up to 3) children as well; only grandchildren go back to the frontier.
+// That halves the number of dependent launches of this latency-bound phase.  Output slots are reserved
+// with one packed block scan and three concurrent atomics per block.
 __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab, const int2 *__restrict__ fin, int2 *__restrict__ fout,
                                                           int2 *__restrict__ p2p, int2 *__restrict__ m2l, int *__restrict__ counters, int it,
-                                                          long long cap, float par, int m2l_first)
+                                                          long long cap, float par, int m2l_first, unsigned *__restrict__ cnt_p2p,
+                                                          unsigned *__restrict__ cnt_m2l)
 {
-	__shared__ int sh_wave[4];
+	__shared__ uint64_t sh_wave[4];
 	__shared__ int sh_base[3];
 	const int nin = counters[4 + it];
-	const int ntot = t.ntot;
-	for (long long base = (long long)blockIdx.x * (kBlock * kItems); base < nin; base += (long long)gridDim.x * (kBlock * kItems))
+	const int lbeg = kd_beg(t.L);
+	for (long long base = (long long)blockIdx.x * kBlock; base < nin; base += (long long)gridDim.x * kBlock)
 	{
-		int kind[kItems];   // 0 none, 1 p2p, 2 m2l, 3 self split (3 children), 4 split second, 5 split first
-		int2 pr[kItems];
-		int cf = 0, cp = 0, cm = 0;
+		const long long i = base + threadIdx.x;
+		// up to 4 classified pairs per thread: the input pair and its children
+		int2 pr[4];
+		int kd[4] = {0, 0, 0, 0};
+		int nch = 0;
+		if (i < nin)
+		{
+			pr[0] = fin[i];
+			kd[0] = classify_pair(t, tab, pr[0], par, m2l_first);
+			nch = pair_children(kd[0], pr[0], pr + 1);
 #pragma unroll
-		for (int q = 0; q < kItems; ++q)
-		{
-			long long i = base + (long long)q * kBlock + threadIdx.x;
-			kind[q] = 0;
-			pr[q] = make_int2(0, 0);
-			if (i < nin)
-			{
-				int2 np = fin[i];
-				pr[q] = np;
-				const bool leaf1 = 2 * np.x + 1 >= ntot, leaf2 = 2 * np.y + 1 >= ntot;
-				int kd = 0;
-				if (!m2l_first && leaf1 && leaf2) kd = (np.x != np.y) ? 1 : 0;
-				else if (np.x == np.y && !leaf1) kd = 3;
-				else if (np.x == np.y) kd = 0;   // leaf self pair under m2l_first
-				else
-				{
-					const float4 c1 = t.csz[np.x], c2 = t.csz[np.y];
-					if (kd_admissible(c1, c2, np.x, np.y, t.mult, tab, par)) kd = 2;
-					else if (leaf1 && leaf2) kd = 1;
-					else kd = (leaf1 || (!leaf2 && c1.w <= c2.w)) ? 4 : 5;
-				}
-				kind[q] = kd;
-				cf += kd == 3 ? 3 : (kd >= 4 ? 2 : 0);
-				cp += kd == 1;
-				cm += kd == 2;
-			}
+			for (int k = 1; k < 4; ++k)
+				if (k <= nch) kd[k] = classify_pair(t, tab, pr[k], par, m2l_first);
 		}
-		int tf, tp, tm;
-		int of = block_exclusive_scan(cf, sh_wave, tf);
-		int op = block_exclusive_scan(cp, sh_wave, tp);
-		int om = block_exclusive_scan(cm, sh_wave, tm);
-		if (threadIdx.x == 0)
+		uint64_t cnt = 0;
+#pragma unroll
+		for (int k = 0; k < 4; ++k)
 		{
-			sh_base[0] = tf ? atomicAdd(&counters[4 + it + 1], tf) : 0;
-			sh_base[1] = tp ? atomicAdd(&counters[0], tp) : 0;
-			sh_base[2] = tm ? atomicAdd(&counters[1], tm) : 0;
+			if (k == 0 && nch > 0) continue;   // a split input pair itself emits nothing
+			const int q = kd[k];
+			cnt += (uint64_t)(q == 3 ? 3 : (q >= 4 ? 2 : 0)) | ((uint64_t)(q == 1) << 20) | ((uint64_t)(q == 2) << 40);
 		}
+		uint64_t tot;
+		const uint64_t off = block_exclusive_scan3(cnt, sh_wave, tot);
+		const int tf = (int)(tot & 0xFFFFF), tp = (int)((tot >> 20) & 0xFFFFF), tm = (int)(tot >> 40);
+		if (threadIdx.x == 0) sh_base[0] = tf ? atomicAdd(&counters[4 + it + 1], tf) : 0;
+		if (threadIdx.x == 64) sh_base[1] = tp ? atomicAdd(&counters[0], tp) : 0;
+		if (threadIdx.x == 128) sh_base[2] = tm ? atomicAdd(&counters[1], tm) : 0;
 		__syncthreads();
 		long long bf = sh_base[0], bp = sh_base[1], bm = sh_base[2];
 		const bool okf = bf + tf <= cap, okp = bp + tp <= cap, okm = bm + tm <= cap;
 		if (threadIdx.x == 0 && !(okf && okp && okm)) counters[2] = 1;
-		bf += of; bp += op; bm += om;
+		bf += (long long)(off & 0xFFFFF); bp += (long long)((off >> 20) & 0xFFFFF); bm += (long long)(off >> 40);
 #pragma unroll
-		for (int q = 0; q < kItems; ++q)
+		for (int k = 0; k < 4; ++k)
 		{
-			const int kd = kind[q];
-			const int2 np = pr[q];
-			if (kd == 1) { if (okp) p2p[bp] = np; ++bp; }
-			else if (kd == 2) { if (okm) m2l[bm] = np; ++bm; }
-			else if (kd == 3)
+			if (k == 0 && nch > 0) continue;
+			const int q = kd[k];
+			const int2 np = pr[k];
+			// the per-target entry counts of the directed lists are accumulated here, under the traversal's latency
+			if (q == 1)
 			{
+				if (okp) { p2p[bp] = np; atomicAdd(&cnt_p2p[np.x - lbeg], 1u); atomicAdd(&cnt_p2p[np.y - lbeg], 1u); }
+				++bp;
+			}
+			else if (q == 2)
+			{
+				if (okm) { m2l[bm] = np; atomicAdd(&cnt_m2l[np.x], 1u); atomicAdd(&cnt_m2l[np.y], 1u); }
+				++bm;
+			}
+			else if (q >= 3)
+			{
+				int2 ch[3];
+				const int nc = pair_children(q, np, ch);
 				if (okf)
-				{
-					fout[bf] = make_int2(2 * np.x + 1, 2 * np.x + 1);
-					fout[bf + 1] = make_int2(2 * np.x + 1, 2 * np.x + 2);
-					fout[bf + 2] = make_int2(2 * np.x + 2, 2 * np.x + 2);
-				}
-				bf += 3;
-			}
-			else if (kd == 4)
-			{
-				if (okf) { fout[bf] = make_int2(np.x, 2 * np.y + 1); fout[bf + 1] = make_int2(np.x, 2 * np.y + 2); }
-				bf += 2;
-			}
-			else if (kd == 5)
-			{
-				if (okf) { fout[bf] = make_int2(2 * np.x + 1, np.y); fout[bf + 1] = make_int2(2 * np.x + 2, np.y); }
-				bf += 2;
+					for (int e = 0; e < nc; ++e) fout[bf + e] = ch[e];
+				bf += nc;
 			}
 		}
 		__syncthreads();
@@ -661,6 +678,89 @@ __global__ __launch_bounds__(kBlock) void list_starts_kernel(const uint64_t *__r
 		for (int q = prev + 1; q <= tg; ++q) start[q] = (int)i;
 		if (i == count - 1)
 			for (int q = tg + 1; q <= ntargets; ++q) start[q] = (int)count;
+	}
+}
+
+// LDS hand-off between lanes of ONE wave: DS operations of a wave execute in order, so only the compiler
+// has to be kept from reordering them (no s_barrier: the waves of a block work on different items; a
+// fence or __syncthreads would also drain vmcnt and with it any prefetched global data).
+__device__ __forceinline__ void wave_lds_sync()
+{
+	asm volatile("" ::: "memory");
+	__builtin_amdgcn_wave_barrier();
+	asm volatile("" ::: "memory");
+}
+
+// ---- directed lists by counting sort ---------------------------------------------------------------
+// count -> exclusive scan -> scatter (slot order inside a target is whatever the atomics give) ->
+// per-target sort of the (short) source ranges.  The last step makes the lists, and with them every
+// floating-point sum downstream, identical from run to run.
+__global__ __launch_bounds__(kBlock) void add_one_kernel(unsigned *__restrict__ v, int n)
+{
+	for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) v[i] += 1u;
+}
+
+__global__ __launch_bounds__(kBlock) void list_fill_kernel(const int2 *__restrict__ pairs, long long npairs, int sub, int nself, int shift,
+                                                           const int *__restrict__ start, unsigned *__restrict__ fill,
+                                                           uint64_t *__restrict__ keys)
+{
+	const long long total = npairs + nself;
+	for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock)
+	{
+		if (i < npairs)
+		{
+			const int2 p = pairs[i];
+			const uint64_t a = (uint64_t)(p.x - sub), b = (uint64_t)(p.y - sub);
+			keys[start[a] + atomicAdd(&fill[a], 1u)] = (a << shift) | b;
+			keys[start[b] + atomicAdd(&fill[b], 1u)] = (b << shift) | a;
+		}
+		else
+		{
+			const uint64_t t = (uint64_t)(i - npairs);
+			keys[start[t] + atomicAdd(&fill[t], 1u)] = (t << shift) | t;
+		}
+	}
+}
+
+// one wave per target: rank sort of its source range (distinct keys); ranges of up to kSegLds entries are
+// staged in LDS, longer ones (not seen in practice) are ranked straight from global memory
+constexpr int kSegLds = 512;
+__global__ __launch_bounds__(kBlock) void list_segsort_kernel(const int *__restrict__ start, int ntargets, const uint64_t *__restrict__ in,
+                                                              uint64_t *__restrict__ out)
+{
+	__shared__ uint64_t stage[kBlock / 64][kSegLds];
+	const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	for (int t = blockIdx.x * (kBlock / 64) + wv; t < ntargets; t += gridDim.x * (kBlock / 64))
+	{
+		const int s = start[t], cnt = start[t + 1] - s;
+		if (cnt <= 64)
+		{
+			const uint64_t key = lane < cnt ? in[s + lane] : ~0ull;
+			int rank = 0;
+			for (int q = 0; q < cnt; ++q) rank += __shfl(key, q) < key ? 1 : 0;
+			if (lane < cnt) out[s + rank] = key;
+		}
+		else if (cnt <= kSegLds)
+		{
+			for (int i = lane; i < cnt; i += 64) stage[wv][i] = in[s + i];
+			wave_lds_sync();
+			for (int i = lane; i < cnt; i += 64)
+			{
+				const uint64_t key = stage[wv][i];
+				int rank = 0;
+				for (int q = 0; q < cnt; ++q) rank += stage[wv][q] < key ? 1 : 0;
+				out[s + rank] = key;
+			}
+			wave_lds_sync();
+		}
+		else
+			for (int i = lane; i < cnt; i += 64)
+			{
+				const uint64_t key = in[s + i];
+				int rank = 0;
+				for (int q = 0; q < cnt; ++q) rank += in[s + q] < key ? 1 : 0;
+				out[s + rank] = key;
+			}
 	}
 }
 
@@ -722,16 +822,6 @@ __global__ __launch_bounds__(kBlock) void p2p_chunk_fill_kernel(const int *__res
 // consumed, staged in a double-buffered LDS tile and read back as group-uniform ds_read_b128
 // broadcasts.  Slots beyond a source leaf hold a far point whose r^-3 underflows to exactly 0 (3e36 <
 // FLT_MAX, (3e36)^-3/2 ~ 2e-55 -> 0): the pair loop needs no predicate.
-// LDS hand-off between lanes of ONE wave: DS operations of a wave execute in order, so only the compiler
-// has to be kept from reordering them (no s_barrier: the waves of a block work on different chunks; a
-// fence or __syncthreads here would also drain vmcnt and with it the prefetched tile).
-__device__ __forceinline__ void wave_lds_sync()
-{
-	asm volatile("" ::: "memory");
-	__builtin_amdgcn_wave_barrier();
-	asm volatile("" ::: "memory");
-}
-
 #define P2P_PAIR(PX, PY, PZ)                                               \
 	{                                                                      \
 		float dx = pi.x - (PX), dy = pi.y - (PY), dz = pi.z - (PZ);        \
@@ -1082,6 +1172,26 @@ static int sort_keys_u64(nbco_ctx *c, uint64_t *kin, uint64_t *kout, long long n
 	return NBCO_OK;
 }
 
+// directed, per-target sorted list of `pairs` (+ one self entry per target when nself > 0) into keys_out; start[0..T].
+// cnt[0..T) holds the per-target pair-entry counts accumulated by the traversal, fill[0..T) is zero.
+static int build_directed_list(nbco_ctx *c, const int2 *pairs, long long npairs, int sub, int nself, int ntargets, int shift, unsigned *cnt,
+                               unsigned *fill, int *start, uint64_t *keys_tmp, uint64_t *keys_out)
+{
+	hipStream_t st = c->stream;
+	if (nself > 0) hipLaunchKernelGGL(add_one_kernel, dim3(grid1d(nself)), dim3(kBlock), 0, st, cnt, nself);
+	size_t bytes = 0;
+	NBCO_HIP(rocprim::exclusive_scan(nullptr, bytes, (int *)cnt, start, 0, (size_t)(ntargets + 1), rocprim::plus<int>(), st));
+	NBCO_TRY(c->reserve(c->sort_tmp, bytes));
+	bytes = c->sort_tmp.bytes;
+	NBCO_HIP(rocprim::exclusive_scan(c->sort_tmp.ptr, bytes, (int *)cnt, start, 0, (size_t)(ntargets + 1), rocprim::plus<int>(), st));
+	hipLaunchKernelGGL(list_fill_kernel, dim3(grid1d(npairs + nself)), dim3(kBlock), 0, st, pairs, npairs, sub, nself, shift, (const int *)start, fill,
+	                   keys_tmp);
+	hipLaunchKernelGGL(list_segsort_kernel, dim3((ntargets + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, (const int *)start, ntargets,
+	                   (const uint64_t *)keys_tmp, keys_out);
+	NBCO_HIP(hipGetLastError());
+	return NBCO_OK;
+}
+
 template <int TPL>
 static void launch_p2p(nbco_ctx *c, const TreeView &tv, const float4 *pos, const int2 *desc, const int4 *chunk, const int *ntotal,
                        long long max_chunks, int mlt_max, float4 *partial)
@@ -1223,12 +1333,17 @@ int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 		}
 		int *ctr = c->counters.as<int>();
 		int2 *fa = c->frontier_a.as<int2>(), *fb = c->frontier_b.as<int2>();
+		// per-target entry counters / fill cursors of the two directed lists: [cnt_p2p | fill_p2p | cnt_m2l | fill_m2l]
+		const size_t np_ = (size_t)nleaf + 2, nm_ = (size_t)ntot + 2;
+		NBCO_TRY(c->reserve(c->list_cnt, sizeof(unsigned) * 2 * (np_ + nm_)));
+		NBCO_HIP(hipMemsetAsync(c->list_cnt.ptr, 0, sizeof(unsigned) * 2 * (np_ + nm_), st));
+		unsigned *cnt_p2p = c->list_cnt.as<unsigned>(), *cnt_m2l = cnt_p2p + 2 * np_;
 		hipLaunchKernelGGL(traverse_init_kernel, dim3(1), dim3(128), 0, st, fa, ctr, 104);   // [110] is the selection-build flag
-		const int iters = 2 * L + 2;
+		const int iters = L + 2;   // every launch performs two traversal steps (2L + 1 are needed)
 		for (int it = 0; it < iters; ++it)
 		{
 			hipLaunchKernelGGL(traverse_kernel, dim3(1024), dim3(kBlock), 0, st, tv, tab, (const int2 *)fa, fb, c->p2p_list.as<int2>(),
-			                   c->m2l_list.as<int2>(), ctr, it, cap, c->o.tree_radius, c->o.m2l_first);
+			                   c->m2l_list.as<int2>(), ctr, it, cap, c->o.tree_radius, c->o.m2l_first, cnt_p2p, cnt_m2l);
 			std::swap(fa, fb);
 		}
 		NBCO_HIP(hipGetLastError());
@@ -1261,11 +1376,9 @@ int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 		NBCO_TRY(c->reserve(c->m2l_start, sizeof(int) * (size_t)(ntot + 2)));
 		if (dp2p > 0)
 		{
-			hipLaunchKernelGGL(expand_pairs_kernel, dim3(grid1d(np2p + nleaf)), dim3(kBlock), 0, st, c->p2p_list.as<int2>(), np2p, beg, shift,
-			                   (long long)nleaf, c->p2p_keys.as<uint64_t>());
-			NBCO_TRY(sort_keys_u64(c, c->p2p_keys.as<uint64_t>(), c->p2p_keys_alt.as<uint64_t>(), dp2p, 2 * shift));
-			hipLaunchKernelGGL(list_starts_kernel, dim3(grid1d(dp2p)), dim3(kBlock), 0, st, c->p2p_keys_alt.as<uint64_t>(), dp2p, shift, nleaf,
-			                   c->p2p_start.as<int>());
+			unsigned *cp = c->list_cnt.as<unsigned>();
+			NBCO_TRY(build_directed_list(c, c->p2p_list.as<int2>(), np2p, beg, nleaf, nleaf, shift, cp, cp + ((size_t)nleaf + 2), c->p2p_start.as<int>(),
+			                             c->p2p_keys.as<uint64_t>(), c->p2p_keys_alt.as<uint64_t>()));
 			hipLaunchKernelGGL(pair_count_kernel, dim3(grid1d(dp2p, 256)), dim3(kBlock), 0, st, tv, (const uint64_t *)c->p2p_keys_alt.as<uint64_t>(),
 			                   dp2p, shift, (unsigned long long *)(c->counters.as<int>() + 100));
 			hipLaunchKernelGGL(p2p_srcdesc_kernel, dim3(grid1d(dp2p)), dim3(kBlock), 0, st, tv, (const uint64_t *)c->p2p_keys_alt.as<uint64_t>(), dp2p,
@@ -1291,11 +1404,9 @@ int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 		}
 		if (dm2l > 0)
 		{
-			hipLaunchKernelGGL(expand_pairs_kernel, dim3(grid1d(nm2l)), dim3(kBlock), 0, st, c->m2l_list.as<int2>(), nm2l, 0, shift, 0LL,
-			                   c->m2l_keys.as<uint64_t>());
-			NBCO_TRY(sort_keys_u64(c, c->m2l_keys.as<uint64_t>(), c->m2l_keys_alt.as<uint64_t>(), dm2l, 2 * shift));
-			hipLaunchKernelGGL(list_starts_kernel, dim3(grid1d(dm2l)), dim3(kBlock), 0, st, c->m2l_keys_alt.as<uint64_t>(), dm2l, shift, ntot,
-			                   c->m2l_start.as<int>());
+			unsigned *cm = c->list_cnt.as<unsigned>() + 2 * ((size_t)nleaf + 2);
+			NBCO_TRY(build_directed_list(c, c->m2l_list.as<int2>(), nm2l, 0, 0, ntot, shift, cm, cm + ((size_t)ntot + 2), c->m2l_start.as<int>(),
+			                             c->m2l_keys.as<uint64_t>(), c->m2l_keys_alt.as<uint64_t>()));
 		}
 		else
 			NBCO_HIP(hipMemsetAsync(c->m2l_start.ptr, 0, sizeof(int) * (size_t)(ntot + 2), st));

@@ -73,6 +73,7 @@ struct nbco_ctx
 	DevBuf frontier_a, frontier_b, p2p_list, m2l_list, counters;
 	DevBuf p2p_keys, p2p_keys_alt, m2l_keys, m2l_keys_alt, p2p_start, m2l_start;
 	DevBuf p2p_chunk_cnt, p2p_chunk_off, p2p_chunks;
+	DevBuf list_cnt;
 	DevBuf sel_hist, sel_nodes, sel_ties;   // selection build (k_kdselect.hip)
 	bool force_sort_build = false;          // set after a tie overflow: use the sorting build from then on
 	long long list_cap = 0;
