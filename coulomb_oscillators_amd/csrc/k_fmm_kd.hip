@@ -290,21 +290,86 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 	}
 	__syncthreads();
 
-	auto bitonic = [&]() {
-		for (int k = 2; k <= P2; k <<= 1)
+	// Bitonic sort of keys[0, P2), ascending inside every aligned block of `seg` elements (seg = P2: the whole
+	// slice).  Each wave owns a contiguous chunk of 64 R keys in registers (R = 1, 2 or 4 per lane): all
+	// compare-exchange stages whose partner distance stays inside the chunk run on shuffles / register
+	// swaps with no barrier; only the (at most 10) stages with larger strides go through LDS.
+	auto bitonic = [&](int seg) {
+		const int nw = kSubT / 64;                                   // 16 waves
+		const int R = P2 >= 64 * nw ? P2 / (64 * nw) : 1;           // keys per lane
+		const int chunk = 64 * R;
+		const int wv = tid >> 6, lane = tid & 63;
+		const int wbase = wv * chunk;
+		const bool active = wbase < P2;
+		uint64_t v[4];
+		auto load = [&]() {
+#pragma unroll
+			for (int r = 0; r < 4; ++r)
+				if (r < R && active) v[r] = (wbase + lane + 64 * r) < P2 ? keys[wbase + lane + 64 * r] : ~0ull;
+		};
+		auto store = [&]() {
+#pragma unroll
+			for (int r = 0; r < 4; ++r)
+				if (r < R && active && (wbase + lane + 64 * r) < P2) keys[wbase + lane + 64 * r] = v[r];
+		};
+		auto local_stage = [&](int k, int j) {
+			if (!active) return;
+			if (j < 64)
+			{
+#pragma unroll
+				for (int r = 0; r < 4; ++r)
+					if (r < R)
+					{
+						const int e = wbase + lane + 64 * r;
+						const uint64_t o = __shfl_xor(v[r], j);
+						const bool up = ((e & ~j & k) == 0) || k == seg;
+						const bool keep_min = ((e & j) == 0) == up;
+						v[r] = keep_min ? (v[r] < o ? v[r] : o) : (v[r] < o ? o : v[r]);
+					}
+			}
+			else
+			{
+				const int dr = j >> 6;   // 1 or 2
+#pragma unroll
+				for (int r = 0; r < 4; ++r)
+					if (r < R && (r & dr) == 0)
+					{
+						const int e = wbase + lane + 64 * r;
+						const bool up = ((e & k) == 0) || k == seg;
+						const uint64_t a = v[r], b = v[r | dr];
+						if ((a > b) == up) { v[r] = b; v[r | dr] = a; }
+					}
+			}
+		};
+		bool in_regs = false;
+		for (int k = 2; k <= seg; k <<= 1)
 			for (int j = k >> 1; j > 0; j >>= 1)
 			{
-				for (int q = tid; q < (P2 >> 1); q += kSubT)
+				if (j < chunk)
 				{
-					const int i = ((q & ~(j - 1)) << 1) | (q & (j - 1));
-					const int ixj = i | j;
-					const uint64_t a = keys[i], b = keys[ixj];
-					const bool up = (i & k) == 0;
-					if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+					if (!in_regs) { load(); in_regs = true; }
+					local_stage(k, j);
 				}
-				__syncthreads();
+				else
+				{
+					if (in_regs) { store(); in_regs = false; __syncthreads(); }
+					for (int q = tid; q < (P2 >> 1); q += kSubT)
+					{
+						const int i = ((q & ~(j - 1)) << 1) | (q & (j - 1));
+						const int ixj = i | j;
+						const uint64_t a = keys[i], b = keys[ixj];
+						const bool up = ((i & k) == 0) || k == seg;
+						if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+					}
+					__syncthreads();
+				}
 			}
+		if (in_regs) store();
+		__syncthreads();
 	};
+	// n a power of two: every node of every level is an aligned power-of-two block of the slice, so a level's sort
+	// only has to merge inside its own nodes
+	const bool pow2 = cnt == P2 && (n & (n - 1)) == 0;
 	// permute positions and the cumulative permutation in place, through registers
 	auto permute = [&]() {
 		float rx[kSubE], ry[kSubE], rz[kSubE];
@@ -339,7 +404,7 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 		for (int i = tid; i < P2; i += kSubT)
 			keys[i] = i < cnt ? (((uint64_t)ordered_bits(coord(i, b1)) << 12) | (uint64_t)i) : ~0ull;
 		__syncthreads();
-		bitonic();
+		bitonic(P2);
 		permute();
 		for (int i = tid; i + 1 < cnt; i += kSubT)
 		{
@@ -386,7 +451,7 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 		}
 		__syncthreads();
 		// (b) bitonic sort, ascending; (c) apply the permutation
-		bitonic();
+		bitonic(pow2 ? (P2 >> s) : P2);
 		permute();
 		// (d) evalBox for the children (fmm_cart3_kdtree.cuh:109-137); parents' boxes were written by this
 		// workgroup (or by the global pass for l = l0): read them past the L1
@@ -1273,6 +1338,7 @@ int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 			int l0 = 0;
 			while (l0 < L && (n + (1LL << l0) - 1) / (1LL << l0) > kSubS) ++l0;
 			const bool use_select = !c->force_sort_build;
+			if (use_select && l0 > 0) NBCO_TRY(kd_select_begin(c, l0));
 			for (int l = 0; l < l0; ++l)
 			{
 				if (use_select)

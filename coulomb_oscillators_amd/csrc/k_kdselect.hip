@@ -27,55 +27,141 @@ constexpr int kChunk = 2048;            // elements per block; nodes handled her
 constexpr int kBins = 2048;
 constexpr int kTieCap = 64;
 
+// per-node state of one level (zeroed for all levels by one memset per build)
 struct SelNode
 {
-	uint32_t prefix;   // selected digits so far (after the last pass: the pivot key)
+	uint32_t prefix;   // selected digits so far (after three passes: the pivot key)
 	uint32_t r;        // 0-based rank of the pivot inside the current candidate set
-	uint32_t nless;    // elements with key < candidate prefix
-	uint32_t neq;      // elements equal to the pivot key
+	uint32_t neq;      // elements equal to the pivot key (after three passes)
 	uint32_t need;     // how many of them belong to the left child
+	uint32_t done[3];  // blocks that have finished their histogram contribution, per pass
 	uint32_t cntL, cntR, tiecnt;
-	uint32_t minR;     // smallest ordered key of the right child
-	uint32_t pad[7];
+	uint32_t minR;     // smallest ordered key of the right child, stored inverted (~key) so that zero = "none yet"
+	uint32_t pivot;    // the pivot as an ordered key (valid after the third pass)
 };
 
-__global__ __launch_bounds__(kBlock) void sel_init_kernel(SelNode *__restrict__ nodes, uint32_t *__restrict__ hist, long long n, int l)
+struct SelPivot { uint32_t prefix, r, neq, need; };
+
+__device__ inline uint32_t ld_agent_u32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Locate the bin holding rank r in one 2048-bin histogram and descend into it.  Called by all kBlock threads.
+__device__ inline void descend(const uint32_t *__restrict__ h, int bits, SelPivot &pv, uint32_t *sh /* [kBlock/64 + 3] */)
 {
-	const int m = 1 << l;
-	for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < 3LL * m * kBins; i += (long long)gridDim.x * kBlock) hist[i] = 0;
-	const int j = blockIdx.x * kBlock + threadIdx.x;
-	if (j < m)
+	constexpr int PER = kBins / kBlock;
+	uint32_t v[PER], s = 0;
+#pragma unroll
+	for (int q = 0; q < PER; ++q) { v[q] = ld_agent_u32(&h[threadIdx.x * PER + q]); s += v[q]; }
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	uint32_t incl = s;
+	for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+	__syncthreads();
+	if (lane == 63) sh[w] = incl;
+	__syncthreads();
+	uint32_t base = 0;
+	for (int q = 0; q < w; ++q) base += sh[q];
+	uint32_t cum = base + incl - s;
+#pragma unroll
+	for (int q = 0; q < PER; ++q)
 	{
-		const long long start = range_start(n, j, m), mid = range_start(n, 2 * j + 1, 2 * m);
-		SelNode s{};
-		s.r = (uint32_t)(mid - start - 1);
-		s.minR = 0xFFFFFFFFu;
-		nodes[j] = s;
+		if (pv.r >= cum && pv.r < cum + v[q]) { sh[4] = threadIdx.x * PER + q; sh[5] = cum; sh[6] = v[q]; }
+		cum += v[q];
+	}
+	__syncthreads();
+	pv.prefix = (pv.prefix << bits) | sh[4];
+	pv.r -= sh[5];
+	pv.neq = sh[6];
+	pv.need = pv.r + 1;
+}
+
+// All keys of a node lie between the ordered images of its box faces along the split axis.  Subtracting the lower
+// face and shifting the span up to bit 31 is order preserving and spreads the FIRST radix digit over all bins
+// (the raw top 11 bits of neighbouring coordinates are nearly identical: every LDS atomic would hit one bin).
+__device__ inline void key_window(const float *__restrict__ lbound, const float *__restrict__ rbound, const int *__restrict__ sd_l, int l,
+                                  long long j, uint32_t &kmin, int &shl)
+{
+	const int node = (1 << l) - 1 + (int)j, a = sd_l[j];
+	kmin = ordered_bits(lbound[3 * node + a]);
+	const uint32_t span = ordered_bits(rbound[3 * node + a]) - kmin;
+	shl = span ? __clz(span) : 0;
+}
+
+// number of kChunk-sized blocks whose element range overlaps node j
+__device__ inline uint32_t chunks_of_node(long long n, long long j, long long m)
+{
+	const long long s = range_start(n, j, m), e = range_start(n, j + 1, m);
+	return (uint32_t)((e - 1) / kChunk - s / kChunk + 1);
+}
+
+// The block that completes node j's histogram of pass PASS descends into the bin holding the pivot rank and
+// publishes the new select state (the classic last-block-done pattern: nobody waits).
+template <int PASS>
+__device__ inline void finish_pass(const uint32_t *__restrict__ hist, SelNode *__restrict__ nodes, long long n, int l, long long j, uint32_t kmin,
+                                   int shl, uint32_t *sh)
+{
+	const long long m = 1LL << l;
+	// the histogram is only ever touched by device-scope atomics and agent-scope loads (both served by the L2), so
+	// completion of this block's atomics is all the ordering the counter needs -- no cache write-back / invalidate
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	if (threadIdx.x == 0) sh[7] = atomicAdd(&nodes[j].done[PASS], 1u);
+	__syncthreads();
+	if (sh[7] != chunks_of_node(n, j, m) - 1) return;   // uniform over the block
+	SelPivot pv;
+	if (PASS == 0) { pv.prefix = 0; pv.r = (uint32_t)(range_start(n, 2 * j + 1, 2 * m) - range_start(n, j, m) - 1); }
+	else { pv.prefix = ld_agent_u32(&nodes[j].prefix); pv.r = ld_agent_u32(&nodes[j].r); }
+	pv.neq = 0; pv.need = 0;
+	descend(hist + ((size_t)PASS * m + j) * kBins, PASS == 2 ? 10 : 11, pv, sh);
+	if (threadIdx.x == 0)
+	{
+		nodes[j].prefix = pv.prefix; nodes[j].r = pv.r; nodes[j].neq = pv.neq; nodes[j].need = pv.need;
+		if (PASS == 2) nodes[j].pivot = (pv.prefix >> shl) + kmin;   // back to the un-normalised ordered key
 	}
 }
 
 template <int PASS>
-__global__ __launch_bounds__(kBlock) void sel_hist_kernel(const float4 *__restrict__ pos, const int *__restrict__ sd_l, const SelNode *__restrict__ nodes,
-                                                          uint32_t *__restrict__ hist, long long n, int l)
+__global__ __launch_bounds__(kBlock) void sel_hist_kernel(const float4 *__restrict__ pos, const int *__restrict__ sd_l, uint32_t *__restrict__ hist,
+                                                          SelNode *__restrict__ nodes, const float *__restrict__ lbound,
+                                                          const float *__restrict__ rbound, long long n, int l)
 {
 	__shared__ uint32_t h[2][kBins];
+	__shared__ uint32_t sh[8];
 	const long long m = 1LL << l;
 	for (int t = threadIdx.x; t < 2 * kBins; t += kBlock) (&h[0][0])[t] = 0;
-	__syncthreads();
 	const long long i0 = (long long)blockIdx.x * kChunk;
-	const long long j0 = (m * i0) / n;
-	for (int e = 0; e < kChunk / kBlock; ++e)
+	const long long ilast = (i0 + kChunk < n ? i0 + kChunk : n) - 1;
+	const long long j0 = (m * i0) / n, j1 = (m * ilast) / n;
+	uint32_t pfx[2] = {0, 0}, kmin[2] = {0, 0};
+	int shl[2] = {0, 0};
+	for (int jj = 0; jj < 2; ++jj)
+		if (j0 + jj <= j1)
+		{
+			if (PASS > 0) pfx[jj] = nodes[j0 + jj].prefix;
+			key_window(lbound, rbound, sd_l, l, j0 + jj, kmin[jj], shl[jj]);
+		}
+	__syncthreads();
+	const long long split = j1 > j0 ? range_start(n, j1, m) : n;
+	const int sd[2] = {sd_l[j0], sd_l[j1]};
+	constexpr int PER = kChunk / kBlock;
+	float4 p[PER];
+#pragma unroll
+	for (int e = 0; e < PER; ++e)
+	{
+		const long long i = i0 + e * kBlock + threadIdx.x;
+		if (i < n) p[e] = pos[i];
+	}
+#pragma unroll
+	for (int e = 0; e < PER; ++e)
 	{
 		const long long i = i0 + e * kBlock + threadIdx.x;
 		if (i < n)
 		{
-			const long long j = (m * i) / n;
-			const uint32_t key = ordered_bits(axis_of(pos[i], sd_l[j]));
+			const int jj = i >= split ? 1 : 0;
+			const uint32_t key = (ordered_bits(axis_of(p[e], sd[jj])) - kmin[jj]) << shl[jj];
 			bool ok = true;
 			uint32_t d = key >> 21;
-			if (PASS == 1) { ok = (key >> 21) == nodes[j].prefix; d = (key >> 10) & 0x7FFu; }
-			if (PASS == 2) { ok = (key >> 10) == nodes[j].prefix; d = key & 0x3FFu; }
-			if (ok) atomicAdd(&h[j - j0][d], 1u);
+			if (PASS == 1) { ok = (key >> 21) == pfx[jj]; d = (key >> 10) & 0x7FFu; }
+			if (PASS == 2) { ok = (key >> 10) == pfx[jj]; d = key & 0x3FFu; }
+			if (ok) atomicAdd(&h[jj][d], 1u);
 		}
 	}
 	__syncthreads();
@@ -83,193 +169,227 @@ __global__ __launch_bounds__(kBlock) void sel_hist_kernel(const float4 *__restri
 	{
 		const uint32_t v = (&h[0][0])[t];
 		const long long j = j0 + (t / kBins);
-		if (v && j < m) atomicAdd(&hist[((size_t)PASS * m + j) * kBins + (t % kBins)], v);
+		if (v && j <= j1) atomicAdd(&hist[((size_t)PASS * m + j) * kBins + (t % kBins)], v);
 	}
+	finish_pass<PASS>(hist, nodes, n, l, j0, kmin[0], shl[0], sh);
+	if (j1 > j0) finish_pass<PASS>(hist, nodes, n, l, j1, kmin[1], shl[1], sh);
 }
 
-// one block per node: locate the bin that holds rank r, descend into it
-template <int PASS>
-__global__ __launch_bounds__(kBlock) void sel_scan_kernel(SelNode *__restrict__ nodes, const uint32_t *__restrict__ hist, int l)
+// exclusive scan over the block of four 16-bit counters packed in a uint64 (each block total <= kChunk < 2^16)
+__device__ inline uint64_t block_scan4(uint64_t v, uint64_t *sh_wave, uint64_t &total)
 {
-	__shared__ uint32_t wsum[kBlock / 64];
-	__shared__ uint32_t found[3];
-	const int m = 1 << l, j = blockIdx.x;
-	const uint32_t *h = hist + ((size_t)PASS * m + j) * kBins;
-	constexpr int PER = kBins / kBlock;
-	uint32_t v[PER], s = 0;
-#pragma unroll
-	for (int q = 0; q < PER; ++q) { v[q] = h[threadIdx.x * PER + q]; s += v[q]; }
-	// exclusive scan of the per-thread sums
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-	uint32_t incl = s;
-	for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(incl, o); if (lane >= o) incl += y; }
-	if (lane == 63) wsum[w] = incl;
-	__syncthreads();
-	uint32_t base = 0;
-	for (int q = 0; q < w; ++q) base += wsum[q];
-	uint32_t cum = base + incl - s;
-	const uint32_t r = nodes[j].r;
-#pragma unroll
-	for (int q = 0; q < PER; ++q)
+	uint64_t incl = v;
+	for (int o = 1; o < 64; o <<= 1)
 	{
-		if (r >= cum && r < cum + v[q]) { found[0] = threadIdx.x * PER + q; found[1] = cum; found[2] = v[q]; }
-		cum += v[q];
+		const uint64_t y = __shfl_up(incl, o);
+		if (lane >= o) incl += y;
 	}
+	if (lane == 63) sh_wave[w] = incl;
 	__syncthreads();
-	if (threadIdx.x == 0)
+	uint64_t base = 0, tot = 0;
+	for (int k = 0; k < kBlock / 64; ++k)
 	{
-		SelNode nd = nodes[j];
-		const int bits = PASS == 2 ? 10 : 11;
-		nd.prefix = (nd.prefix << bits) | found[0];
-		nd.nless += found[1];
-		nd.r -= found[1];
-		if (PASS == 2) { nd.neq = found[2]; nd.need = nd.r + 1; }
-		nodes[j] = nd;
+		const uint64_t t = sh_wave[k];
+		if (k < w) base += t;
+		tot += t;
 	}
+	total = tot;
+	return base + incl - v;
 }
 
+// Unordered partition of every node into [keys below the pivot | keys above the pivot]; elements equal to the
+// pivot go left when all of them belong there and to the tie list otherwise.  All loads of a thread's 8 elements
+// are issued up front, slots are reserved with one packed block scan and four concurrent global atomics.
 __global__ __launch_bounds__(kBlock) void sel_partition_kernel(const float4 *__restrict__ pos_in, const int *__restrict__ unsort_in,
                                                                float4 *__restrict__ pos_out, int *__restrict__ unsort_out,
                                                                const int *__restrict__ sd_l, SelNode *__restrict__ nodes,
                                                                uint32_t *__restrict__ tielist, long long n, int l)
 {
-	__shared__ uint32_t cL[2], cR[2], bL[2], bR[2], mR[2];
+	__shared__ uint64_t sh_wave[kBlock / 64];
+	__shared__ uint32_t base_s[4], mR[2];
 	const long long m = 1LL << l;
-	if (threadIdx.x < 2) { cL[threadIdx.x] = 0; cR[threadIdx.x] = 0; mR[threadIdx.x] = 0xFFFFFFFFu; }
-	__syncthreads();
 	const long long i0 = (long long)blockIdx.x * kChunk;
-	const long long j0 = (m * i0) / n;
+	const long long ilast = (i0 + kChunk < n ? i0 + kChunk : n) - 1;
+	const long long j0 = (m * i0) / n, j1 = (m * ilast) / n;
+	// first element of node j1 (only meaningful when the chunk straddles two nodes)
+	const long long split = j1 > j0 ? range_start(n, j1, m) : n;
+	uint32_t piv[2], all_left[2];
+	for (int jj = 0; jj < 2; ++jj)
+	{
+		const SelNode &nd = nodes[j0 + jj <= j1 ? j0 + jj : j0];
+		piv[jj] = nd.pivot;
+		all_left[jj] = nd.need == nd.neq;
+	}
+	const int sd[2] = {sd_l[j0], sd_l[j1]};
+	if (threadIdx.x < 2) mR[threadIdx.x] = 0xFFFFFFFFu;
 	constexpr int PER = kChunk / kBlock;
-	int cls[PER];          // 0 none, 1 left, 2 right
-	uint32_t rank[PER];
+	float4 p[PER];
+	int org[PER];
+#pragma unroll
+	for (int e = 0; e < PER; ++e)
+	{
+		const long long i = i0 + e * kBlock + threadIdx.x;
+		if (i < n) { p[e] = pos_in[i]; org[e] = unsort_in[i]; }
+	}
+	int cls[PER];   // 0 none / tie, 1 left, 2 right
+	uint64_t cnt = 0;
+	uint32_t tmin[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+#pragma unroll
 	for (int e = 0; e < PER; ++e)
 	{
 		const long long i = i0 + e * kBlock + threadIdx.x;
 		cls[e] = 0;
-		rank[e] = 0;
 		if (i < n)
 		{
-			const long long j = (m * i) / n;
-			const int jj = (int)(j - j0);
-			const uint32_t key = ordered_bits(axis_of(pos_in[i], sd_l[j]));
-			const uint32_t piv = nodes[j].prefix;
-			if (key < piv || (key == piv && nodes[j].need == nodes[j].neq)) { cls[e] = 1; rank[e] = atomicAdd(&cL[jj], 1u); }
-			else if (key > piv) { cls[e] = 2; rank[e] = atomicAdd(&cR[jj], 1u); atomicMin(&mR[jj], key); }
+			const int jj = i >= split ? 1 : 0;
+			const uint32_t key = ordered_bits(axis_of(p[e], sd[jj]));
+			if (key < piv[jj] || (key == piv[jj] && all_left[jj])) { cls[e] = 1; cnt += 1ull << (32 * jj); }
+			else if (key > piv[jj]) { cls[e] = 2; cnt += 1ull << (32 * jj + 16); tmin[jj] = key < tmin[jj] ? key : tmin[jj]; }
 			else
 			{
-				const uint32_t t = atomicAdd(&nodes[j].tiecnt, 1u);
-				if (t < kTieCap) tielist[(size_t)j * kTieCap + t] = (uint32_t)i;
+				const uint32_t t = atomicAdd(&nodes[j0 + jj].tiecnt, 1u);
+				if (t < kTieCap) tielist[(size_t)(j0 + jj) * kTieCap + t] = (uint32_t)i;
 			}
+		}
+	}
+	uint64_t tot;
+	const uint64_t off = block_scan4(cnt, sh_wave, tot);
+	if (threadIdx.x < 4)
+	{
+		const int jj = threadIdx.x >> 1, right = threadIdx.x & 1;
+		const uint32_t c = (uint32_t)((tot >> (16 * threadIdx.x)) & 0xFFFF);
+		base_s[threadIdx.x] = c ? atomicAdd(right ? &nodes[j0 + jj].cntR : &nodes[j0 + jj].cntL, c) : 0;
+	}
+#pragma unroll
+	for (int q = 0; q < 2; ++q)
+	{
+		uint32_t v = tmin[q];
+		for (int o = 32; o > 0; o >>= 1) { const uint32_t y = __shfl_xor(v, o); v = y < v ? y : v; }
+		if ((threadIdx.x & 63) == 0 && v != 0xFFFFFFFFu) atomicMin(&mR[q], v);
+	}
+	__syncthreads();
+	if (threadIdx.x < 2 && mR[threadIdx.x] != 0xFFFFFFFFu) atomicMax(&nodes[j0 + threadIdx.x].minR, ~mR[threadIdx.x]);
+	// destination cursors of this thread: [left0, right0, left1, right1]
+	long long cur[4];
+#pragma unroll
+	for (int q = 0; q < 4; ++q)
+	{
+		const int jj = q >> 1;
+		const long long j = j0 + jj;
+		const long long region = (q & 1) ? range_start(n, 2 * j + 1, 2 * m) : range_start(n, j, m);
+		cur[q] = region + base_s[q] + (long long)((off >> (16 * q)) & 0xFFFF);
+	}
+#pragma unroll
+	for (int e = 0; e < PER; ++e)
+	{
+		if (!cls[e]) continue;
+		const long long i = i0 + e * kBlock + threadIdx.x;
+		const int q = (i >= split ? 2 : 0) + (cls[e] - 1);
+		const long long dst = q == 0 ? cur[0]++ : (q == 1 ? cur[1]++ : (q == 2 ? cur[2]++ : cur[3]++));
+		pos_out[dst] = p[e];
+		unsort_out[dst] = org[e];
+	}
+}
+
+#pragma clang fp contract(off)
+// One block per node of level l.  Wave 0 first orders the elements that tie with the pivot by the remaining
+// keys of the stable-sort chain -- the next distinct ancestor split axes, then the original index -- and
+// hands the first `need` of them to the left child; then evalBox for the two children
+// (fmm_cart3_kdtree.cuh:109-137): the sorted order's boundary elements are the pivot (largest key of the
+// left child) and the smallest key of the right child.
+__global__ __launch_bounds__(64) void sel_ties_box_kernel(const float4 *__restrict__ pos_in, const int *__restrict__ unsort_in,
+                                                              float4 *__restrict__ pos_out, int *__restrict__ unsort_out,
+                                                              float *__restrict__ lbound, float *__restrict__ rbound, int *__restrict__ splitdim,
+                                                              int *__restrict__ index, SelNode *__restrict__ nodes,
+                                                              const uint32_t *__restrict__ tielist, int *__restrict__ flag, long long n, int l)
+{
+	__shared__ uint32_t tie_min;
+	const int m = 1 << l, j = blockIdx.x, lane = threadIdx.x;
+	const SelPivot pv{nodes[j].pivot, nodes[j].r, nodes[j].neq, nodes[j].need};
+	const int node = m - 1 + j, a1 = splitdim[node];
+	const uint32_t nt = nodes[j].tiecnt;
+	if (threadIdx.x == 0) tie_min = 0;
+	__syncthreads();
+	if (nt > kTieCap) { if (threadIdx.x == 0) *flag = 1; }
+	else if (nt > 0)
+	{
+		int a2 = -1, a3 = -1;
+		for (int anc = node; anc > 0;)
+		{
+			anc = (anc - 1) >> 1;
+			const int a = splitdim[anc];
+			if (a == a1 || a == a2) continue;
+			if (a2 < 0) a2 = a;
+			else { a3 = a; break; }
+		}
+		uint32_t idx = 0, k2 = 0, k3 = 0, org = 0;
+		if ((uint32_t)lane < nt)
+		{
+			idx = tielist[(size_t)j * kTieCap + lane];
+			const float4 p = pos_in[idx];
+			k2 = a2 >= 0 ? ordered_bits(axis_of(p, a2)) : 0;
+			k3 = a3 >= 0 ? ordered_bits(axis_of(p, a3)) : 0;
+			org = (uint32_t)unsort_in[idx];
+		}
+		uint32_t rank = 0;
+		for (uint32_t q = 0; q < nt; ++q)
+		{
+			const uint32_t q2 = __shfl(k2, q), q3 = __shfl(k3, q), qo = __shfl(org, q);
+			const bool before = q2 < k2 || (q2 == k2 && (q3 < k3 || (q3 == k3 && qo < org)));
+			rank += before ? 1u : 0u;
+		}
+		if ((uint32_t)lane < nt)
+		{
+			long long dst;
+			if (rank < pv.need) dst = range_start(n, j, m) + atomicAdd(&nodes[j].cntL, 1u);
+			else
+			{
+				dst = range_start(n, 2 * j + 1, 2LL * m) + atomicAdd(&nodes[j].cntR, 1u);
+				tie_min = 1;   // a pivot-valued element went right: it is the right child's smallest key
+			}
+			pos_out[dst] = pos_in[idx];
+			unsort_out[dst] = unsort_in[idx];
 		}
 	}
 	__syncthreads();
 	if (threadIdx.x < 2)
 	{
-		const long long j = j0 + threadIdx.x;
-		if (j < m)
+		const int c = 2 * j + threadIdx.x, child = 2 * m - 1 + c;
+		float lb[3] = {lbound[3 * node], lbound[3 * node + 1], lbound[3 * node + 2]};
+		float rb[3] = {rbound[3 * node], rbound[3 * node + 1], rbound[3 * node + 2]};
+		if (c & 1)
 		{
-			bL[threadIdx.x] = cL[threadIdx.x] ? atomicAdd(&nodes[j].cntL, cL[threadIdx.x]) : 0;
-			bR[threadIdx.x] = cR[threadIdx.x] ? atomicAdd(&nodes[j].cntR, cR[threadIdx.x]) : 0;
-			if (mR[threadIdx.x] != 0xFFFFFFFFu) atomicMin(&nodes[j].minR, mR[threadIdx.x]);
+			const uint32_t mr = tie_min ? pv.prefix : ~nodes[j].minR;
+			const float v = unordered_bits(mr);
+			if (a1 == 0) lb[0] = v; else if (a1 == 1) lb[1] = v; else lb[2] = v;
 		}
-	}
-	__syncthreads();
-	for (int e = 0; e < PER; ++e)
-	{
-		if (!cls[e]) continue;
-		const long long i = i0 + e * kBlock + threadIdx.x;
-		const long long j = (m * i) / n;
-		const int jj = (int)(j - j0);
-		const long long dst = cls[e] == 1 ? range_start(n, j, m) + bL[jj] + rank[e] : range_start(n, 2 * j + 1, 2 * m) + bR[jj] + rank[e];
-		pos_out[dst] = pos_in[i];
-		unsort_out[dst] = unsort_in[i];
-	}
-}
-
-// one wave per node: order the elements that tie with the pivot by the remaining keys of the stable-sort
-// chain -- the next distinct ancestor split axes, then the original index -- and hand the first `need`
-// of them to the left child
-__global__ __launch_bounds__(64) void sel_ties_kernel(const float4 *__restrict__ pos_in, const int *__restrict__ unsort_in,
-                                                      float4 *__restrict__ pos_out, int *__restrict__ unsort_out, const int *__restrict__ splitdim,
-                                                      SelNode *__restrict__ nodes, const uint32_t *__restrict__ tielist, int *__restrict__ flag,
-                                                      long long n, int l)
-{
-	const int m = 1 << l, j = blockIdx.x, lane = threadIdx.x;
-	const uint32_t nt = nodes[j].tiecnt;
-	if (nt == 0) return;
-	if (nt > kTieCap) { if (lane == 0) *flag = 1; return; }
-	// next two distinct axes above this node
-	const int node = m - 1 + j, a1 = splitdim[node];
-	int a2 = -1, a3 = -1;
-	for (int anc = node; anc > 0;)
-	{
-		anc = (anc - 1) >> 1;
-		const int a = splitdim[anc];
-		if (a == a1 || a == a2) continue;
-		if (a2 < 0) a2 = a;
-		else { a3 = a; break; }
-	}
-	uint32_t idx = 0, k2 = 0, k3 = 0, org = 0;
-	if ((uint32_t)lane < nt)
-	{
-		idx = tielist[(size_t)j * kTieCap + lane];
-		const float4 p = pos_in[idx];
-		k2 = a2 >= 0 ? ordered_bits(axis_of(p, a2)) : 0;
-		k3 = a3 >= 0 ? ordered_bits(axis_of(p, a3)) : 0;
-		org = (uint32_t)unsort_in[idx];
-	}
-	uint32_t rank = 0;
-	for (uint32_t q = 0; q < nt; ++q)
-	{
-		const uint32_t q2 = __shfl(k2, q), q3 = __shfl(k3, q), qo = __shfl(org, q);
-		const bool before = q2 < k2 || (q2 == k2 && (q3 < k3 || (q3 == k3 && qo < org)));
-		rank += before ? 1u : 0u;
-	}
-	if ((uint32_t)lane < nt)
-	{
-		const uint32_t need = nodes[j].need;
-		long long dst;
-		if (rank < need) dst = range_start(n, j, m) + atomicAdd(&nodes[j].cntL, 1u);
 		else
 		{
-			dst = range_start(n, 2 * j + 1, 2LL * m) + atomicAdd(&nodes[j].cntR, 1u);
-			atomicMin(&nodes[j].minR, nodes[j].prefix);
+			const float v = unordered_bits(pv.prefix);
+			if (a1 == 0) rb[0] = v; else if (a1 == 1) rb[1] = v; else rb[2] = v;
 		}
-		pos_out[dst] = pos_in[idx];
-		unsort_out[dst] = unsort_in[idx];
+		lbound[3 * child] = lb[0]; lbound[3 * child + 1] = lb[1]; lbound[3 * child + 2] = lb[2];
+		rbound[3 * child] = rb[0]; rbound[3 * child + 1] = rb[1]; rbound[3 * child + 2] = rb[2];
+		splitdim[child] = longest_axis(rb[0] - lb[0], rb[1] - lb[1], rb[2] - lb[2]);
+		index[child] = (int)range_start(n, c, 2LL * m);
 	}
-}
-
-#pragma clang fp contract(off)
-// evalBox for the children of level l (fmm_cart3_kdtree.cuh:109-137): the sorted order's boundary
-// elements are the pivot (largest key of the left child) and the smallest key of the right child
-__global__ __launch_bounds__(kBlock) void sel_box_kernel(float *__restrict__ lbound, float *__restrict__ rbound, int *__restrict__ splitdim,
-                                                         int *__restrict__ index, const SelNode *__restrict__ nodes, long long n, int l)
-{
-	const int m = 1 << l;
-	const int c = blockIdx.x * kBlock + threadIdx.x;
-	if (c >= 2 * m) return;
-	const int j = c >> 1, parent = m - 1 + j, node = 2 * m - 1 + c, split = splitdim[parent];
-	float lb[3] = {lbound[3 * parent], lbound[3 * parent + 1], lbound[3 * parent + 2]};
-	float rb[3] = {rbound[3 * parent], rbound[3 * parent + 1], rbound[3 * parent + 2]};
-	if (c & 1)
-	{
-		const float v = unordered_bits(nodes[j].minR);
-		if (split == 0) lb[0] = v; else if (split == 1) lb[1] = v; else lb[2] = v;
-	}
-	else
-	{
-		const float v = unordered_bits(nodes[j].prefix);
-		if (split == 0) rb[0] = v; else if (split == 1) rb[1] = v; else rb[2] = v;
-	}
-	lbound[3 * node] = lb[0]; lbound[3 * node + 1] = lb[1]; lbound[3 * node + 2] = lb[2];
-	rbound[3 * node] = rb[0]; rbound[3 * node + 1] = rb[1]; rbound[3 * node + 2] = rb[2];
-	splitdim[node] = longest_axis(rb[0] - lb[0], rb[1] - lb[1], rb[2] - lb[2]);
-	index[node] = (int)range_start(n, c, 2LL * m);
 }
 #pragma clang fp contract(on)
 
 } // namespace
+
+// Zero the pass histograms and node counters of levels 0 .. l0-1 (one memset each per build).
+int kd_select_begin(nbco_ctx *c, int l0)
+{
+	const size_t nodes = ((size_t)1 << l0) - 1;
+	NBCO_TRY(c->reserve(c->sel_hist, sizeof(uint32_t) * 3 * nodes * kBins));
+	NBCO_TRY(c->reserve(c->sel_nodes, sizeof(SelNode) * nodes));
+	NBCO_TRY(c->reserve(c->sel_ties, sizeof(uint32_t) * nodes * kTieCap));
+	NBCO_HIP(hipMemsetAsync(c->sel_hist.ptr, 0, sizeof(uint32_t) * 3 * nodes * kBins, c->stream));
+	NBCO_HIP(hipMemsetAsync(c->sel_nodes.ptr, 0, sizeof(SelNode) * nodes, c->stream));
+	return NBCO_OK;
+}
 
 // Split every node of level l (all of which hold more than 4096 particles) and write the boxes of level
 // l + 1.  `flag` (device int) is set when a node had more ties than the resolver handles.
@@ -277,30 +397,19 @@ int kd_select_level(nbco_ctx *c, int l, long long n, const float4 *pos_in, const
                     float *lbound, float *rbound, int *splitdim, int *index, int *flag)
 {
 	const int m = 1 << l;
-	const size_t hist_bytes = sizeof(uint32_t) * 3 * (size_t)m * kBins;
-	NBCO_TRY(c->reserve(c->sel_hist, hist_bytes));
-	NBCO_TRY(c->reserve(c->sel_nodes, sizeof(SelNode) * (size_t)m));
-	NBCO_TRY(c->reserve(c->sel_ties, sizeof(uint32_t) * (size_t)m * kTieCap));
-	SelNode *nodes = c->sel_nodes.as<SelNode>();
-	uint32_t *hist = c->sel_hist.as<uint32_t>();
-	uint32_t *ties = c->sel_ties.as<uint32_t>();
+	// level l uses the slices [m - 1, 2m - 1) of the per-build arrays
+	SelNode *nodes = c->sel_nodes.as<SelNode>() + (m - 1);
+	uint32_t *hist = c->sel_hist.as<uint32_t>() + (size_t)3 * (m - 1) * kBins;
+	uint32_t *ties = c->sel_ties.as<uint32_t>() + (size_t)(m - 1) * kTieCap;
 	const int *sd_l = splitdim + (m - 1);
 	hipStream_t st = c->stream;
 	const int gchunks = (int)((n + kChunk - 1) / kChunk);
-	int ginit = (int)((3LL * m * kBins + kBlock - 1) / kBlock);
-	if (ginit > 2048) ginit = 2048;
-	hipLaunchKernelGGL(sel_init_kernel, dim3(ginit), dim3(kBlock), 0, st, nodes, hist, n, l);
-	hipLaunchKernelGGL(sel_hist_kernel<0>, dim3(gchunks), dim3(kBlock), 0, st, pos_in, sd_l, (const SelNode *)nodes, hist, n, l);
-	hipLaunchKernelGGL(sel_scan_kernel<0>, dim3(m), dim3(kBlock), 0, st, nodes, (const uint32_t *)hist, l);
-	hipLaunchKernelGGL(sel_hist_kernel<1>, dim3(gchunks), dim3(kBlock), 0, st, pos_in, sd_l, (const SelNode *)nodes, hist, n, l);
-	hipLaunchKernelGGL(sel_scan_kernel<1>, dim3(m), dim3(kBlock), 0, st, nodes, (const uint32_t *)hist, l);
-	hipLaunchKernelGGL(sel_hist_kernel<2>, dim3(gchunks), dim3(kBlock), 0, st, pos_in, sd_l, (const SelNode *)nodes, hist, n, l);
-	hipLaunchKernelGGL(sel_scan_kernel<2>, dim3(m), dim3(kBlock), 0, st, nodes, (const uint32_t *)hist, l);
+	hipLaunchKernelGGL(sel_hist_kernel<0>, dim3(gchunks), dim3(kBlock), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l);
+	hipLaunchKernelGGL(sel_hist_kernel<1>, dim3(gchunks), dim3(kBlock), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l);
+	hipLaunchKernelGGL(sel_hist_kernel<2>, dim3(gchunks), dim3(kBlock), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l);
 	hipLaunchKernelGGL(sel_partition_kernel, dim3(gchunks), dim3(kBlock), 0, st, pos_in, unsort_in, pos_out, unsort_out, sd_l, nodes, ties, n, l);
-	hipLaunchKernelGGL(sel_ties_kernel, dim3(m), dim3(64), 0, st, pos_in, unsort_in, pos_out, unsort_out, (const int *)splitdim, nodes,
+	hipLaunchKernelGGL(sel_ties_box_kernel, dim3(m), dim3(64), 0, st, pos_in, unsort_in, pos_out, unsort_out, lbound, rbound, splitdim, index, nodes,
 	                   (const uint32_t *)ties, flag, n, l);
-	hipLaunchKernelGGL(sel_box_kernel, dim3((2 * m + kBlock - 1) / kBlock), dim3(kBlock), 0, st, lbound, rbound, splitdim, index,
-	                   (const SelNode *)nodes, n, l);
 	NBCO_HIP(hipGetLastError());
 	return NBCO_OK;
 }

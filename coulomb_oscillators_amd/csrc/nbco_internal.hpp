@@ -138,6 +138,7 @@ int launch_energy(nbco_ctx *c, const float *buf, long long n, const float *param
 int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *param);
 int kd_copy_out(nbco_ctx *c, int which, void *host_dst, long long host_bytes);
 // k_kdselect.hip
+int kd_select_begin(nbco_ctx *c, int l0);
 int kd_select_level(nbco_ctx *c, int l, long long n, const float4 *pos_in, const int *unsort_in, float4 *pos_out, int *unsort_out,
                     float *lbound, float *rbound, int *splitdim, int *index, int *flag);
 // k_farfield.hip
