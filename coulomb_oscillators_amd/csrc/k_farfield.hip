@@ -70,6 +70,17 @@ __device__ inline void parent_centre(const float *center, const int *mult, int k
 		c[a] = s / ft;
 	}
 }
+// same rounding with the children's data passed in
+__device__ inline void centre_of(int m0, int m1, const float *c0, const float *c1, float c[3])
+{
+	const float f0 = (float)m0, f1 = (float)m1, ft = (float)(m0 + m1);
+	for (int a = 0; a < 3; ++a)
+	{
+		float s = f0 * c0[a];
+		s = s + f1 * c1[a];
+		c[a] = s / ft;
+	}
+}
 #pragma clang fp contract(on)
 
 template <int P, bool AGENT>
@@ -112,14 +123,69 @@ __global__ __launch_bounds__(kBlock) void m2m_gen_kernel(float *center, float *m
 	m2m_node<P, false>(center, mpole, mult, (1 << l) - 1 + i);
 }
 
-// levels ltop .. 0 in one workgroup
+// levels ltop .. 0 in one workgroup.  The expansions, centres and multiplicities of the level just built stay
+// in LDS (node i of a level sits in slot i), so a level costs LDS latency instead of HBM round trips.
 template <int P>
 __global__ __launch_bounds__(kTopNodes) void m2m_top_kernel(float *center, float *mpole, int *mult, int ltop)
 {
+	constexpr int offM = P * (P + 1) * (P + 2) / 6, offS = offM > 0 ? offM : 1;
+	extern __shared__ float lds[];
+	float *Ml = lds;                                  // [2^ltop][offS]
+	float *Cl = Ml + (size_t)(1 << ltop) * offS;      // [2^ltop][3]
+	int *Nl = (int *)(Cl + (size_t)(1 << ltop) * 3);  // [2^ltop]
+	const int t = threadIdx.x;
 	for (int l = ltop; l >= 0; --l)
 	{
-		if ((int)threadIdx.x < (1 << l)) m2m_node<P, true>(center, mpole, mult, (1 << l) - 1 + threadIdx.x);
-		__threadfence();
+		const bool on = t < (1 << l);
+		const int k = (1 << l) - 1 + t;
+		float A[offS], c[3] = {0.f, 0.f, 0.f};
+		int mlt = 0;
+		if (on)
+		{
+#pragma unroll
+			for (int q = 0; q < offS; ++q) A[q] = 0.f;
+			if (l == ltop)
+			{
+				// children are in HBM (written by the previous launch)
+				parent_centre<false>(center, mult, k, c, mlt);
+				if (P >= 3)
+					for (int ch = 0; ch < 2; ++ch)
+					{
+						const int child = 2 * k + 1 + ch;
+						m2m_accum<P>(mpole + (size_t)child * offM, c[0] - center[3 * child], c[1] - center[3 * child + 1],
+						             c[2] - center[3 * child + 2], A);
+					}
+			}
+			else
+			{
+				const int s0 = 2 * t, s1 = 2 * t + 1;   // LDS slots of the children
+				const int m0 = Nl[s0], m1 = Nl[s1];
+				mlt = m0 + m1;
+				centre_of(m0, m1, Cl + 3 * s0, Cl + 3 * s1, c);
+				if (P >= 3)
+					for (int ch = 0; ch < 2; ++ch)
+					{
+						const int sl = 2 * t + ch;
+						m2m_accum<P>(Ml + (size_t)sl * offS, c[0] - Cl[3 * sl], c[1] - Cl[3 * sl + 1], c[2] - Cl[3 * sl + 2], A);
+					}
+			}
+		}
+		__syncthreads();   // all reads of the child slots are done
+		if (on)
+		{
+			float *M = mpole + (size_t)k * offM;
+			float *Ms = Ml + (size_t)t * offS;
+			if (offM > 0) M[0] = (float)mlt;
+			if (offM > 1) { M[1] = 0.f; M[2] = 0.f; M[3] = 0.f; }
+			m2m_store<P>(A, M);
+			if (offM > 0) Ms[0] = (float)mlt;
+			if (offM > 1) { Ms[1] = 0.f; Ms[2] = 0.f; Ms[3] = 0.f; }
+			m2m_store<P>(A, Ms);
+			center[3 * k] = c[0]; center[3 * k + 1] = c[1]; center[3 * k + 2] = c[2];
+			mult[k] = mlt;
+			Cl[3 * t] = c[0]; Cl[3 * t + 1] = c[1]; Cl[3 * t + 2] = c[2];
+			Nl[t] = mlt;
+		}
 		__syncthreads();
 	}
 }
@@ -147,14 +213,41 @@ __global__ __launch_bounds__(kBlock) void l2l_gen_kernel(const float *__restrict
 	l2l_node<P, false>(center, local, (1 << lchild) - 1 + i);
 }
 
-// child levels 2 .. ltop in one workgroup
+// child levels 2 .. ltop in one workgroup; the level just finished stays in LDS as the next level's parents
 template <int P>
 __global__ __launch_bounds__(kTopNodes) void l2l_top_kernel(const float *__restrict__ center, float *local, int ltop)
 {
+	constexpr int offL = (P + 1) * (P + 1);
+	extern __shared__ float lds[];   // [2^ltop][offL]
+	const int t = threadIdx.x;
+	// level-1 nodes are the first parents
+	if (t < 2)
+		for (int q = 0; q < offL; ++q) lds[(size_t)t * offL + q] = local[(size_t)(1 + t) * offL + q];
+	__syncthreads();
 	for (int lc = 2; lc <= ltop; ++lc)
 	{
-		if ((int)threadIdx.x < (1 << lc)) l2l_node<P, true>(center, local, (1 << lc) - 1 + threadIdx.x);
-		__threadfence();
+		const bool on = t < (1 << lc);
+		const int c = (1 << lc) - 1 + t, p = (c - 1) >> 1;
+		float O[offL];
+		if (on)
+		{
+			float Lp[offL];
+			const float *src = lds + (size_t)(t >> 1) * offL;
+#pragma unroll
+			for (int q = 0; q < offL; ++q) Lp[q] = src[q];
+			l2l_body<P>(Lp, center[3 * c] - center[3 * p], center[3 * c + 1] - center[3 * p + 1], center[3 * c + 2] - center[3 * p + 2], O);
+			float *Lc = local + (size_t)c * offL;
+#pragma unroll
+			for (int q = 1; q < offL; ++q) { O[q] += Lc[q]; Lc[q] = O[q]; }
+			O[0] = 0.f;
+		}
+		__syncthreads();
+		if (on)
+		{
+			float *dst = lds + (size_t)t * offL;
+#pragma unroll
+			for (int q = 0; q < offL; ++q) dst[q] = O[q];
+		}
 		__syncthreads();
 	}
 }
@@ -202,10 +295,14 @@ static int run_upward(nbco_ctx *c, const float4 *pos, float *center, float *mpol
 	const int nleaf = 1 << L, beg = nleaf - 1;
 	hipLaunchKernelGGL(p2m_gen_kernel<P>, dim3(grid_for(nleaf)), dim3(kBlock), 0, c->stream, pos, (const float *)center, (const int *)mult, index,
 	                   mpole, beg, nleaf);
+	constexpr int offM = P * (P + 1) * (P + 2) / 6, offS = offM > 0 ? offM : 1;
+	int top = kTopNodes;
+	while (top > 1 && (size_t)top * (offS + 4) * sizeof(float) > 60 * 1024) top >>= 1;   // LDS budget of the fused top kernel
 	int l = L - 1;
-	for (; l >= 0 && (1 << l) > kTopNodes; --l)
+	for (; l >= 0 && (1 << l) > top; --l)
 		hipLaunchKernelGGL(m2m_gen_kernel<P>, dim3(grid_for(1 << l)), dim3(kBlock), 0, c->stream, center, mpole, mult, l);
-	if (l >= 0) hipLaunchKernelGGL(m2m_top_kernel<P>, dim3(1), dim3(kTopNodes), 0, c->stream, center, mpole, mult, l);
+	if (l >= 0)
+		hipLaunchKernelGGL(m2m_top_kernel<P>, dim3(1), dim3(kTopNodes), (size_t)(1 << l) * (offS + 4) * sizeof(float), c->stream, center, mpole, mult, l);
 	NBCO_HIP(hipGetLastError());
 	return NBCO_OK;
 }
@@ -213,9 +310,13 @@ static int run_upward(nbco_ctx *c, const float4 *pos, float *center, float *mpol
 template <int P>
 static int run_downward(nbco_ctx *c, const float *center, float *local, int L)
 {
+	constexpr int offL = (P + 1) * (P + 1);
+	int top = kTopNodes;
+	while (top > 4 && (size_t)top * offL * sizeof(float) > 60 * 1024) top >>= 1;
 	int ltop = 1;
-	while (ltop + 1 <= L && (1 << (ltop + 1)) <= kTopNodes) ++ltop;
-	if (ltop >= 2) hipLaunchKernelGGL(l2l_top_kernel<P>, dim3(1), dim3(kTopNodes), 0, c->stream, center, local, ltop);
+	while (ltop + 1 <= L && (1 << (ltop + 1)) <= top) ++ltop;
+	if (ltop >= 2)
+		hipLaunchKernelGGL(l2l_top_kernel<P>, dim3(1), dim3(kTopNodes), (size_t)(1 << ltop) * offL * sizeof(float), c->stream, center, local, ltop);
 	for (int lc = ltop + 1; lc <= L; ++lc)
 		hipLaunchKernelGGL(l2l_gen_kernel<P>, dim3(grid_for(1 << lc)), dim3(kBlock), 0, c->stream, center, local, lc);
 	NBCO_HIP(hipGetLastError());
