@@ -10,7 +10,9 @@ from .engine import (Engine, EngineError, lib_path, build_library, default_opts,
                      EVAL_DIRECT, EVAL_DIRECT_KAHAN, EVAL_FMM_KDTREE, EVAL_FMM_TRACELESS,
                      INTEG_EULER, INTEG_PRE_EULER, INTEG_LEAPFROG, INTEG_FORESTRUTH, INTEG_PEFRL,
                      PHASES)
+from .dist import DomainRun, TorchComm, SingleComm, LoopbackWorld
 
 __all__ = ["Engine", "EngineError", "lib_path", "build_library", "default_opts",
            "EVAL_DIRECT", "EVAL_DIRECT_KAHAN", "EVAL_FMM_KDTREE", "EVAL_FMM_TRACELESS",
-           "INTEG_EULER", "INTEG_PRE_EULER", "INTEG_LEAPFROG", "INTEG_FORESTRUTH", "INTEG_PEFRL", "PHASES"]
+           "INTEG_EULER", "INTEG_PRE_EULER", "INTEG_LEAPFROG", "INTEG_FORESTRUTH", "INTEG_PEFRL", "PHASES",
+           "DomainRun", "TorchComm", "SingleComm", "LoopbackWorld"]

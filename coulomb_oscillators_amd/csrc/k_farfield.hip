@@ -206,11 +206,11 @@ __device__ inline void l2l_node(const float *center, float *local, int c)
 }
 
 template <int P>
-__global__ __launch_bounds__(kBlock) void l2l_gen_kernel(const float *__restrict__ center, float *local, int lchild)
+__global__ __launch_bounds__(kBlock) void l2l_gen_kernel(const float *__restrict__ center, float *local, int lchild, int first, int count)
 {
 	const int i = blockIdx.x * kBlock + threadIdx.x;
-	if (i >= (1 << lchild)) return;
-	l2l_node<P, false>(center, local, (1 << lchild) - 1 + i);
+	if (i >= count) return;
+	l2l_node<P, false>(center, local, (1 << lchild) - 1 + first + i);
 }
 
 // child levels 2 .. ltop in one workgroup; the level just finished stays in LDS as the next level's parents
@@ -259,11 +259,13 @@ __global__ __launch_bounds__(kBlock) void l2p_gen_kernel(const float4 *__restric
                                                          const float *__restrict__ local, const float4 *__restrict__ near,
                                                          const int *__restrict__ chunk_off, const int *__restrict__ index, int mlt_max,
                                                          const int *__restrict__ unsort, int scatter, const float *__restrict__ param,
-                                                         float *__restrict__ a_out, int have_near, long long n, int L)
+                                                         float *__restrict__ a_out, int have_near, long long n, int L, long long own0,
+                                                         long long own_n)
 {
 	constexpr int offL = (P + 1) * (P + 1);
-	const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
-	if (i >= n) return;
+	const long long io = (long long)blockIdx.x * kBlock + threadIdx.x;   // index among the domain's own particles
+	if (io >= own_n) return;
+	const long long i = own0 + io;
 	const int lf = (int)(((1LL << L) * i) / n), leaf = (1 << L) - 1 + lf;
 	const float4 p = pos[i];
 	float Lp[offL];
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(kBlock) void l2p_gen_kernel(const float4 *__restric
 		fx += nx; fy += ny; fz += nz;
 	}
 	const float scale = param ? param[0] : 1.f;
-	const long long o = scatter ? (long long)unsort[i] : i;
+	const long long o = scatter ? (long long)unsort[io] : io;
 	a_out[3 * o] = fx * scale; a_out[3 * o + 1] = fy * scale; a_out[3 * o + 2] = fz * scale;
 }
 
@@ -307,8 +309,20 @@ static int run_upward(nbco_ctx *c, const float4 *pos, float *center, float *mpol
 	return NBCO_OK;
 }
 
+// levels ltop .. 0 of a tree whose level ltop + 1 is already in place (the levels above the kd-domains)
 template <int P>
-static int run_downward(nbco_ctx *c, const float *center, float *local, int L)
+static int run_m2m_top(nbco_ctx *c, float *center, float *mpole, int *mult, int ltop)
+{
+	constexpr int offM = P * (P + 1) * (P + 2) / 6, offS = offM > 0 ? offM : 1;
+	if ((1 << ltop) > kTopNodes || (size_t)(1 << ltop) * (offS + 4) * sizeof(float) > 60 * 1024)
+		return c->fail(NBCO_ERR_UNSUPPORTED, "launch_m2m_top_gen: too many top levels");
+	hipLaunchKernelGGL(m2m_top_kernel<P>, dim3(1), dim3(kTopNodes), (size_t)(1 << ltop) * (offS + 4) * sizeof(float), c->stream, center, mpole, mult, ltop);
+	NBCO_HIP(hipGetLastError());
+	return NBCO_OK;
+}
+
+template <int P>
+static int run_downward(nbco_ctx *c, const float *center, float *local, int L, int dom_d, int dom_g)
 {
 	constexpr int offL = (P + 1) * (P + 1);
 	int top = kTopNodes;
@@ -318,17 +332,22 @@ static int run_downward(nbco_ctx *c, const float *center, float *local, int L)
 	if (ltop >= 2)
 		hipLaunchKernelGGL(l2l_top_kernel<P>, dim3(1), dim3(kTopNodes), (size_t)(1 << ltop) * offL * sizeof(float), c->stream, center, local, ltop);
 	for (int lc = ltop + 1; lc <= L; ++lc)
-		hipLaunchKernelGGL(l2l_gen_kernel<P>, dim3(grid_for(1 << lc)), dim3(kBlock), 0, c->stream, center, local, lc);
+	{
+		// below the domain level only the own subtree's nodes are needed
+		const int first = lc >= dom_d ? dom_g << (lc - dom_d) : 0, count = lc >= dom_d ? 1 << (lc - dom_d) : 1 << lc;
+		hipLaunchKernelGGL(l2l_gen_kernel<P>, dim3(grid_for(count)), dim3(kBlock), 0, c->stream, center, local, lc, first, count);
+	}
 	NBCO_HIP(hipGetLastError());
 	return NBCO_OK;
 }
 
 template <int P>
 static int run_l2p(nbco_ctx *c, const float4 *pos, const float *center, const float *local, const float4 *near, const int *chunk_off,
-                   const int *index, int mlt_max, const int *unsort, int scatter, const float *param, float *a, int have_near, long long n, int L)
+                   const int *index, int mlt_max, const int *unsort, int scatter, const float *param, float *a, int have_near, long long n, int L,
+                   long long own0, long long own_n)
 {
-	hipLaunchKernelGGL(l2p_gen_kernel<P>, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, pos, center, local, near, chunk_off, index, mlt_max,
-	                   unsort, scatter, param, a, have_near, n, L);
+	hipLaunchKernelGGL(l2p_gen_kernel<P>, dim3(grid_for(own_n)), dim3(kBlock), 0, c->stream, pos, center, local, near, chunk_off, index, mlt_max,
+	                   unsort, scatter, param, a, have_near, n, L, own0, own_n);
 	NBCO_HIP(hipGetLastError());
 	return NBCO_OK;
 }
@@ -350,17 +369,25 @@ int launch_upward_gen(nbco_ctx *c, int P, const float4 *pos, float *center, floa
 #undef CALL
 }
 
-int launch_downward_gen(nbco_ctx *c, int P, const float *center, float *local, int L)
+int launch_m2m_top_gen(nbco_ctx *c, int P, float *center, float *mpole, int *mult, int ltop)
 {
-#define CALL(PP) run_downward<PP>(c, center, local, L)
+#define CALL(PP) run_m2m_top<PP>(c, center, mpole, mult, ltop)
+	NBCO_DISPATCH_P(P, CALL)
+#undef CALL
+}
+
+int launch_downward_gen(nbco_ctx *c, int P, const float *center, float *local, int L, int dom_d, int dom_g)
+{
+#define CALL(PP) run_downward<PP>(c, center, local, L, dom_d, dom_g)
 	NBCO_DISPATCH_P(P, CALL)
 #undef CALL
 }
 
 int launch_l2p_gen(nbco_ctx *c, int P, const float4 *pos, const float *center, const float *local, const float4 *near, const int *chunk_off,
-                   const int *index, int mlt_max, const int *unsort, int scatter, const float *param, float *a, int have_near, long long n, int L)
+                   const int *index, int mlt_max, const int *unsort, int scatter, const float *param, float *a, int have_near, long long n, int L,
+                   long long own0, long long own_n)
 {
-#define CALL(PP) run_l2p<PP>(c, pos, center, local, near, chunk_off, index, mlt_max, unsort, scatter, param, a, have_near, n, L)
+#define CALL(PP) run_l2p<PP>(c, pos, center, local, near, chunk_off, index, mlt_max, unsort, scatter, param, a, have_near, n, L, own0, own_n)
 	NBCO_DISPATCH_P(P, CALL)
 #undef CALL
 }

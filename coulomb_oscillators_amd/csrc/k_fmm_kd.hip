@@ -74,6 +74,25 @@ constexpr int kBlock = 256;
 __host__ __device__ inline int kd_beg(int l) { return (1 << l) - 1; }
 __host__ __device__ inline int kd_cnt(int l) { return 1 << l; }
 
+// kd-domain of a multi-GPU run: this GPU owns the subtree of node 2^d - 1 + g of the global
+// tree.  A node "touches" the domain when it lies in that subtree or on the path from its root to the
+// global root; d = 0 is the single-GPU case, where every node touches.
+struct Dom
+{
+	int d, g;
+};
+__host__ __device__ inline bool dom_touch(const Dom dm, int node)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+	const int l = 31 - __clz(node + 1);
+#else
+	int l = 0;
+	while ((2 << l) <= node + 1) ++l;
+#endif
+	const int pos = node - ((1 << l) - 1);
+	return l >= dm.d ? (pos >> (l - dm.d)) == dm.g : (dm.g >> (dm.d - l)) == pos;
+}
+
 __device__ inline float powi(float b, int e)
 {
 	float r = 1.f;
@@ -598,9 +617,10 @@ __device__ inline uint64_t block_exclusive_scan3(uint64_t v, uint64_t *sh_wave, 
 
 // classification of one node pair (fmm_cart3_kdtree.cuh:586-609 CPU order, :504-542 GPU order):
 // 0 nothing, 1 P2P, 2 M2L, 3 self pair -> 3 children, 4 split the second node, 5 split the first node
-__device__ inline int classify_pair(const TreeView &t, const AdmTab &tab, int2 np, float par, int m2l_first)
+__device__ inline int classify_pair(const TreeView &t, const AdmTab &tab, int2 np, float par, int m2l_first, const Dom dm)
 {
 	const int ntot = t.ntot;
+	if (dm.d > 0 && !dom_touch(dm, np.x) && !dom_touch(dm, np.y)) return 0;   // nothing below this pair reaches the domain
 	const bool leaf1 = 2 * np.x + 1 >= ntot, leaf2 = 2 * np.y + 1 >= ntot;
 	if (!m2l_first && leaf1 && leaf2) return (np.x != np.y) ? 1 : 0;
 	if (np.x == np.y) return leaf1 ? 0 : 3;
@@ -631,7 +651,7 @@ __device__ inline int pair_children(int kd, int2 np, int2 ch[3])
 __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab, const int2 *__restrict__ fin, int2 *__restrict__ fout,
                                                           int2 *__restrict__ p2p, int2 *__restrict__ m2l, int *__restrict__ counters, int it,
                                                           long long cap, float par, int m2l_first, unsigned *__restrict__ cnt_p2p,
-                                                          unsigned *__restrict__ cnt_m2l)
+                                                          unsigned *__restrict__ cnt_m2l, const Dom dm)
 {
 	__shared__ uint64_t sh_wave[4];
 	__shared__ int sh_base[3];
@@ -647,11 +667,11 @@ __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab
 		if (i < nin)
 		{
 			pr[0] = fin[i];
-			kd[0] = classify_pair(t, tab, pr[0], par, m2l_first);
+			kd[0] = classify_pair(t, tab, pr[0], par, m2l_first, dm);
 			nch = pair_children(kd[0], pr[0], pr + 1);
 #pragma unroll
 			for (int k = 1; k < 4; ++k)
-				if (k <= nch) kd[k] = classify_pair(t, tab, pr[k], par, m2l_first);
+				if (k <= nch) kd[k] = classify_pair(t, tab, pr[k], par, m2l_first, dm);
 		}
 		uint64_t cnt = 0;
 #pragma unroll
@@ -681,12 +701,22 @@ __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab
 			// the per-target entry counts of the directed lists are accumulated here, under the traversal's latency
 			if (q == 1)
 			{
-				if (okp) { p2p[bp] = np; atomicAdd(&cnt_p2p[np.x - lbeg], 1u); atomicAdd(&cnt_p2p[np.y - lbeg], 1u); }
+				if (okp)
+				{
+					p2p[bp] = np;
+					if (dm.d == 0 || dom_touch(dm, np.x)) atomicAdd(&cnt_p2p[np.x - lbeg], 1u);
+					if (dm.d == 0 || dom_touch(dm, np.y)) atomicAdd(&cnt_p2p[np.y - lbeg], 1u);
+				}
 				++bp;
 			}
 			else if (q == 2)
 			{
-				if (okm) { m2l[bm] = np; atomicAdd(&cnt_m2l[np.x], 1u); atomicAdd(&cnt_m2l[np.y], 1u); }
+				if (okm)
+				{
+					m2l[bm] = np;
+					if (dm.d == 0 || dom_touch(dm, np.x)) atomicAdd(&cnt_m2l[np.x], 1u);
+					if (dm.d == 0 || dom_touch(dm, np.y)) atomicAdd(&cnt_m2l[np.y], 1u);
+				}
 				++bm;
 			}
 			else if (q >= 3)
@@ -765,9 +795,9 @@ __global__ __launch_bounds__(kBlock) void add_one_kernel(unsigned *__restrict__ 
 	for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) v[i] += 1u;
 }
 
-__global__ __launch_bounds__(kBlock) void list_fill_kernel(const int2 *__restrict__ pairs, long long npairs, int sub, int nself, int shift,
-                                                           const int *__restrict__ start, unsigned *__restrict__ fill,
-                                                           uint64_t *__restrict__ keys)
+__global__ __launch_bounds__(kBlock) void list_fill_kernel(const int2 *__restrict__ pairs, long long npairs, int sub, int self0, int nself,
+                                                           int shift, const int *__restrict__ start, unsigned *__restrict__ fill,
+                                                           uint64_t *__restrict__ keys, const Dom dm)
 {
 	const long long total = npairs + nself;
 	for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock)
@@ -776,12 +806,12 @@ __global__ __launch_bounds__(kBlock) void list_fill_kernel(const int2 *__restric
 		{
 			const int2 p = pairs[i];
 			const uint64_t a = (uint64_t)(p.x - sub), b = (uint64_t)(p.y - sub);
-			keys[start[a] + atomicAdd(&fill[a], 1u)] = (a << shift) | b;
-			keys[start[b] + atomicAdd(&fill[b], 1u)] = (b << shift) | a;
+			if (dm.d == 0 || dom_touch(dm, p.x)) keys[start[a] + atomicAdd(&fill[a], 1u)] = (a << shift) | b;
+			if (dm.d == 0 || dom_touch(dm, p.y)) keys[start[b] + atomicAdd(&fill[b], 1u)] = (b << shift) | a;
 		}
 		else
 		{
-			const uint64_t t = (uint64_t)(i - npairs);
+			const uint64_t t = (uint64_t)(self0 + (i - npairs));   // self entries of the domain's own leaves
 			keys[start[t] + atomicAdd(&fill[t], 1u)] = (t << shift) | t;
 		}
 	}
@@ -831,9 +861,10 @@ __global__ __launch_bounds__(kBlock) void list_segsort_kernel(const int *__restr
 
 // directed pair interactions = sum over the directed P2P entries of mult[target] * mult[source]
 // (the self entries contribute mult^2), SURVEY 8(d)
-__global__ __launch_bounds__(kBlock) void pair_count_kernel(TreeView t, const uint64_t *__restrict__ keys, long long count, int shift,
-                                                            unsigned long long *__restrict__ out)
+__global__ __launch_bounds__(kBlock) void pair_count_kernel(TreeView t, const uint64_t *__restrict__ keys, const int *__restrict__ count_ptr,
+                                                            int shift, unsigned long long *__restrict__ out)
 {
+	const long long count = *count_ptr;
 	const uint64_t mask = (1ull << shift) - 1;
 	const int beg = kd_beg(t.L);
 	unsigned long long s = 0;
@@ -846,9 +877,10 @@ __global__ __launch_bounds__(kBlock) void pair_count_kernel(TreeView t, const ui
 // ---- P2P ---------------------------------------------------------------------------------------------
 // source descriptors of the sorted directed list: first particle and multiplicity of every source leaf,
 // so the pair kernel does no dependent index -> mult -> position loads
-__global__ __launch_bounds__(kBlock) void p2p_srcdesc_kernel(TreeView t, const uint64_t *__restrict__ keys, long long count, int shift,
-                                                             int2 *__restrict__ desc)
+__global__ __launch_bounds__(kBlock) void p2p_srcdesc_kernel(TreeView t, const uint64_t *__restrict__ keys, const int *__restrict__ count_ptr,
+                                                             int shift, int2 *__restrict__ desc)
 {
+	const long long count = *count_ptr;
 	const uint64_t mask = (1ull << shift) - 1;
 	const int beg = kd_beg(t.L);
 	for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < count; i += (long long)gridDim.x * kBlock)
@@ -868,7 +900,7 @@ constexpr int kP2PChunk = 16;
 __global__ __launch_bounds__(kBlock) void p2p_chunk_count_kernel(const int *__restrict__ start, int nleaf, int *__restrict__ cnt)
 {
 	for (int i = blockIdx.x * kBlock + threadIdx.x; i <= nleaf; i += gridDim.x * kBlock)
-		cnt[i] = i < nleaf ? max(1, (start[i + 1] - start[i] + kP2PChunk - 1) / kP2PChunk) : 0;
+		cnt[i] = i < nleaf ? (start[i + 1] - start[i] + kP2PChunk - 1) / kP2PChunk : 0;   // leaves of other domains have no entries
 }
 
 __global__ __launch_bounds__(kBlock) void p2p_chunk_fill_kernel(const int *__restrict__ start, const int *__restrict__ off, int nleaf,
@@ -1237,20 +1269,20 @@ static int sort_keys_u64(nbco_ctx *c, uint64_t *kin, uint64_t *kout, long long n
 	return NBCO_OK;
 }
 
-// directed, per-target sorted list of `pairs` (+ one self entry per target when nself > 0) into keys_out; start[0..T].
-// cnt[0..T) holds the per-target pair-entry counts accumulated by the traversal, fill[0..T) is zero.
-static int build_directed_list(nbco_ctx *c, const int2 *pairs, long long npairs, int sub, int nself, int ntargets, int shift, unsigned *cnt,
-                               unsigned *fill, int *start, uint64_t *keys_tmp, uint64_t *keys_out)
+// directed, per-target sorted list of `pairs` (+ one self entry for each of the targets [self0, self0 + nself)) into
+// keys_out; start[0..T].  cnt[0..T) holds the per-target pair-entry counts accumulated by the traversal, fill[0..T) is zero.
+static int build_directed_list(nbco_ctx *c, const int2 *pairs, long long npairs, int sub, int self0, int nself, int ntargets, int shift,
+                               unsigned *cnt, unsigned *fill, int *start, uint64_t *keys_tmp, uint64_t *keys_out, const Dom dm)
 {
 	hipStream_t st = c->stream;
-	if (nself > 0) hipLaunchKernelGGL(add_one_kernel, dim3(grid1d(nself)), dim3(kBlock), 0, st, cnt, nself);
+	if (nself > 0) hipLaunchKernelGGL(add_one_kernel, dim3(grid1d(nself)), dim3(kBlock), 0, st, cnt + self0, nself);
 	size_t bytes = 0;
 	NBCO_HIP(rocprim::exclusive_scan(nullptr, bytes, (int *)cnt, start, 0, (size_t)(ntargets + 1), rocprim::plus<int>(), st));
 	NBCO_TRY(c->reserve(c->sort_tmp, bytes));
 	bytes = c->sort_tmp.bytes;
 	NBCO_HIP(rocprim::exclusive_scan(c->sort_tmp.ptr, bytes, (int *)cnt, start, 0, (size_t)(ntargets + 1), rocprim::plus<int>(), st));
-	hipLaunchKernelGGL(list_fill_kernel, dim3(grid1d(npairs + nself)), dim3(kBlock), 0, st, pairs, npairs, sub, nself, shift, (const int *)start, fill,
-	                   keys_tmp);
+	hipLaunchKernelGGL(list_fill_kernel, dim3(grid1d(npairs + nself)), dim3(kBlock), 0, st, pairs, npairs, sub, self0, nself, shift, (const int *)start,
+	                   fill, keys_tmp, dm);
 	hipLaunchKernelGGL(list_segsort_kernel, dim3((ntargets + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, (const int *)start, ntargets,
 	                   (const uint64_t *)keys_tmp, keys_out);
 	NBCO_HIP(hipGetLastError());
@@ -1266,40 +1298,55 @@ static void launch_p2p(nbco_ctx *c, const TreeView &tv, const float4 *pos, const
 	                   partial);
 }
 
-} // namespace
-
-int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *param)
+// node arrays of a tree with ntot nodes carved out of `buf`
+static int kd_carve(nbco_ctx *c, DevBuf &buf, KdTreeDev &k, int ntot, int offM, int offL)
 {
-	if (n <= 0) return c->fail(NBCO_ERR_ARG, "nbco_fmm_kdtree: n must be positive");
-	if (n > 0x7fffffffLL / 4) return c->fail(NBCO_ERR_UNSUPPORTED, "nbco_fmm_kdtree: n too large for 32-bit tree indices");
-	const int P = c->o.fmm_order;
-	DevTables tb;
-	NBCO_TRY(ensure_tables(c, tb));
-	const int L = kd_levels(n, P, c->o.dens_inhom, c->o.tree_L);
-	const int ntot = (1 << (L + 1)) - 1, nleaf = 1 << L, beg = kd_beg(L);
-	const int offM = tb.offM, offL = tb.offL;
-	const int mlt_max = (int)((n - 1) / nleaf + 1);
-	hipStream_t st = c->stream;
+	size_t bytes = (size_t)ntot * (3 * 3 * sizeof(float) + sizeof(float4) + (size_t)(offM + offL) * sizeof(float) + 3 * sizeof(int)) + 256;
+	NBCO_TRY(c->reserve(buf, bytes));
+	char *q = (char *)buf.ptr;
+	k.csz = (float4 *)q; q += sizeof(float4) * (size_t)ntot;
+	k.center = (float *)q; q += 12 * (size_t)ntot;
+	k.lbound = (float *)q; q += 12 * (size_t)ntot;
+	k.rbound = (float *)q; q += 12 * (size_t)ntot;
+	k.mpole = (float *)q; q += 4 * (size_t)ntot * offM;
+	k.local = (float *)q; q += 4 * (size_t)ntot * offL;
+	k.mult = (int *)q; q += 4 * (size_t)ntot;
+	k.index = (int *)q; q += 4 * (size_t)ntot;
+	k.splitdim = (int *)q;
+	return NBCO_OK;
+}
 
-	// ---- storage ------------------------------------------------------------------------------------
+// Levels [0, l0) of a tree over pos[0..n): exact median selection + partition (k_kdselect.hip) or, after a tie
+// overflow, one global stable radix sort per level.  The root's box / split axis must be in place; on return
+// pos / unsort point at the buffers holding the result and the boxes of level l0 are written.
+static int kd_build_top(nbco_ctx *c, const TreeView &tv, float4 *&pos, float4 *&pos_alt, int *&unsort, int *&unsort_alt, long long n, int l0,
+                        bool use_select)
+{
+	hipStream_t st = c->stream;
+	if (use_select && l0 > 0) NBCO_TRY(kd_select_begin(c, l0));
+	for (int l = 0; l < l0; ++l)
 	{
-		size_t bytes = (size_t)ntot * (3 * 3 * sizeof(float) + sizeof(float4) + (size_t)(offM + offL) * sizeof(float) + 3 * sizeof(int)) + 256;
-		NBCO_TRY(c->reserve(c->treebuf, bytes));
-		char *q = (char *)c->treebuf.ptr;
-		KdTreeDev &k = c->kd;
-		k.csz = (float4 *)q; q += sizeof(float4) * (size_t)ntot;
-		k.center = (float *)q; q += 12 * (size_t)ntot;
-		k.lbound = (float *)q; q += 12 * (size_t)ntot;
-		k.rbound = (float *)q; q += 12 * (size_t)ntot;
-		k.mpole = (float *)q; q += 4 * (size_t)ntot * offM;
-		k.local = (float *)q; q += 4 * (size_t)ntot * offL;
-		k.mult = (int *)q; q += 4 * (size_t)ntot;
-		k.index = (int *)q; q += 4 * (size_t)ntot;
-		k.splitdim = (int *)q;
-		const bool topo_change = k.L != L || k.ntot != ntot || k.order != P || k.n != n;
-		if (topo_change) c->tree_valid = false;
-		k.L = L; k.ntot = ntot; k.order = P; k.mlt_max = mlt_max; k.n = n;
+		if (use_select)
+			NBCO_TRY(kd_select_level(c, l, n, pos, unsort, pos_alt, unsort_alt, tv.lbound, tv.rbound, tv.splitdim, tv.index,
+			                         c->counters.as<int>() + 110));
+		else
+		{
+			if (l > 0) hipLaunchKernelGGL(kd_box_kernel, dim3(grid1d(kd_cnt(l))), dim3(kBlock), 0, st, tv, pos, n, l);
+			hipLaunchKernelGGL(kd_keys_kernel, dim3(grid1d(n)), dim3(kBlock), 0, st, pos, tv.splitdim + kd_beg(l), n, l,
+			                   c->keys.as<uint64_t>(), c->idx.as<uint32_t>());
+			NBCO_TRY(sort_pairs_u64(c, c->keys.as<uint64_t>(), c->keys_alt.as<uint64_t>(), c->idx.as<uint32_t>(), c->idx_alt.as<uint32_t>(), n, 32 + l));
+			hipLaunchKernelGGL(kd_permute_kernel, dim3(grid1d(n)), dim3(kBlock), 0, st, pos, unsort, c->idx_alt.as<uint32_t>(), pos_alt, unsort_alt, n);
+		}
+		std::swap(pos, pos_alt);
+		std::swap(unsort, unsort_alt);
 	}
+	if (l0 > 0 && !use_select) hipLaunchKernelGGL(kd_box_kernel, dim3(grid1d(kd_cnt(l0))), dim3(kBlock), 0, st, tv, pos, n, l0);
+	NBCO_HIP(hipGetLastError());
+	return NBCO_OK;
+}
+
+static int kd_reserve_particles(nbco_ctx *c, long long n)
+{
 	NBCO_TRY(c->reserve(c->pos4, sizeof(float4) * (size_t)n));
 	NBCO_TRY(c->reserve(c->pos4_alt, sizeof(float4) * (size_t)n));
 	NBCO_TRY(c->reserve(c->unsort, sizeof(int) * (size_t)n));
@@ -1308,54 +1355,53 @@ int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 	NBCO_TRY(c->reserve(c->keys_alt, sizeof(uint64_t) * (size_t)n));
 	NBCO_TRY(c->reserve(c->idx, sizeof(uint32_t) * (size_t)n));
 	NBCO_TRY(c->reserve(c->idx_alt, sizeof(uint32_t) * (size_t)n));
-	const long long cap = (long long)c->o.list_factor * ntot + 4096;
-	NBCO_TRY(c->reserve(c->frontier_a, sizeof(int2) * (size_t)cap));
-	NBCO_TRY(c->reserve(c->frontier_b, sizeof(int2) * (size_t)cap));
-	NBCO_TRY(c->reserve(c->p2p_list, sizeof(int2) * (size_t)cap));
-	NBCO_TRY(c->reserve(c->m2l_list, sizeof(int2) * (size_t)cap));
 	NBCO_TRY(c->reserve(c->counters, sizeof(int) * 128));
-	c->list_cap = cap;
+	return NBCO_OK;
+}
 
+// ---- stage 1: tree over p[0..n) with L levels + upward pass ---------------------------------------------
+// root6 (device, {lbound, rbound}) overrides the root box: the box of a kd-domain is inherited from the
+// global tree's top splits.  On return c->pos4 / c->unsort hold the tree-ordered positions and the map
+// back to the caller's order.
+static int kd_build_upward(nbco_ctx *c, const float *p, long long n, int L, const float *root6, bool &rebuild)
+{
+	const int P = c->o.fmm_order;
+	DevTables tb;
+	NBCO_TRY(ensure_tables(c, tb));
+	const int ntot = (1 << (L + 1)) - 1, nleaf = 1 << L;
+	const int mlt_max = (int)((n - 1) / nleaf + 1);
+	hipStream_t st = c->stream;
+	{
+		KdTreeDev &k = c->kd;
+		NBCO_TRY(kd_carve(c, c->treebuf, k, ntot, tb.offM, tb.offL));
+		const bool topo_change = k.L != L || k.ntot != ntot || k.order != P || k.n != n;
+		if (topo_change) c->tree_valid = false;
+		k.L = L; k.ntot = ntot; k.order = P; k.mlt_max = mlt_max; k.n = n;
+	}
+	NBCO_TRY(kd_reserve_particles(c, n));
 	TreeView tv = view_of(c->kd);
 	float4 *pos = c->pos4.as<float4>(), *pos_alt = c->pos4_alt.as<float4>();
 	int *unsort = c->unsort.as<int>(), *unsort_alt = c->unsort_alt.as<int>();
-
-	const bool rebuild = c->o.unsort || !c->tree_valid || (c->eval_counter % c->o.tree_steps) == 0;
-
-	// ---- build ----------------------------------------------------------------------------------------
+	rebuild = c->o.unsort || !c->tree_valid || (c->eval_counter % c->o.tree_steps) == 0;
 	{
 		PhaseScope ph(c, NBCO_PH_BUILD);
 		NBCO_TRY(launch_pack4(c, pos, p, n));
 		NBCO_HIP(hipMemsetAsync(c->counters.as<int>() + 110, 0, sizeof(int), st));
 		if (rebuild)
 		{
-			float *mm = c->small.as<float>() + 64;
-			NBCO_TRY(launch_minmax4(c, pos, n, mm));
-			hipLaunchKernelGGL(kd_root_kernel, dim3(1), dim3(64), 0, st, tv, mm);
+			if (!root6)
+			{
+				float *mm = c->small.as<float>() + 64;
+				NBCO_TRY(launch_minmax4(c, pos, n, mm));
+				root6 = mm;
+			}
+			hipLaunchKernelGGL(kd_root_kernel, dim3(1), dim3(64), 0, st, tv, root6);
 			hipLaunchKernelGGL(iota_kernel, dim3(grid1d(n)), dim3(kBlock), 0, st, unsort, n);
-			// levels whose nodes exceed the LDS slice: exact median selection + partition (k_kdselect.hip), or,
-			// after a tie overflow, the global stable radix sort per level
+			// levels whose nodes exceed the LDS slice
 			int l0 = 0;
 			while (l0 < L && (n + (1LL << l0) - 1) / (1LL << l0) > kSubS) ++l0;
 			const bool use_select = !c->force_sort_build;
-			if (use_select && l0 > 0) NBCO_TRY(kd_select_begin(c, l0));
-			for (int l = 0; l < l0; ++l)
-			{
-				if (use_select)
-					NBCO_TRY(kd_select_level(c, l, n, pos, unsort, pos_alt, unsort_alt, tv.lbound, tv.rbound, tv.splitdim, tv.index,
-					                         c->counters.as<int>() + 110));
-				else
-				{
-					if (l > 0) hipLaunchKernelGGL(kd_box_kernel, dim3(grid1d(kd_cnt(l))), dim3(kBlock), 0, st, tv, pos, n, l);
-					hipLaunchKernelGGL(kd_keys_kernel, dim3(grid1d(n)), dim3(kBlock), 0, st, pos, tv.splitdim + kd_beg(l), n, l,
-					                   c->keys.as<uint64_t>(), c->idx.as<uint32_t>());
-					NBCO_TRY(sort_pairs_u64(c, c->keys.as<uint64_t>(), c->keys_alt.as<uint64_t>(), c->idx.as<uint32_t>(), c->idx_alt.as<uint32_t>(), n, 32 + l));
-					hipLaunchKernelGGL(kd_permute_kernel, dim3(grid1d(n)), dim3(kBlock), 0, st, pos, unsort, c->idx_alt.as<uint32_t>(), pos_alt, unsort_alt, n);
-				}
-				std::swap(pos, pos_alt);
-				std::swap(unsort, unsort_alt);
-			}
-			if (l0 > 0 && !use_select) hipLaunchKernelGGL(kd_box_kernel, dim3(grid1d(kd_cnt(l0))), dim3(kBlock), 0, st, tv, pos, n, l0);
+			NBCO_TRY(kd_build_top(c, tv, pos, pos_alt, unsort, unsort_alt, n, l0, use_select));
 			// the rest of every level-l0 subtree inside one workgroup's LDS
 			hipLaunchKernelGGL(kd_subtree_kernel, dim3(kd_cnt(l0)), dim3(kSubT), 0, st, tv, (const float4 *)pos, (const int *)unsort, pos_alt, unsort_alt, n, l0,
 			                   use_select ? 1 : 0);
@@ -1364,13 +1410,11 @@ int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 			NBCO_HIP(hipGetLastError());
 			// keep the "current" buffers in the primary slots
 			if (pos != c->pos4.as<float4>()) { std::swap(c->pos4, c->pos4_alt); std::swap(c->unsort, c->unsort_alt); }
-			pos = c->pos4.as<float4>(); pos_alt = c->pos4_alt.as<float4>();
-			unsort = c->unsort.as<int>(); unsort_alt = c->unsort_alt.as<int>();
+			pos = c->pos4.as<float4>();
 		}
 		hipLaunchKernelGGL(kd_leaf_kernel, dim3(grid1d(nleaf)), dim3(kBlock), 0, st, tv, pos, n);
 		NBCO_HIP(hipGetLastError());
 	}
-	// ---- P2M, M2M ---------------------------------------------------------------------------------------
 	{
 		PhaseScope ph(c, NBCO_PH_P2M_M2M);
 		if (P <= 8)
@@ -1383,6 +1427,38 @@ int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 		hipLaunchKernelGGL(kd_csz_kernel, dim3(grid1d(ntot)), dim3(kBlock), 0, st, tv);
 		NBCO_HIP(hipGetLastError());
 	}
+	return NBCO_OK;
+}
+
+// ---- stage 2: traversal, lists, P2P, M2L, L2L, L2P on the tree `tv` over pos[0..n) --------------------------
+// Only targets touching the domain `dm` are served; accelerations come out for the particles
+// [own0, own0 + own_n) (tree order, or scattered through `unsort` when opts.unsort is set).
+struct KdCounts
+{
+	long long np2p = 0, nm2l = 0;
+	int sel_overflow = 0;
+};
+
+static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long long n, int mlt_max, const Dom dm, long long own0, long long own_n,
+                       const int *unsort, float *a, const float *param, KdCounts &out)
+{
+	const int P = c->o.fmm_order;
+	DevTables tb;
+	NBCO_TRY(ensure_tables(c, tb));
+	const int L = tv.L, ntot = tv.ntot, nleaf = 1 << L, beg = kd_beg(L);
+	const int offL = tb.offL, offM = tb.offM;
+	const int self0 = dm.g << (L - dm.d), nself = 1 << (L - dm.d);   // the domain's own leaves
+	hipStream_t st = c->stream;
+	if (dm.d > 0 && P > 8) return c->fail(NBCO_ERR_UNSUPPORTED, "kd-domain sharding needs the generated operators (fmm_order <= 8)");
+
+	const long long cap = (long long)c->o.list_factor * ntot + 4096;
+	NBCO_TRY(c->reserve(c->frontier_a, sizeof(int2) * (size_t)cap));
+	NBCO_TRY(c->reserve(c->frontier_b, sizeof(int2) * (size_t)cap));
+	NBCO_TRY(c->reserve(c->p2p_list, sizeof(int2) * (size_t)cap));
+	NBCO_TRY(c->reserve(c->m2l_list, sizeof(int2) * (size_t)cap));
+	NBCO_TRY(c->reserve(c->counters, sizeof(int) * 128));
+	c->list_cap = cap;
+
 	// ---- dual tree traversal ----------------------------------------------------------------------------
 	int h_cnt[4] = {0, 0, 0, 0};
 	{
@@ -1409,27 +1485,28 @@ int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 		for (int it = 0; it < iters; ++it)
 		{
 			hipLaunchKernelGGL(traverse_kernel, dim3(1024), dim3(kBlock), 0, st, tv, tab, (const int2 *)fa, fb, c->p2p_list.as<int2>(),
-			                   c->m2l_list.as<int2>(), ctr, it, cap, c->o.tree_radius, c->o.m2l_first, cnt_p2p, cnt_m2l);
+			                   c->m2l_list.as<int2>(), ctr, it, cap, c->o.tree_radius, c->o.m2l_first, cnt_p2p, cnt_m2l, dm);
 			std::swap(fa, fb);
 		}
 		NBCO_HIP(hipGetLastError());
 		NBCO_HIP(hipMemcpyAsync(h_cnt, ctr, sizeof(int) * 3, hipMemcpyDeviceToHost, st));
 		NBCO_HIP(hipMemcpyAsync(&h_cnt[3], ctr + 110, sizeof(int), hipMemcpyDeviceToHost, st));
 		NBCO_HIP(hipStreamSynchronize(st));
-		if (h_cnt[3] != 0 && !c->force_sort_build)
+		if (h_cnt[3] != 0)
 		{
 			// a node had more pivot ties than the selection build resolves (degenerate coordinates): nothing has
-			// been written to p or a yet, so redo the evaluation with the sorting build
-			c->force_sort_build = true;
-			c->tree_valid = false;
-			return fmm_kdtree_eval(c, p, a, n, param);
+			// been written to the caller's arrays yet, the caller redoes the evaluation with the sorting build
+			out.sel_overflow = 1;
+			return NBCO_OK;
 		}
 		if (h_cnt[2] != 0)
 			return c->fail(NBCO_ERR_CAPACITY, "dual tree traversal exceeded the list capacity (raise opts.list_factor)");
 	}
 	const long long np2p = h_cnt[0], nm2l = h_cnt[1];
+	out.np2p = np2p; out.nm2l = nm2l;
 	const int shift = L + 1;
-	const long long dp2p = c->o.coll ? 2 * np2p + nleaf : 0, dm2l = 2 * nm2l;
+	// upper bounds of the directed entry counts (exact for a single domain); the exact totals stay on the device
+	const long long dp2p = c->o.coll ? 2 * np2p + nself : 0, dm2l = 2 * nm2l;
 	long long max_chunks = 0;
 	// ---- directed sorted lists --------------------------------------------------------------------------
 	{
@@ -1443,14 +1520,15 @@ int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 		if (dp2p > 0)
 		{
 			unsigned *cp = c->list_cnt.as<unsigned>();
-			NBCO_TRY(build_directed_list(c, c->p2p_list.as<int2>(), np2p, beg, nleaf, nleaf, shift, cp, cp + ((size_t)nleaf + 2), c->p2p_start.as<int>(),
-			                             c->p2p_keys.as<uint64_t>(), c->p2p_keys_alt.as<uint64_t>()));
+			NBCO_TRY(build_directed_list(c, c->p2p_list.as<int2>(), np2p, beg, self0, nself, nleaf, shift, cp, cp + ((size_t)nleaf + 2),
+			                             c->p2p_start.as<int>(), c->p2p_keys.as<uint64_t>(), c->p2p_keys_alt.as<uint64_t>(), dm));
+			const int *total = c->p2p_start.as<int>() + nleaf;
 			hipLaunchKernelGGL(pair_count_kernel, dim3(grid1d(dp2p, 256)), dim3(kBlock), 0, st, tv, (const uint64_t *)c->p2p_keys_alt.as<uint64_t>(),
-			                   dp2p, shift, (unsigned long long *)(c->counters.as<int>() + 100));
-			hipLaunchKernelGGL(p2p_srcdesc_kernel, dim3(grid1d(dp2p)), dim3(kBlock), 0, st, tv, (const uint64_t *)c->p2p_keys_alt.as<uint64_t>(), dp2p,
+			                   total, shift, (unsigned long long *)(c->counters.as<int>() + 100));
+			hipLaunchKernelGGL(p2p_srcdesc_kernel, dim3(grid1d(dp2p)), dim3(kBlock), 0, st, tv, (const uint64_t *)c->p2p_keys_alt.as<uint64_t>(), total,
 			                   shift, c->p2p_keys.as<int2>());
 			// chunked work units: counts -> exclusive scan -> descriptors
-			max_chunks = dp2p / kP2PChunk + nleaf;
+			max_chunks = dp2p / kP2PChunk + nself;
 			NBCO_TRY(c->reserve(c->p2p_chunk_cnt, sizeof(int) * (size_t)(nleaf + 2)));
 			NBCO_TRY(c->reserve(c->p2p_chunk_off, sizeof(int) * (size_t)(nleaf + 2)));
 			NBCO_TRY(c->reserve(c->p2p_chunks, sizeof(int4) * (size_t)max_chunks));
@@ -1471,8 +1549,8 @@ int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 		if (dm2l > 0)
 		{
 			unsigned *cm = c->list_cnt.as<unsigned>() + 2 * ((size_t)nleaf + 2);
-			NBCO_TRY(build_directed_list(c, c->m2l_list.as<int2>(), nm2l, 0, 0, ntot, shift, cm, cm + ((size_t)ntot + 2), c->m2l_start.as<int>(),
-			                             c->m2l_keys.as<uint64_t>(), c->m2l_keys_alt.as<uint64_t>()));
+			NBCO_TRY(build_directed_list(c, c->m2l_list.as<int2>(), nm2l, 0, 0, 0, ntot, shift, cm, cm + ((size_t)ntot + 2), c->m2l_start.as<int>(),
+			                             c->m2l_keys.as<uint64_t>(), c->m2l_keys_alt.as<uint64_t>(), dm));
 		}
 		else
 			NBCO_HIP(hipMemsetAsync(c->m2l_start.ptr, 0, sizeof(int) * (size_t)(ntot + 2), st));
@@ -1510,7 +1588,7 @@ int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 	}
 	{
 		PhaseScope ph(c, NBCO_PH_L2L);
-		if (P <= 8) NBCO_TRY(launch_downward_gen(c, P, tv.center, tv.local, L));
+		if (P <= 8) NBCO_TRY(launch_downward_gen(c, P, tv.center, tv.local, L, dm.d, dm.g));
 		else
 			for (int lc = 2; lc <= L; ++lc) hipLaunchKernelGGL(l2l_kernel, dim3(kd_cnt(lc)), dim3(64), 0, st, tv, tb, lc);
 		NBCO_HIP(hipGetLastError());
@@ -1521,33 +1599,315 @@ int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 		size_t lds = (288 + (size_t)std::max(offM, 1) * 64) * sizeof(float);
 		if (P <= 8)
 			NBCO_TRY(launch_l2p_gen(c, P, pos, tv.center, tv.local, near, c->p2p_chunk_off.as<int>(), tv.index, mlt_max, unsort, c->o.unsort ? 1 : 0,
-			                        param, a, dp2p > 0 ? 1 : 0, n, L));
+			                        param, a, dp2p > 0 ? 1 : 0, n, L, own0, own_n));
 		else
-		hipLaunchKernelGGL(l2p_kernel, dim3(nleaf), dim3(64), lds, st, tv, tb, (const float4 *)pos, (const float4 *)near,
-		                   (const int *)c->p2p_chunk_off.as<int>(), mlt_max, (const int *)unsort, c->o.unsort ? 1 : 0, param, a, dp2p > 0 ? 1 : 0);
+			hipLaunchKernelGGL(l2p_kernel, dim3(nleaf), dim3(64), lds, st, tv, tb, (const float4 *)pos, (const float4 *)near,
+			                   (const int *)c->p2p_chunk_off.as<int>(), mlt_max, (const int *)unsort, c->o.unsort ? 1 : 0, param, a, dp2p > 0 ? 1 : 0);
 		NBCO_HIP(hipGetLastError());
 	}
+	return NBCO_OK;
+}
+
+// positions in tree order; velocities follow (fmm_cart3_kdtree.cuh:1755-1760)
+static int kd_finish_order(nbco_ctx *c, float *p, long long n)
+{
+	PhaseScope ph(c, NBCO_PH_FINISH);
+	hipStream_t st = c->stream;
+	hipLaunchKernelGGL(unpack4_kernel, dim3(grid1d(n)), dim3(kBlock), 0, st, (const float4 *)c->pos4.as<float4>(), p, n);
+	NBCO_TRY(c->reserve(c->tmp3, sizeof(float) * 3 * (size_t)n));
+	NBCO_TRY(launch_gather3(c, c->tmp3.as<float>(), p + 3 * n, c->unsort.as<int>(), n, false));
+	NBCO_HIP(hipMemcpyAsync(p + 3 * n, c->tmp3.ptr, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToDevice, st));
+	NBCO_HIP(hipGetLastError());
+	return NBCO_OK;
+}
+
+} // namespace
+
+int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *param)
+{
+	if (n <= 0) return c->fail(NBCO_ERR_ARG, "nbco_fmm_kdtree: n must be positive");
+	if (n > 0x7fffffffLL / 4) return c->fail(NBCO_ERR_UNSUPPORTED, "nbco_fmm_kdtree: n too large for 32-bit tree indices");
+	const int P = c->o.fmm_order;
+	const int L = kd_levels(n, P, c->o.dens_inhom, c->o.tree_L);
+	bool rebuild = false;
+	NBCO_TRY(kd_build_upward(c, p, n, L, nullptr, rebuild));
+	KdCounts cnt;
+	const Dom whole{0, 0};
+	NBCO_TRY(kd_interact(c, view_of(c->kd), c->pos4.as<float4>(), n, c->kd.mlt_max, whole, 0, n, c->unsort.as<int>(), a, param, cnt));
+	if (cnt.sel_overflow)
 	{
-		PhaseScope ph(c, NBCO_PH_FINISH);
-		if (!c->o.unsort && rebuild)
-		{
-			// positions in tree order; velocities follow (fmm_cart3_kdtree.cuh:1755-1760)
-			hipLaunchKernelGGL(unpack4_kernel, dim3(grid1d(n)), dim3(kBlock), 0, st, (const float4 *)pos, p, n);
-			NBCO_TRY(c->reserve(c->tmp3, sizeof(float) * 3 * (size_t)n));
-			NBCO_TRY(launch_gather3(c, c->tmp3.as<float>(), p + 3 * n, unsort, n, false));
-			NBCO_HIP(hipMemcpyAsync(p + 3 * n, c->tmp3.ptr, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToDevice, st));
-		}
-		NBCO_HIP(hipGetLastError());
+		if (c->force_sort_build) return c->fail(NBCO_ERR_UNSUPPORTED, "kd-tree build: tie flag raised by the sorting build");
+		c->force_sort_build = true;
+		c->tree_valid = false;
+		return fmm_kdtree_eval(c, p, a, n, param);
 	}
+	if (!c->o.unsort && rebuild) NBCO_TRY(kd_finish_order(c, p, n));
 
 	c->tree_valid = true;
 	c->tree_n = n;
 	c->tree_order = P;
 	c->eval_counter += 1;
 	nbco_kd_info &info = c->info;
-	info.L = L; info.ntot = ntot; info.order = P; info.mlt_max = mlt_max; info.n = n;
-	info.p2p_pairs = np2p; info.m2l_pairs = nm2l; info.rebuilt = rebuild ? 1 : 0;
+	info.L = L; info.ntot = c->kd.ntot; info.order = P; info.mlt_max = c->kd.mlt_max; info.n = n;
+	info.p2p_pairs = cnt.np2p; info.m2l_pairs = cnt.nm2l; info.rebuilt = rebuild ? 1 : 0;
 	info.directed_p2p = -1;   // read back from the device counter on demand (nbco_kd_get_info)
+	return NBCO_OK;
+}
+
+// =====================================================================================================
+// Multi-GPU: kd-domain sharding.  GPU g of G = 2^d owns the subtree of node 2^d - 1 + g of
+// the GLOBAL balanced kd-tree: N / G particles, the global levels d .. L.  One force evaluation is
+//   local    build levels d .. L of the own subtree + P2M/M2M up to its root          (kd_dist_local)
+//   exchange all-gather of {centre+size, multipoles} of every domain's nodes and of the
+//            tree-ordered positions -- done by the caller (RCCL), this library never communicates
+//   finish   assemble the global node arrays, M2M for levels d-1 .. 0, dual traversal pruned to pairs
+//            that touch the own domain, P2P / M2L / L2L / L2P for the own targets only    (kd_dist_finish)
+// Cross-domain pairs are evaluated one-directionally on the owner of the target, so no force reduction
+// is needed and every target's sums run in the single-GPU order: the result equals the 1-GPU result bit
+// for bit (particles with exactly tied coordinates excepted: their order inside a leaf may differ).
+// The top d median splits (kd_dist_partition) run redundantly on every GPU over the gathered state.
+namespace {
+
+int log2_exact(int v)
+{
+	int d = 0;
+	while ((1 << d) < v) ++d;
+	return (1 << d) == v ? d : -1;
+}
+
+// global node id of local node k of domain r
+__host__ __device__ inline int dist_global_id(int k, int r, int d)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+	const int l = 31 - __clz(k + 1);
+#else
+	int l = 0;
+	while ((2 << l) <= k + 1) ++l;
+#endif
+	return (1 << (l + d)) - 1 + (r << l) + (k - ((1 << l) - 1));
+}
+
+// gathered blocks [csz ntot_loc float4 | mpole ntot_loc * offM float] x G  ->  global node arrays (levels >= d)
+__global__ __launch_bounds__(kBlock) void dist_unpack_nodes_kernel(TreeView t, const char *__restrict__ blocks, size_t block_bytes, int ntot_loc, int G,
+                                                                   int d, int offM)
+{
+	const long long total = (long long)G * ntot_loc;
+	for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock)
+	{
+		const int r = (int)(i / ntot_loc), k = (int)(i % ntot_loc);
+		const float4 cs = reinterpret_cast<const float4 *>(blocks + (size_t)r * block_bytes)[k];
+		const int gid = dist_global_id(k, r, d);
+		t.csz[gid] = cs;
+		t.center[3 * gid] = cs.x; t.center[3 * gid + 1] = cs.y; t.center[3 * gid + 2] = cs.z;
+	}
+}
+__global__ __launch_bounds__(kBlock) void dist_unpack_mpole_kernel(TreeView t, const char *__restrict__ blocks, size_t block_bytes, int ntot_loc, int G,
+                                                                   int d, int offM)
+{
+	const long long per = (long long)ntot_loc * offM, total = (long long)G * per;
+	for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock)
+	{
+		const int r = (int)(i / per);
+		const long long e = i % per;
+		const int k = (int)(e / offM), comp = (int)(e % offM);
+		const float *src = reinterpret_cast<const float *>(blocks + (size_t)r * block_bytes + sizeof(float4) * (size_t)ntot_loc);
+		t.mpole[(size_t)dist_global_id(k, r, d) * offM + comp] = src[e];
+	}
+}
+// ranges of evalBox's rule for every node of the global tree (fmm_cart3_kdtree.cuh:109-137)
+__global__ __launch_bounds__(kBlock) void dist_ranges_kernel(TreeView t, long long n)
+{
+	for (int j = blockIdx.x * kBlock + threadIdx.x; j < t.ntot; j += gridDim.x * kBlock)
+	{
+		const int l = 31 - __clz(j + 1);
+		const long long m = 1LL << l, i = j - (m - 1);
+		const long long start = (i == 0) ? 0 : (n * i - 1) / m + 1, end = (n * (i + 1) - 1) / m + 1;
+		t.index[j] = (int)start;
+		t.mult[j] = (int)(end - start);
+	}
+}
+#pragma clang fp contract(off)
+// centre + squared box diagonal of the levels above the domains (boxes from the partition step)
+__global__ void dist_top_csz_kernel(TreeView t, const float *__restrict__ lb, const float *__restrict__ rb, int ntop)
+{
+	for (int i = threadIdx.x; i < ntop; i += blockDim.x)
+	{
+		float dx = rb[3 * i] - lb[3 * i], dy = rb[3 * i + 1] - lb[3 * i + 1], dz = rb[3 * i + 2] - lb[3 * i + 2];
+		float sz = dx * dx + dy * dy + dz * dz;
+		t.csz[i] = make_float4(t.center[3 * i], t.center[3 * i + 1], t.center[3 * i + 2], sz);
+	}
+}
+#pragma clang fp contract(on)
+__global__ void dist_root6_kernel(const float *__restrict__ lb, const float *__restrict__ rb, int node, float *__restrict__ out6)
+{
+	if (threadIdx.x < 3) { out6[threadIdx.x] = lb[3 * node + threadIdx.x]; out6[3 + threadIdx.x] = rb[3 * node + threadIdx.x]; }
+}
+
+// top-tree arrays (levels 0 .. d) inside c->dist_top
+struct TopView
+{
+	float *lbound, *rbound;
+	int *splitdim, *index;
+};
+TopView top_view(nbco_ctx *c, int ntop)
+{
+	TopView v;
+	char *q = (char *)c->dist_top.ptr;
+	v.lbound = (float *)q; q += 12 * (size_t)ntop;
+	v.rbound = (float *)q; q += 12 * (size_t)ntop;
+	v.splitdim = (int *)q; q += 4 * (size_t)ntop;
+	v.index = (int *)q;
+	return v;
+}
+
+} // namespace
+
+int kd_dist_layout(nbco_ctx *c, long long n_global, int world, int rank, nbco_dist_layout *out)
+{
+	const int d = log2_exact(world);
+	if (d < 0 || world > 64) return c->fail(NBCO_ERR_ARG, "nbco_dist: the number of domains must be a power of two <= 64");
+	if (rank < 0 || rank >= world) return c->fail(NBCO_ERR_ARG, "nbco_dist: rank out of range");
+	if (n_global <= 0 || n_global % world != 0) return c->fail(NBCO_ERR_ARG, "nbco_dist: n must be a positive multiple of the number of domains");
+	if (n_global > 0x7fffffffLL / 4) return c->fail(NBCO_ERR_UNSUPPORTED, "nbco_dist: n too large for 32-bit tree indices");
+	const int P = c->o.fmm_order;
+	if (P > 8) return c->fail(NBCO_ERR_UNSUPPORTED, "kd-domain sharding needs the generated operators (fmm_order <= 8)");
+	const int L = kd_levels(n_global, P, c->o.dens_inhom, c->o.tree_L);
+	if (L - d < 2) return c->fail(NBCO_ERR_ARG, "nbco_dist: too few particles per domain (the local tree needs >= 2 levels)");
+	if (d > 0 && n_global / world < 4096) return c->fail(NBCO_ERR_ARG, "nbco_dist: at least 4096 particles per domain are required");
+	out->world = world; out->rank = rank; out->d = d; out->L = L; out->L_local = L - d; out->order = P;
+	out->ntot_local = (1 << (L - d + 1)) - 1;
+	out->n_global = n_global; out->n_local = n_global / world;
+	out->nodes_bytes = (long long)out->ntot_local * (long long)(sizeof(float4) + sizeof(float) * sym_off(P));
+	out->pos_bytes = (long long)out->n_local * (long long)sizeof(float4);
+	return NBCO_OK;
+}
+
+// state_all = [pos N x 3 | vel N x 3] (every rank passes the same gathered state), state_local = [pos | vel] of
+// the rank's domain in partition order.
+int kd_dist_partition(nbco_ctx *c, const float *state_all, long long n_global, int world, int rank, float *state_local)
+{
+	nbco_dist_layout lay;
+	NBCO_TRY(kd_dist_layout(c, n_global, world, rank, &lay));
+	const int d = lay.d, ntop = (1 << (d + 1)) - 1;
+	const long long n = n_global, nl = lay.n_local;
+	hipStream_t st = c->stream;
+	NBCO_TRY(c->reserve(c->dist_top, (size_t)ntop * 32 + 64));
+	NBCO_TRY(kd_reserve_particles(c, n));
+	TopView top = top_view(c, ntop);
+	TreeView tv{};
+	tv.lbound = top.lbound; tv.rbound = top.rbound; tv.splitdim = top.splitdim; tv.index = top.index; tv.L = d; tv.ntot = ntop;
+	for (int attempt = 0; attempt < 2; ++attempt)
+	{
+		float4 *pos = c->pos4.as<float4>(), *pos_alt = c->pos4_alt.as<float4>();
+		int *unsort = c->unsort.as<int>(), *unsort_alt = c->unsort_alt.as<int>();
+		PhaseScope ph(c, NBCO_PH_BUILD);
+		NBCO_TRY(launch_pack4(c, pos, state_all, n));
+		NBCO_HIP(hipMemsetAsync(c->counters.as<int>() + 110, 0, sizeof(int), st));
+		float *mm = c->small.as<float>() + 64;
+		NBCO_TRY(launch_minmax4(c, pos, n, mm));
+		hipLaunchKernelGGL(kd_root_kernel, dim3(1), dim3(64), 0, st, tv, (const float *)mm);
+		hipLaunchKernelGGL(iota_kernel, dim3(grid1d(n)), dim3(kBlock), 0, st, unsort, n);
+		const bool use_select = !c->force_sort_build;
+		NBCO_TRY(kd_build_top(c, tv, pos, pos_alt, unsort, unsort_alt, n, d, use_select));
+		int flag = 0;
+		NBCO_HIP(hipMemcpyAsync(&flag, c->counters.as<int>() + 110, sizeof(int), hipMemcpyDeviceToHost, st));
+		NBCO_HIP(hipStreamSynchronize(st));
+		if (flag && use_select) { c->force_sort_build = true; continue; }
+		// the domain's slice of the partitioned state
+		hipLaunchKernelGGL(unpack4_kernel, dim3(grid1d(nl)), dim3(kBlock), 0, st, (const float4 *)(pos + (size_t)rank * nl), state_local, nl);
+		NBCO_TRY(launch_gather3(c, state_local + 3 * nl, state_all + 3 * n, unsort + (size_t)rank * nl, nl, false));
+		NBCO_HIP(hipGetLastError());
+		break;
+	}
+	c->dist.world = world; c->dist.rank = rank; c->dist.d = d; c->dist.n_global = n_global; c->dist.n_local = nl; c->dist.L = lay.L;
+	c->dist.partitioned = true;
+	c->tree_valid = false;
+	return NBCO_OK;
+}
+
+int kd_dist_local(nbco_ctx *c, float *buf_local, long long n_local, void *nodes_send, void *pos_send)
+{
+	if (!c->dist.partitioned || n_local != c->dist.n_local)
+		return c->fail(NBCO_ERR_ARG, "nbco_dist_local: call nbco_dist_partition first (and pass its local particle count)");
+	if (c->o.unsort) return c->fail(NBCO_ERR_UNSUPPORTED, "nbco_dist: opts.unsort is not available with kd-domain sharding");
+	nbco_dist_layout lay;
+	NBCO_TRY(kd_dist_layout(c, c->dist.n_global, c->dist.world, c->dist.rank, &lay));
+	if (lay.L != c->dist.L) return c->fail(NBCO_ERR_ARG, "nbco_dist_local: options changed since nbco_dist_partition");
+	const int d = lay.d, ntop = (1 << (d + 1)) - 1;
+	hipStream_t st = c->stream;
+	TopView top = top_view(c, ntop);
+	float *root6 = c->small.as<float>() + 80;
+	hipLaunchKernelGGL(dist_root6_kernel, dim3(1), dim3(64), 0, st, (const float *)top.lbound, (const float *)top.rbound, (1 << d) - 1 + lay.rank, root6);
+	bool rebuild = false;
+	NBCO_TRY(kd_build_upward(c, buf_local, n_local, lay.L_local, root6, rebuild));
+	if (rebuild && !c->force_sort_build && n_local > kSubS)
+	{
+		// A tie overflow of the selection build has to be caught BEFORE the exchange (the other domains are
+		// about to consume these nodes); the retry with the sorting build is purely local.
+		int flag = 0;
+		NBCO_HIP(hipMemcpyAsync(&flag, c->counters.as<int>() + 110, sizeof(int), hipMemcpyDeviceToHost, st));
+		NBCO_HIP(hipStreamSynchronize(st));
+		if (flag)
+		{
+			c->force_sort_build = true;
+			c->tree_valid = false;
+			NBCO_TRY(kd_build_upward(c, buf_local, n_local, lay.L_local, root6, rebuild));
+		}
+	}
+	c->dist.rebuilt = rebuild;
+	const int offM = sym_off(lay.order);
+	NBCO_HIP(hipMemcpyAsync(nodes_send, c->kd.csz, sizeof(float4) * (size_t)lay.ntot_local, hipMemcpyDeviceToDevice, st));
+	NBCO_HIP(hipMemcpyAsync((char *)nodes_send + sizeof(float4) * (size_t)lay.ntot_local, c->kd.mpole, sizeof(float) * (size_t)lay.ntot_local * offM,
+	                        hipMemcpyDeviceToDevice, st));
+	NBCO_HIP(hipMemcpyAsync(pos_send, c->pos4.ptr, sizeof(float4) * (size_t)n_local, hipMemcpyDeviceToDevice, st));
+	c->dist.local_done = true;
+	return NBCO_OK;
+}
+
+int kd_dist_finish(nbco_ctx *c, const void *nodes_all, const void *pos_all, float *buf_local, float *a_local, const float *param)
+{
+	if (!c->dist.local_done) return c->fail(NBCO_ERR_ARG, "nbco_dist_finish: call nbco_dist_local first");
+	c->dist.local_done = false;
+	nbco_dist_layout lay;
+	NBCO_TRY(kd_dist_layout(c, c->dist.n_global, c->dist.world, c->dist.rank, &lay));
+	const int d = lay.d, G = lay.world, L = lay.L, P = lay.order;
+	const int ntot = (1 << (L + 1)) - 1, ntop = (1 << (d + 1)) - 1;
+	const int offM = sym_off(P), offL = tl_off(P + 1);
+	const long long N = lay.n_global, nl = lay.n_local;
+	hipStream_t st = c->stream;
+	KdTreeDev g;
+	NBCO_TRY(kd_carve(c, c->dist_tree, g, ntot, offM, offL));
+	g.L = L; g.ntot = ntot; g.order = P; g.n = N; g.mlt_max = (int)((N - 1) / (1LL << L) + 1);
+	TreeView tv = view_of(g);
+	{
+		PhaseScope ph(c, NBCO_PH_P2M_M2M);
+		hipLaunchKernelGGL(dist_ranges_kernel, dim3(grid1d(ntot)), dim3(kBlock), 0, st, tv, N);
+		hipLaunchKernelGGL(dist_unpack_nodes_kernel, dim3(grid1d((long long)G * lay.ntot_local)), dim3(kBlock), 0, st, tv, (const char *)nodes_all,
+		                   (size_t)lay.nodes_bytes, lay.ntot_local, G, d, offM);
+		if (offM > 0)
+			hipLaunchKernelGGL(dist_unpack_mpole_kernel, dim3(grid1d((long long)G * lay.ntot_local * offM)), dim3(kBlock), 0, st, tv,
+			                   (const char *)nodes_all, (size_t)lay.nodes_bytes, lay.ntot_local, G, d, offM);
+		if (d > 0)
+		{
+			NBCO_TRY(launch_m2m_top_gen(c, P, tv.center, tv.mpole, tv.mult, d - 1));
+			TopView top = top_view(c, ntop);
+			hipLaunchKernelGGL(dist_top_csz_kernel, dim3(1), dim3(64), 0, st, tv, (const float *)top.lbound, (const float *)top.rbound, (1 << d) - 1);
+		}
+		NBCO_HIP(hipGetLastError());
+	}
+	KdCounts cnt;
+	const Dom dm{d, lay.rank};
+	NBCO_TRY(kd_interact(c, tv, (const float4 *)pos_all, N, g.mlt_max, dm, (long long)lay.rank * nl, nl, c->unsort.as<int>(), a_local, param, cnt));
+	if (cnt.sel_overflow) return c->fail(NBCO_ERR_UNSUPPORTED, "nbco_dist_finish: unresolved tie overflow of the selection build");
+	if (c->dist.rebuilt) NBCO_TRY(kd_finish_order(c, buf_local, nl));
+	c->tree_valid = true;
+	c->tree_n = nl;
+	c->tree_order = P;
+	c->eval_counter += 1;
+	nbco_kd_info &info = c->info;
+	info.L = L; info.ntot = ntot; info.order = P; info.mlt_max = g.mlt_max; info.n = N;
+	info.p2p_pairs = cnt.np2p; info.m2l_pairs = cnt.nm2l; info.rebuilt = c->dist.rebuilt ? 1 : 0;
+	info.directed_p2p = -1;
 	return NBCO_OK;
 }
 

@@ -218,6 +218,30 @@ int nbco_fmm_traceless(nbco_ctx *c, float *p, float *a, long long n, const float
 	return c ? c->fail(NBCO_ERR_UNSUPPORTED, "nbco_fmm_traceless: the octree-traceless evaluator is not built yet") : NBCO_ERR_ARG;
 }
 
+int nbco_dist_layout_query(nbco_ctx *c, long long n_global, int world, int rank, nbco_dist_layout *out)
+{
+	if (!c || !out) return c ? c->fail(NBCO_ERR_ARG, "nbco_dist_layout_query: null pointer") : NBCO_ERR_ARG;
+	return kd_dist_layout(c, n_global, world, rank, out);
+}
+int nbco_dist_partition(nbco_ctx *c, const float *state_all, long long n_global, int world, int rank, float *state_local)
+{
+	if (!c || !state_all || !state_local) return c ? c->fail(NBCO_ERR_ARG, "nbco_dist_partition: null pointer") : NBCO_ERR_ARG;
+	NBCO_TRY(kd_dist_partition(c, state_all, n_global, world, rank, state_local));
+	return maybe_sync(c);
+}
+int nbco_dist_local(nbco_ctx *c, float *buf_local, long long n_local, void *nodes_send, void *pos_send)
+{
+	if (!c || !buf_local || !nodes_send || !pos_send) return c ? c->fail(NBCO_ERR_ARG, "nbco_dist_local: null pointer") : NBCO_ERR_ARG;
+	NBCO_TRY(kd_dist_local(c, buf_local, n_local, nodes_send, pos_send));
+	return maybe_sync(c);
+}
+int nbco_dist_finish(nbco_ctx *c, const void *nodes_all, const void *pos_all, float *buf_local, float *a_local, const float *param)
+{
+	if (!c || !nodes_all || !pos_all || !buf_local || !a_local) return c ? c->fail(NBCO_ERR_ARG, "nbco_dist_finish: null pointer") : NBCO_ERR_ARG;
+	NBCO_TRY(kd_dist_finish(c, nodes_all, pos_all, buf_local, a_local, param));
+	return maybe_sync(c);
+}
+
 static int eval_kind(nbco_ctx *c, int kind, float *p, float *a, long long n, const float *param)
 {
 	switch (kind)

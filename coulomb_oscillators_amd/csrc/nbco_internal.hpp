@@ -75,6 +75,14 @@ struct nbco_ctx
 	DevBuf p2p_chunk_cnt, p2p_chunk_off, p2p_chunks;
 	DevBuf list_cnt;
 	DevBuf sel_hist, sel_nodes, sel_ties;   // selection build (k_kdselect.hip)
+	// multi-GPU kd-domain sharding: boxes / split axes of the global levels 0 .. d, the assembled global tree
+	DevBuf dist_top, dist_tree;
+	struct DistState
+	{
+		int world = 0, rank = 0, d = 0, L = 0;
+		long long n_global = 0, n_local = 0;
+		bool partitioned = false, local_done = false, rebuilt = false;
+	} dist;
 	bool force_sort_build = false;          // set after a tie overflow: use the sorting build from then on
 	long long list_cap = 0;
 	// operator tables
@@ -137,15 +145,22 @@ int launch_energy(nbco_ctx *c, const float *buf, long long n, const float *param
 // k_fmm_kd.hip
 int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *param);
 int kd_copy_out(nbco_ctx *c, int which, void *host_dst, long long host_bytes);
+// multi-GPU kd-domain sharding (k_fmm_kd.hip)
+int kd_dist_layout(nbco_ctx *c, long long n_global, int world, int rank, nbco_dist_layout *out);
+int kd_dist_partition(nbco_ctx *c, const float *state_all, long long n_global, int world, int rank, float *state_local);
+int kd_dist_local(nbco_ctx *c, float *buf_local, long long n_local, void *nodes_send, void *pos_send);
+int kd_dist_finish(nbco_ctx *c, const void *nodes_all, const void *pos_all, float *buf_local, float *a_local, const float *param);
 // k_kdselect.hip
 int kd_select_begin(nbco_ctx *c, int l0);
 int kd_select_level(nbco_ctx *c, int l, long long n, const float4 *pos_in, const int *unsort_in, float4 *pos_out, int *unsort_out,
                     float *lbound, float *rbound, int *splitdim, int *index, int *flag);
 // k_farfield.hip
 int launch_upward_gen(nbco_ctx *c, int P, const float4 *pos, float *center, float *mpole, int *mult, const int *index, int L);
-int launch_downward_gen(nbco_ctx *c, int P, const float *center, float *local, int L);
+int launch_downward_gen(nbco_ctx *c, int P, const float *center, float *local, int L, int dom_d, int dom_g);
+int launch_m2m_top_gen(nbco_ctx *c, int P, float *center, float *mpole, int *mult, int ltop);
 int launch_l2p_gen(nbco_ctx *c, int P, const float4 *pos, const float *center, const float *local, const float4 *near, const int *chunk_off,
-                   const int *index, int mlt_max, const int *unsort, int scatter, const float *param, float *a, int have_near, long long n, int L);
+                   const int *index, int mlt_max, const int *unsort, int scatter, const float *param, float *a, int have_near, long long n, int L,
+                   long long own0, long long own_n);
 // k_m2l.hip
 int launch_m2l_lanes(nbco_ctx *c, int P, const float4 *csz, const float *mpole, float *local, const uint64_t *keys, const int *start,
                      int shift, int ntot);

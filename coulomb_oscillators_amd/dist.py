@@ -1,0 +1,166 @@
+"""Multi-GPU orchestration of the kd-tree FMM: kd-domain sharding with one all-gather per force evaluation.
+
+SURVEY 8(e): the balanced kd-tree's level-log2(G) nodes hold exactly N/G particles each
+(fmm_cart3_kdtree.cuh:109-137), so GPU g owns the subtree of node 2^d - 1 + g.  The C-ABI library does the
+three compute stages (``nbco_dist_partition`` / ``nbco_dist_local`` / ``nbco_dist_finish``, include/nbco.h)
+and never communicates; this module moves the two exchange buffers with ``torch.distributed``
+(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+One process per GPU::
+
+    run = DomainRun(Engine(fmm_order=6, ...), n_global, TorchComm())
+    run.partition(pos_mine, vel_mine)          # rebalance: every `rebalance` steps
+    run.leapfrog(param, dt)                    # or run.force(param)
+
+The exchange per evaluation is one all-gather of the node block (csz + multipoles of the domain's subtree)
+and one of the tree-ordered positions; forces need no reduction because cross-domain pairs are evaluated
+one-directionally on the owner of the target.
+"""
+import torch
+
+
+class TorchComm:
+    """all-gather over a torch.distributed process group (one rank per GPU)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def all_gather(self, out, inp):
+        if self.world == 1:
+            out.copy_(inp)
+        else:
+            self.dist.all_gather_into_tensor(out, inp, group=self.group)
+
+
+class SingleComm:
+    """world of one: the exchange degenerates to a copy (used by bench.py --gpus 1 style checks)."""
+    world, rank = 1, 0
+
+    def all_gather(self, out, inp):
+        out.copy_(inp)
+
+
+class DomainRun:
+    """State and per-step protocol of ONE rank.
+
+    `engine` needs dist_layout / dist_partition / dist_local / dist_finish / step / add_elastic (the
+    ctypes Engine, or a test double with the same methods for the CPU tests).
+    """
+
+    def __init__(self, engine, n_global, comm, device=None, rebalance=8):
+        self.eng = engine
+        self.comm = comm
+        self.world, self.rank = comm.world, comm.rank
+        self.n_global = int(n_global)
+        self.lay = engine.dist_layout(self.n_global, self.world, self.rank)
+        self.n_local = int(self.lay.n_local)
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.rebalance = int(rebalance)
+        f32, u8 = torch.float32, torch.uint8
+        nl, G = self.n_local, self.world
+        self.buf = torch.zeros(9 * nl, dtype=f32, device=self.device)          # [pos | vel | acc], float3 AoS each
+        self.state_all = torch.empty(6 * self.n_global, dtype=f32, device=self.device)
+        self.nodes_send = torch.empty(int(self.lay.nodes_bytes), dtype=u8, device=self.device)
+        self.pos_send = torch.empty(int(self.lay.pos_bytes), dtype=u8, device=self.device)
+        self.nodes_all = torch.empty(G * int(self.lay.nodes_bytes), dtype=u8, device=self.device)
+        self.pos_all = torch.empty(G * int(self.lay.pos_bytes), dtype=u8, device=self.device)
+        self.evals = 0
+
+    # views of the local state
+    @property
+    def pos(self):
+        return self.buf[: 3 * self.n_local]
+
+    @property
+    def vel(self):
+        return self.buf[3 * self.n_local: 6 * self.n_local]
+
+    @property
+    def acc(self):
+        return self.buf[6 * self.n_local:]
+
+    def exchange_bytes(self):
+        """bytes this rank receives per force evaluation"""
+        return (self.world - 1) * (int(self.lay.nodes_bytes) + int(self.lay.pos_bytes))
+
+    # ---- rebalance: gather the full state, redo the top log2(G) median splits, keep the own domain ----
+    def partition(self, pos_mine=None, vel_mine=None):
+        nl, N = self.n_local, self.n_global
+        pos_mine = self.pos if pos_mine is None else pos_mine
+        vel_mine = self.vel if vel_mine is None else vel_mine
+        self.comm.all_gather(self.state_all[: 3 * N], pos_mine.contiguous().view(-1))
+        self.comm.all_gather(self.state_all[3 * N:], vel_mine.contiguous().view(-1))
+        self.eng.dist_partition(self.state_all, N, self.world, self.rank, self.buf)
+        self.evals = 0
+
+    # ---- one force evaluation -------------------------------------------------------------------
+    def local(self):
+        self.eng.dist_local(self.buf, self.n_local, self.nodes_send, self.pos_send)
+
+    def exchange(self):
+        self.comm.all_gather(self.nodes_all, self.nodes_send)
+        self.comm.all_gather(self.pos_all, self.pos_send)
+
+    def finish(self, param=None, elastic=True):
+        self.eng.dist_finish(self.nodes_all, self.pos_all, self.buf, self.acc, param)
+        if elastic and param is not None:
+            self.eng.add_elastic(self.pos, self.acc, self.n_local, param[3:])
+        self.evals += 1
+
+    def force(self, param=None, elastic=True):
+        if self.rebalance > 0 and self.evals >= self.rebalance:
+            self.partition()
+        self.local()
+        self.exchange()
+        self.finish(param, elastic)
+
+    # ---- kick-drift-kick leapfrog on the local state (integrator.cuh:68-80) --------------------------
+    def leapfrog(self, param, dt, elastic=True, first=False):
+        nl = self.n_local
+        if first:
+            self.force(param, elastic)
+        self.eng.step(self.vel, self.acc, 0.5 * dt, nl)
+        self.eng.step(self.pos, self.vel, dt, nl)
+        self.force(param, elastic)
+        self.eng.step(self.vel, self.acc, 0.5 * dt, nl)
+
+
+class LoopbackWorld:
+    """G domains driven in lockstep inside ONE process / on ONE GPU (one Engine context per domain).
+
+    The collectives become concatenations, everything else is the production code path; this is how the
+    1-GPU box checks the sharded evaluation against the single-GPU one.
+    """
+
+    class _Comm:
+        def __init__(self, world, rank):
+            self.world, self.rank = world, rank
+
+        def all_gather(self, out, inp):   # filled in by LoopbackWorld
+            raise RuntimeError("loopback domains exchange through LoopbackWorld")
+
+    def __init__(self, engines, n_global, device=None, rebalance=0):
+        G = len(engines)
+        self.runs = [DomainRun(e, n_global, LoopbackWorld._Comm(G, r), device=device, rebalance=rebalance) for r, e in enumerate(engines)]
+        self.G = G
+
+    def partition(self, pos_parts, vel_parts):
+        state = torch.cat([torch.cat([p.reshape(-1) for p in pos_parts]), torch.cat([v.reshape(-1) for v in vel_parts])])
+        for r in self.runs:
+            r.state_all.copy_(state)
+            r.eng.dist_partition(r.state_all, r.n_global, r.world, r.rank, r.buf)
+            r.evals = 0
+
+    def force(self, param=None, elastic=True):
+        for r in self.runs:
+            r.local()
+        nodes = torch.cat([r.nodes_send for r in self.runs])
+        pos = torch.cat([r.pos_send for r in self.runs])
+        for r in self.runs:
+            r.nodes_all.copy_(nodes)
+            r.pos_all.copy_(pos)
+            r.finish(param, elastic)

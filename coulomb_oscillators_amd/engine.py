@@ -39,6 +39,12 @@ class KdInfo(C.Structure):
                 ("rebuilt", C.c_int)]
 
 
+class DistLayout(C.Structure):
+    _fields_ = [("world", C.c_int), ("rank", C.c_int), ("d", C.c_int), ("L", C.c_int), ("L_local", C.c_int),
+                ("ntot_local", C.c_int), ("order", C.c_int), ("n_global", C.c_longlong), ("n_local", C.c_longlong),
+                ("nodes_bytes", C.c_longlong), ("pos_bytes", C.c_longlong)]
+
+
 def lib_path():
     return _LIB
 
@@ -91,6 +97,10 @@ def _load():
         "nbco_energy": [P, P, LL, P, C.POINTER(D)],
         "nbco_kd_get_info": [P, C.POINTER(KdInfo)],
         "nbco_kd_copy": [P, I, P, LL],
+        "nbco_dist_layout_query": [P, LL, I, I, C.POINTER(DistLayout)],
+        "nbco_dist_partition": [P, P, LL, I, I, P],
+        "nbco_dist_local": [P, P, LL, P, P],
+        "nbco_dist_finish": [P, P, P, P, P, P],
         "nbco_profile_enable": [P, I],
         "nbco_profile_reset": [P],
         "nbco_profile_get": [P, I, C.POINTER(D), C.POINTER(LL)],
@@ -227,6 +237,21 @@ class Engine:
         out = (C.c_double * 3)()
         self._chk(self.lib.nbco_energy(self.ctx, _ptr(buf), n, _ptr(param), out))
         return list(out)
+
+    # ---- multi-GPU kd-domain sharding (see dist.py for the orchestration) ---------------------------
+    def dist_layout(self, n_global, world, rank):
+        lay = DistLayout()
+        self._chk(self.lib.nbco_dist_layout_query(self.ctx, n_global, world, rank, C.byref(lay)))
+        return lay
+
+    def dist_partition(self, state_all, n_global, world, rank, state_local):
+        self._chk(self.lib.nbco_dist_partition(self.ctx, _ptr(state_all), n_global, world, rank, _ptr(state_local)))
+
+    def dist_local(self, buf_local, n_local, nodes_send, pos_send):
+        self._chk(self.lib.nbco_dist_local(self.ctx, _ptr(buf_local), n_local, _ptr(nodes_send), _ptr(pos_send)))
+
+    def dist_finish(self, nodes_all, pos_all, buf_local, a_local, param=None):
+        self._chk(self.lib.nbco_dist_finish(self.ctx, _ptr(nodes_all), _ptr(pos_all), _ptr(buf_local), _ptr(a_local), _ptr(param)))
 
     # ---- kd-tree introspection ------------------------------------------------------------------
     def kd_info(self):

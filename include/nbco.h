@@ -138,6 +138,40 @@ enum {
 };
 int nbco_kd_copy(nbco_ctx *c, int which, void *host_dst, long long host_bytes);
 
+/* ---- multi-GPU: kd-domain sharding (the reference is single-GPU, the sharded tree is the
+ *      balanced kd-tree of fmm_cart3_kdtree.cuh:109-137 whose level-log2(G) nodes hold N/G particles each) ----
+ * One process per GPU, each with its own nbco_ctx.  This library never communicates: the caller moves
+ * the two send buffers with an all-gather (RCCL) between nbco_dist_local and nbco_dist_finish.
+ *
+ *   nbco_dist_layout_query   sizes of the exchange buffers for (n_global, world, rank) under the current opts
+ *   nbco_dist_partition      every `rebalance` steps: state_all = [pos N x 3 | vel N x 3] gathered from all
+ *                            ranks (identical everywhere); runs the top log2(world) median splits and
+ *                            writes the rank's domain [pos n_local x 3 | vel n_local x 3] to state_local
+ *   nbco_dist_local          builds the domain's subtree over buf_local = [pos | vel | ..] (n_local
+ *                            particles), upward pass; fills nodes_send (nodes_bytes) and pos_send (pos_bytes)
+ *   nbco_dist_finish         nodes_all / pos_all = the world x gathered buffers in rank order; far + near
+ *                            field for the own particles -> a_local (tree order); after a rebuild the
+ *                            positions and velocities in buf_local are permuted into tree order, exactly
+ *                            like nbco_fmm_kdtree with opts.unsort = 0
+ * The accelerations equal those of a single-GPU nbco_fmm_kdtree over the n_global particles bit for bit
+ * (rank r's particles are positions [r n_local, (r+1) n_local) of the single-GPU tree order).
+ * Requirements: world a power of two, n_global % world == 0, n_local >= 4096, fmm_order <= 8, opts.unsort = 0. */
+typedef struct nbco_dist_layout {
+	int world, rank;
+	int d;                 /* log2(world): global level of the domain roots */
+	int L, L_local;        /* leaf level of the global tree, of the domain's subtree (L - d) */
+	int ntot_local;        /* nodes of the domain's subtree */
+	int order;
+	long long n_global, n_local;
+	long long nodes_bytes; /* per-rank node block: float4 csz[ntot_local], float mpole[ntot_local][offM] */
+	long long pos_bytes;   /* per-rank position block: float4[n_local], tree order */
+} nbco_dist_layout;
+int nbco_dist_layout_query(nbco_ctx *c, long long n_global, int world, int rank, nbco_dist_layout *out);
+int nbco_dist_partition(nbco_ctx *c, const float *state_all, long long n_global, int world, int rank, float *state_local);
+int nbco_dist_local(nbco_ctx *c, float *buf_local, long long n_local, void *nodes_send, void *pos_send);
+int nbco_dist_finish(nbco_ctx *c, const void *nodes_all, const void *pos_all, float *buf_local, float *a_local,
+                     const float *param);
+
 /* ---- per-phase device timing (HIP events on the context's stream) ---------------------------- */
 enum {
 	NBCO_PH_BUILD = 0, NBCO_PH_P2M_M2M = 1, NBCO_PH_TRAVERSE = 2, NBCO_PH_LISTS = 3, NBCO_PH_P2P = 4,

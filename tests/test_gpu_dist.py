@@ -1,0 +1,149 @@
+"""GPU tests of the multi-GPU kd-domain sharding on ONE card: G domains, one context each, driven in
+lockstep by LoopbackWorld (the all-gathers become concatenations; everything else is the production path,
+through the C ABI).  Bar: the sharded evaluation equals the single-GPU evaluation BIT FOR BIT -- tree order
+of the particles, velocities carried along, accelerations -- and so inherits its parity with the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def make_state(oracle, n, kind="reference"):
+    if kind == "reference":
+        buf = oracle.init_reference(n)
+        return np.ascontiguousarray(buf[0]), np.ascontiguousarray(buf[1])
+    rng = np.random.default_rng(1234 + n)
+    if kind == "uniform":
+        return rng.random((n, 3), dtype=np.float32), rng.standard_normal((n, 3)).astype(np.float32)
+    # two clumps of different density: exercises uneven interaction lists across the domain boundaries
+    a = rng.standard_normal((n // 2, 3)).astype(np.float32) * 0.1
+    b = rng.standard_normal((n - n // 2, 3)).astype(np.float32) + np.float32(2.0)
+    return np.concatenate([a, b]), rng.standard_normal((n, 3)).astype(np.float32)
+
+
+def single_gpu(n, pos, vel, par, **opts):
+    import torch
+    from coulomb_oscillators_amd import Engine
+    e = Engine(**opts)
+    buf = torch.cat([torch.from_numpy(pos).reshape(-1), torch.from_numpy(vel).reshape(-1), torch.zeros(3 * n)]).cuda()
+    e.fmm_cart3_kdtree(buf, buf[6 * n:], n, par)
+    torch.cuda.synchronize()
+    return e, buf
+
+
+def loopback(n, G, pos, vel, **opts):
+    import torch
+    from coulomb_oscillators_amd import Engine, LoopbackWorld
+    engines = [Engine(**opts) for _ in range(G)]
+    world = LoopbackWorld(engines, n)
+    nl = n // G
+    # the initial ownership is arbitrary: contiguous slices of the caller's order
+    world.partition([torch.from_numpy(pos[r * nl:(r + 1) * nl]).cuda() for r in range(G)],
+                    [torch.from_numpy(vel[r * nl:(r + 1) * nl]).cuda() for r in range(G)])
+    return world
+
+
+@pytest.mark.parametrize("n,G,p,kind", [(32768, 2, 6, "reference"), (32768, 4, 4, "reference"), (32768, 8, 6, "clumps"),
+                                        (40000, 8, 5, "uniform"), (24576, 2, 3, "clumps"), (1 << 20, 4, 6, "reference")])
+def test_sharded_equals_single_gpu(oracle32, n, G, p, kind):
+    import torch
+    pos, vel = make_state(oracle32, n, kind)
+    par = torch.from_numpy(oracle32.params(n)).cuda()
+    opts = dict(fmm_order=p, unsort=0, tree_steps=1)
+    e1, ref = single_gpu(n, pos, vel, par, **opts)
+    world = loopback(n, G, pos, vel, **opts)
+    world.force(par, elastic=False)
+    torch.cuda.synchronize()
+    nl = n // G
+    got_pos = torch.cat([r.pos for r in world.runs])
+    got_vel = torch.cat([r.vel for r in world.runs])
+    got_acc = torch.cat([r.acc for r in world.runs])
+    assert torch.equal(got_pos, ref[:3 * n]), "tree order of the positions differs"
+    assert torch.equal(got_vel, ref[3 * n:6 * n]), "velocities were not carried along"
+    assert torch.isfinite(got_acc).all()
+    assert torch.equal(got_acc, ref[6 * n:]), "accelerations differ from the single-GPU evaluation"
+    # every domain only pays for its own share of the interactions (+ the boundary)
+    i1 = e1.kd_info()
+    tot = sum(r.eng.kd_info().p2p_pairs for r in world.runs)
+    assert i1.p2p_pairs <= tot <= 2 * i1.p2p_pairs
+    assert all(r.eng.kd_info().L == i1.L for r in world.runs)
+
+
+def test_sharded_matches_oracle(oracle32):
+    """end to end against the CPU oracle (1e-5 relative, the bar of the single-GPU path)"""
+    import torch
+    from nbutil import force_err
+    n, G, p = 16384, 4, 6
+    o = oracle32
+    buf = o.init_reference(n)
+    par = o.params(n)
+    want = o.fmm_kd(buf[:2].copy(), par, p=p, threads=4, unsort=True)[1]
+    world = loopback(n, G, np.ascontiguousarray(buf[0]), np.ascontiguousarray(buf[1]), fmm_order=p, unsort=0, tree_steps=1)
+    world.force(torch.from_numpy(par).cuda(), elastic=False)
+    torch.cuda.synchronize()
+    # undo the tree order: the carried positions identify the particles (all distinct)
+    got_pos = torch.cat([r.pos for r in world.runs]).cpu().numpy().reshape(n, 3)
+    got_acc = torch.cat([r.acc for r in world.runs]).cpu().numpy().reshape(n, 3)
+    key = lambda x: np.lexsort((x[:, 2], x[:, 1], x[:, 0]))
+    ka, kb = key(got_pos), key(buf[0])
+    np.testing.assert_array_equal(got_pos[ka], buf[0][kb])
+    acc = np.empty_like(got_acc)
+    acc[kb] = got_acc[ka]
+    assert force_err(acc, want) < 1e-5
+
+
+def test_sharded_leapfrog_with_tree_reuse(oracle32):
+    """several leapfrog steps with opts.tree_steps = rebalance = 3: trajectories stay identical to the single GPU"""
+    import torch
+    from coulomb_oscillators_amd import Engine
+    n, G, p, steps, dt = 32768, 4, 5, 7, 1e-3
+    pos, vel = make_state(oracle32, n, "reference")
+    par = torch.from_numpy(oracle32.params(n)).cuda()
+    opts = dict(fmm_order=p, unsort=0, tree_steps=3)
+    # single GPU, same kernel sequence
+    e = Engine(**opts)
+    buf = torch.cat([torch.from_numpy(pos).reshape(-1), torch.from_numpy(vel).reshape(-1), torch.zeros(3 * n)]).cuda()
+    P, V, A = buf[:3 * n], buf[3 * n:6 * n], buf[6 * n:]
+
+    def f1():
+        e.fmm_cart3_kdtree(buf, A, n, par)
+        e.add_elastic(P, A, n, par[3:])
+    f1()
+    for _ in range(steps):
+        e.step(V, A, 0.5 * dt, n); e.step(P, V, dt, n); f1(); e.step(V, A, 0.5 * dt, n)
+    # sharded
+    world = loopback(n, G, pos, vel, **opts)
+    for r in world.runs:
+        r.rebalance = 0
+    nl = n // G
+
+    def fG(k):
+        if k > 0 and k % 3 == 0:
+            world.partition([r.pos for r in world.runs], [r.vel for r in world.runs])
+        world.force(par, elastic=True)
+    fG(0)
+    for s in range(steps):
+        for r in world.runs:
+            r.eng.step(r.vel, r.acc, 0.5 * dt, nl); r.eng.step(r.pos, r.vel, dt, nl)
+        fG(s + 1)
+        for r in world.runs:
+            r.eng.step(r.vel, r.acc, 0.5 * dt, nl)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat([r.pos for r in world.runs]), P)
+    assert torch.equal(torch.cat([r.vel for r in world.runs]), V)
+    assert torch.equal(torch.cat([r.acc for r in world.runs]), A)
+
+
+def test_layout_and_argument_errors(engine):
+    from coulomb_oscillators_amd import EngineError
+    engine.set(fmm_order=6)
+    lay = engine.dist_layout(1 << 20, 8, 3)
+    assert (lay.d, lay.n_local, lay.L_local) == (3, (1 << 20) // 8, lay.L - 3)
+    assert lay.nodes_bytes == lay.ntot_local * (16 + 4 * 56) and lay.pos_bytes == 16 * lay.n_local
+    for bad in [dict(n_global=1 << 20, world=3, rank=0), dict(n_global=(1 << 20) + 1, world=2, rank=0),
+                dict(n_global=1 << 20, world=2, rank=2), dict(n_global=4096, world=2, rank=0)]:
+        with pytest.raises(EngineError):
+            engine.dist_layout(**bad)
+    engine.set(fmm_order=10)
+    with pytest.raises(EngineError):
+        engine.dist_layout(1 << 20, 2, 0)
