@@ -35,9 +35,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=1048576, help="particles per GPU")
+    ap.add_argument("--particles", dest="n", type=int, default=1048576, help="particles per GPU (not --n: torchrun would read that as an abbreviation of its own flags)")
     ap.add_argument("--order", type=int, default=6)
     ap.add_argument("--tree-steps", type=int, default=1)
+    ap.add_argument("--rebalance", type=int, default=8,
+                    help="multi-GPU: force evaluations between two re-partitions of the kd-domains (top log2(G) splits)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL (one rank per GPU); gloo = rehearsal with several ranks sharing one card")
     ap.add_argument("--workload", default="fmm_kd", choices=["fmm_kd", "direct"])
     ap.add_argument("--dt", type=float, default=5e-4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -82,7 +86,7 @@ def main():
     args = parse()
     import torch
     import torch.distributed as dist
-    from coulomb_oscillators_amd import Engine, EVAL_DIRECT, EVAL_FMM_KDTREE, INTEG_LEAPFROG
+    from coulomb_oscillators_amd import Engine, EVAL_DIRECT, EVAL_FMM_KDTREE, INTEG_LEAPFROG, DomainRun, TorchComm
     from oracle import pyoracle as po          # initial conditions only (reference RNG stream) + cpu_baseline
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -90,21 +94,32 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        devidx = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(devidx)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", devidx))
+        else:
+            dist.init_process_group(backend="gloo")
     else:
         torch.cuda.set_device(0)
     n = args.n
+    sharded = world > 1 and args.workload == "fmm_kd"
+    n_sys = world * n if sharded else n          # particles of ONE physical system
     o = po.Oracle(np.float32)
-    # every rank owns an independent shard of n particles: same distribution, different seed stream
+    # every rank draws n particles of the same Gaussian ball from its own segment of the reference's RNG stream;
+    # sharded run: their union is the N = world * n system, the kd-domains are cut by the first partition
     buf = o.init_reference(n, discard=po.REF_DISCARD + 7919 * rank)
-    par = o.params(n)
+    par = o.params(n_sys)
     d = torch.from_numpy(buf).cuda()
     prm = torch.from_numpy(par).cuda()
 
     kind = EVAL_FMM_KDTREE if args.workload == "fmm_kd" else EVAL_DIRECT
     eng = Engine(fmm_order=args.order, unsort=0, tree_steps=args.tree_steps, sync=0)
     dom = "p2p" if args.workload == "fmm_kd" else "direct"
+    run = None
+    if sharded:
+        run = DomainRun(eng, n_sys, TorchComm(), rebalance=args.rebalance)
+        run.partition(d[0].reshape(-1), d[1].reshape(-1))
 
     def barrier():
         torch.cuda.synchronize()
@@ -112,33 +127,47 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    eng.compute_force(kind, d, n, prm)          # precompute accelerations (main3.cu:836-839)
+    if sharded:
+        run.force(prm)                          # precompute accelerations (main3.cu:836-839)
+        step = lambda: run.leapfrog(prm, args.dt)
+    else:
+        eng.compute_force(kind, d, n, prm)
+        step = lambda: eng.integrate(INTEG_LEAPFROG, kind, d, n, prm, args.dt)
     for _ in range(args.warmup):
-        eng.integrate(INTEG_LEAPFROG, kind, d, n, prm, args.dt)
+        step()
     eng.profile(True if args.profile_all else [dom])
     eng.profile_reset()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        eng.integrate(INTEG_LEAPFROG, kind, d, n, prm, args.dt)
+        step()
     barrier()
     elapsed = time.perf_counter() - t0
     prof = eng.profile_get()
     eng.profile(False)
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def reduce(x, op):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=op)
+        return float(t.item())
+
+    elapsed = reduce(elapsed, dist.ReduceOp.MAX)
 
     if args.workload == "fmm_kd":
         info = eng.kd_info()
-        pairs_per_eval = int(info.directed_p2p)
+        pairs_per_eval = int(info.directed_p2p)   # this rank's directed pair interactions per evaluation
         extra = {"L": info.L, "p2p_pairs": int(info.p2p_pairs), "m2l_pairs": int(info.m2l_pairs)}
+        if sharded:
+            extra.update({"n_system": n_sys, "rebalance_every": args.rebalance,
+                          "allgather_bytes_per_eval_per_gpu": run.exchange_bytes(), "backend": args.backend})
     else:
         pairs_per_eval = n * n
         extra = {}
-    assert torch.isfinite(d).all(), "non-finite state after the timed steps"
+    state = run.buf if sharded else d
+    assert torch.isfinite(state).all(), "non-finite state after the timed steps"
+    pairs_all = reduce(float(pairs_per_eval), dist.ReduceOp.SUM)
 
     value = world * n * args.steps / elapsed
     out = {
@@ -154,11 +183,13 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "gpair_per_s": world * pairs_per_eval * args.steps / elapsed / 1e9,
-        "config": {"workload": ("FMM-3D kd-tree p=%d, N=%d per GPU, leapfrog, Gaussian ball, tree rebuilt every %d step(s)"
-                                % (args.order, n, args.tree_steps)) if args.workload == "fmm_kd"
+        "gpair_per_s": pairs_all * args.steps / elapsed / 1e9,
+        "config": {"workload": ("FMM-3D kd-tree p=%d, N=%d per GPU (one system of %d), leapfrog, Gaussian ball, tree rebuilt every %d step(s)"
+                                % (args.order, n, n_sys, args.tree_steps)) if args.workload == "fmm_kd"
                    else "direct O(N^2) 3D, N=%d per GPU, leapfrog" % n,
-                   "n_per_gpu": n, "order": args.order, "dt": args.dt, "parallelism": "kd-domain shards x%d" % world, **extra},
+                   "n_per_gpu": n, "order": args.order, "dt": args.dt,
+                   "parallelism": ("kd-domain sharding x%d, one all-gather of nodes + positions per evaluation" % world) if sharded
+                   else ("single GPU" if world == 1 else "independent replicas x%d" % world), **extra},
     }
     if rank == 0:
         ms, launches = prof[dom]

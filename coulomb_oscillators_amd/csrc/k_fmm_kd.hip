@@ -125,6 +125,13 @@ __global__ void kd_root_kernel(TreeView t, const float *__restrict__ minmax6)   
 	t.index[0] = 0;
 }
 
+__global__ void root_union_kernel(const float *__restrict__ box6, float *__restrict__ minmax6)
+{
+	const int i = threadIdx.x;
+	if (i < 3) minmax6[i] = fminf(minmax6[i], box6[i]);
+	else if (i < 6) minmax6[i] = fmaxf(minmax6[i], box6[i]);
+}
+
 // composite keys of level l (fmm_cart3_kdtree.cuh:167-187): node j = floor(2^l i / n)
 __global__ __launch_bounds__(kBlock) void kd_keys_kernel(const float4 *__restrict__ pos, const int *__restrict__ splitdim_l, long long n,
                                                          int l, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
@@ -1389,13 +1396,12 @@ static int kd_build_upward(nbco_ctx *c, const float *p, long long n, int L, cons
 		NBCO_HIP(hipMemsetAsync(c->counters.as<int>() + 110, 0, sizeof(int), st));
 		if (rebuild)
 		{
-			if (!root6)
-			{
-				float *mm = c->small.as<float>() + 64;
-				NBCO_TRY(launch_minmax4(c, pos, n, mm));
-				root6 = mm;
-			}
-			hipLaunchKernelGGL(kd_root_kernel, dim3(1), dim3(64), 0, st, tv, root6);
+			float *mm = c->small.as<float>() + 64;
+			NBCO_TRY(launch_minmax4(c, pos, n, mm));
+			// a kd-domain inherits its box from the global tree's top splits; between two partitions the particles
+			// may have left it, and the selection keys are normalised to the node box: keep the union
+			if (root6) hipLaunchKernelGGL(root_union_kernel, dim3(1), dim3(64), 0, st, root6, mm);
+			hipLaunchKernelGGL(kd_root_kernel, dim3(1), dim3(64), 0, st, tv, (const float *)mm);
 			hipLaunchKernelGGL(iota_kernel, dim3(grid1d(n)), dim3(kBlock), 0, st, unsort, n);
 			// levels whose nodes exceed the LDS slice
 			int l0 = 0;

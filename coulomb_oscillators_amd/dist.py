@@ -32,6 +32,11 @@ class TorchComm:
     def all_gather(self, out, inp):
         if self.world == 1:
             out.copy_(inp)
+        elif self.dist.get_backend(self.group) == "gloo" and inp.is_cuda:
+            # rehearsal mode (several ranks on one card / CPU-only transport): stage through host memory
+            host = torch.empty(out.shape, dtype=out.dtype)
+            self.dist.all_gather_into_tensor(host, inp.cpu(), group=self.group)
+            out.copy_(host)
         else:
             self.dist.all_gather_into_tensor(out, inp, group=self.group)
 

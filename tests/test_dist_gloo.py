@@ -1,0 +1,174 @@
+"""CPU tests of the multi-GPU orchestration (coulomb_oscillators_amd/dist.py): world_size = 2 over gloo.
+
+The compute stages of the C-ABI library need a GPU, so here a small numpy test double speaks the same
+three-stage protocol (partition / local / finish) with an O(n^2) sum; what is under test is the host logic
+that the GPU box cannot rehearse with one card: buffer layout of the exchanges, rank order of the gathered
+blocks, the rebalance cadence and the leapfrog sequencing across real processes.  The sharded numerics
+themselves are checked bit for bit on the GPU (tests/test_gpu_dist.py)."""
+import os
+import socket
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from coulomb_oscillators_amd.dist import DomainRun, SingleComm, TorchComm
+
+
+class _Layout:
+    pass
+
+
+class NumpyDomainEngine:
+    """dist_* protocol of include/nbco.h in numpy (float64 arithmetic, float32 storage)."""
+    HDR = 8  # floats in the node block: [rank, n_local, sum x, sum y, sum z, 0, 0, 0]
+
+    def __init__(self, eps2=1e-4):
+        self.eps2 = eps2
+        self.calls = []
+
+    def dist_layout(self, n_global, world, rank):
+        assert n_global % world == 0 and world & (world - 1) == 0
+        lay = _Layout()
+        lay.world, lay.rank, lay.n_global, lay.n_local = world, rank, n_global, n_global // world
+        lay.d = world.bit_length() - 1
+        lay.nodes_bytes, lay.pos_bytes = 4 * self.HDR, 16 * lay.n_local
+        self.lay = lay
+        return lay
+
+    def dist_partition(self, state_all, n_global, world, rank, state_local):
+        self.calls.append("partition")
+        N, nl = n_global, n_global // world
+        st = state_all.numpy()
+        pos, vel = st[:3 * N].reshape(N, 3), st[3 * N:].reshape(N, 3)
+        order = np.arange(N)
+        seg = [(0, N)]
+        for _ in range(self.lay.d):           # balanced median splits along the longest box axis, stable
+            nxt = []
+            for (a, b) in seg:
+                p = pos[order[a:b]]
+                ax = int(np.argmax(p.max(0) - p.min(0)))
+                order[a:b] = order[a:b][np.argsort(p[:, ax], kind="stable")]
+                m = a + (b - a + 1) // 2
+                nxt += [(a, m), (m, b)]
+            seg = nxt
+        mine = order[rank * nl:(rank + 1) * nl]
+        out = state_local.numpy()
+        out[:3 * nl] = pos[mine].reshape(-1)
+        out[3 * nl:6 * nl] = vel[mine].reshape(-1)
+
+    def dist_local(self, buf, n_local, nodes_send, pos_send):
+        self.calls.append("local")
+        p = buf.numpy()[:3 * n_local].reshape(n_local, 3)
+        hdr = nodes_send.numpy().view(np.float32)
+        hdr[:] = 0
+        hdr[0], hdr[1] = self.lay.rank, n_local
+        hdr[2:5] = p.sum(0)
+        p4 = pos_send.numpy().view(np.float32).reshape(n_local, 4)
+        p4[:, :3] = p
+        p4[:, 3] = 0
+
+    def dist_finish(self, nodes_all, pos_all, buf, a_local, param=None):
+        self.calls.append("finish")
+        G, nl = self.lay.world, self.lay.n_local
+        hdr = nodes_all.numpy().view(np.float32).reshape(G, self.HDR)
+        p4 = pos_all.numpy().view(np.float32).reshape(G, nl, 4)
+        for r in range(G):                     # gathered blocks arrive in rank order and describe their positions
+            assert hdr[r, 0] == r and hdr[r, 1] == nl
+            np.testing.assert_allclose(hdr[r, 2:5], p4[r, :, :3].sum(0), rtol=1e-5, atol=1e-5)
+        own = buf.numpy()[:3 * nl].reshape(nl, 3)
+        np.testing.assert_array_equal(own, p4[self.lay.rank, :, :3])
+        src = p4.reshape(G * nl, 4)[:, :3].astype(np.float64)
+        dx = own.astype(np.float64)[:, None, :] - src[None, :, :]
+        r2 = (dx * dx).sum(-1) + self.eps2
+        acc = (dx / r2[..., None] ** 1.5).sum(1)
+        scale = float(param[0]) if param is not None else 1.0
+        a_local.numpy()[:] = (acc * scale).astype(np.float32).reshape(-1)
+
+    def step(self, b, a, ds, n):
+        b.numpy()[:3 * n] += np.float32(ds) * a.numpy()[:3 * n]
+
+    def add_elastic(self, p, a, n, k):
+        kk = k.numpy()[:3]
+        a.numpy().reshape(n, 3)[:] -= p.numpy().reshape(n, 3) * kk
+
+
+def _system(n, seed=11):
+    rng = np.random.default_rng(seed)
+    pos = rng.standard_normal((n, 3)).astype(np.float32)
+    vel = (0.1 * rng.standard_normal((n, 3))).astype(np.float32)
+    par = np.array([1.0 / n, 0, 0, 1.0, 1.5, 2.0], dtype=np.float32)
+    return pos, vel, par
+
+
+def _drive(run, par, steps, dt):
+    run.force(par)
+    for _ in range(steps):
+        run.leapfrog(par, dt)
+    return torch.cat([run.pos.view(-1, 3), run.vel.view(-1, 3), run.acc.view(-1, 3)], dim=1).numpy()
+
+
+def _worker(rank, world, port, n, steps, dt, rebalance, outdir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        pos, vel, par = _system(n)
+        nl = n // world
+        eng = NumpyDomainEngine()
+        run = DomainRun(eng, n, TorchComm(), device=torch.device("cpu"), rebalance=rebalance)
+        assert (run.world, run.rank, run.n_local) == (world, rank, nl)
+        run.partition(torch.from_numpy(pos[rank * nl:(rank + 1) * nl]).reshape(-1), torch.from_numpy(vel[rank * nl:(rank + 1) * nl]).reshape(-1))
+        res = _drive(run, torch.from_numpy(par), steps, dt)
+        np.save(os.path.join(outdir, "rank%d.npy" % rank), res)
+        with open(os.path.join(outdir, "calls%d.txt" % rank), "w") as f:
+            f.write(" ".join(eng.calls))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 4])
+def test_domain_run_over_gloo_matches_single_process(world):
+    import torch.multiprocessing as mp
+    n, steps, dt, rebalance = 512, 5, 1e-2, 2
+    pos, vel, par = _system(n)
+    one = DomainRun(NumpyDomainEngine(), n, SingleComm(), device=torch.device("cpu"), rebalance=rebalance)
+    one.partition(torch.from_numpy(pos).reshape(-1), torch.from_numpy(vel).reshape(-1))
+    ref = _drive(one, torch.from_numpy(par), steps, dt)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, _free_port(), n, steps, dt, rebalance, d), nprocs=world, join=True)
+        got = np.concatenate([np.load(os.path.join(d, "rank%d.npy" % r)) for r in range(world)])
+        calls = [open(os.path.join(d, "calls%d.txt" % r)).read().split() for r in range(world)]
+    # same particles, same trajectories (the summation order differs: float64 inside, so ~1 ulp of float32)
+    ka, kb = np.argsort(got[:, 0]), np.argsort(ref[:, 0])
+    np.testing.assert_allclose(got[ka], ref[kb], rtol=2e-5, atol=2e-6)
+    # protocol: partition first, then local/finish pairs, a re-partition after every `rebalance` evaluations
+    want = ["partition"]
+    ev = 0
+    for _ in range(steps + 1):
+        if ev >= rebalance:
+            want.append("partition")
+            ev = 0
+        want += ["local", "finish"]
+        ev += 1
+    assert all(c == want for c in calls), calls
+
+
+def test_exchange_bytes_and_views():
+    n, world = 256, 1
+    run = DomainRun(NumpyDomainEngine(), n, SingleComm(), device=torch.device("cpu"))
+    assert run.exchange_bytes() == 0
+    assert run.pos.numel() == run.vel.numel() == run.acc.numel() == 3 * n
+    assert run.pos.data_ptr() + 12 * n == run.vel.data_ptr()
