@@ -50,6 +50,21 @@ def parse():
     return ap.parse_args()
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this
+    same command, tools/rocprof_summary.py; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 wide reads)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        k = json.load(f)["kernels"]
+    for name, v in k.items():
+        if name.startswith(kernel):
+            return v["hbm_bytes_fetch_doubled"], os.path.relpath(files[-1], ROOT)
+    return None, None
+
+
 def cpu_baseline(args, n):
     """The oracle (a port of the reference's multithreaded CPU path) on a bounded sample of the same workload."""
     from oracle import pyoracle as po
@@ -196,9 +211,13 @@ def main():
         if launches:
             avg_s = ms * 1e-3 / launches
             ach = pairs_per_eval * FLOP_PER_PAIR / avg_s / 1e12
-            out["roofline"] = {"bound": "valu_fp32", "kernel": "p2p_kernel" if dom == "p2p" else "direct_tiles",
+            kname = "p2p_kernel" if dom == "p2p" else "direct_tiles"
+            default_cfg = world == 1 and n == 1048576 and args.order == 6
+            traffic, src = measured_traffic(kname) if default_cfg else (None, None)
+            out["roofline"] = {"bound": "valu_fp32", "kernel": kname,
                                "achieved": ach, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / FP32_VECTOR_PEAK_TFLOPS, "traffic": None,
+                               "frac": ach / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "B/launch",
+                               "traffic_source": src,
                                "pairs_per_launch": pairs_per_eval, "avg_launch_ms": avg_s * 1e3, "flop_per_pair": FLOP_PER_PAIR}
         if args.profile_all:
             out["phase_ms_per_step"] = {k: v[0] / args.steps for k, v in prof.items() if v[1]}
