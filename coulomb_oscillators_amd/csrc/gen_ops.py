@@ -85,6 +85,125 @@ def emit_expand_local(w, P, src):
                 w("\tconst float F%d = -(F%d + F%d);" % (full(x, y, z), full(x + 2, y, z - 2), full(x, y + 2, z - 2)))
 
 
+def odfact(n):
+    """n!! for odd n (and 1 for n <= 0)"""
+    r = 1
+    while n > 1:
+        r *= n
+        n -= 2
+    return r
+
+
+def coeff13(n, m):
+    return (-1) ** m * odfact(2 * (n - m) - 1)
+
+
+def coeff2(n, m):
+    return fact(n) // (2 ** m * fact(m) * fact(n - 2 * m))
+
+
+def harmonic_terms(n, x, z):
+    """TL(d^n)[x, y, z] * (2n-1)!! for z in {0, 1} as a list of (coefficient, (ex, ey, ez), k): coefficient * d^e * (r^2)^k
+    (fmm_cart_base3.cuh:711-727 / 830-846 / 931-947 written for the un-normalised vector d)"""
+    y = n - x - z
+    terms = []
+    for k1 in range(x // 2 + 1):
+        for k2 in range(y // 2 + 1):
+            c = coeff13(n, k1 + k2) * coeff2(x, k1) * coeff2(y, k2)
+            terms.append((c, (x - 2 * k1, y - 2 * k2, z), k1 + k2))
+    return terms
+
+
+def emit_r2_powers(w, kmax):
+    w("\tconst float R2_0 = 1.0f;")
+    w("\tconst float R2_1 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));")
+    for k in range(2, kmax + 1):
+        w("\tconst float R2_%d = R2_%d * R2_1;" % (k, k - 1))
+
+
+def harmonic_expr(n, x, z, scale):
+    """expression for scale * TL-harmonic component (x, z) of order n in terms of D{i} (= d^K / K!) and R2_k"""
+    by_k = {}
+    for (c, e, k) in harmonic_terms(n, x, z):
+        by_k.setdefault(k, []).append((c * fact(e[0]) * fact(e[1]) * fact(e[2]), e))
+    expr = None
+    for k in sorted(by_k):
+        inner = None
+        for (c, e) in by_k[k]:
+            t = "%s * D%d" % (lit(c * scale), full(*e))
+            inner = t if inner is None else "fmaf(%s, D%d, %s)" % (lit(c * scale), full(*e), inner)
+        t = inner if k == 0 else "(%s) * R2_%d" % (inner, k)
+        expr = t if expr is None else ("fmaf(%s, R2_%d, %s)" % (inner, k, expr) if False else "(%s + %s)" % (expr, t))
+    return expr
+
+
+def gen_oct(P, out):
+    """traceless-multipole operators of the uniform-octree evaluator (fmm_cart3_traceless.cuh):
+    P2M p2m_traceless_acc3 (fmm_cart_base3.cuh:920-949), M2M m2m_traceless_acc3 (:1078-1109)"""
+    w = out.append
+    offL = tl_off(P + 1)
+    # ---------------------------------------------------------------- P2M (traceless), orders 2..P
+    w("template <> __device__ __forceinline__ void p2m_tl_accum<%d>(float dx, float dy, float dz, float (&A)[%d])" % (P, offL))
+    w("{")
+    if P >= 2:
+        emit_monomials(w, P)
+        emit_r2_powers(w, P // 2)
+        for q in range(2, P + 1):
+            C = (-1) ** q / fact(q) / odfact(2 * q - 1)
+            for z in range(0, 2):
+                for x in range(q - z, -1, -1):
+                    w("\tA[%d] += %s;" % (tl_off(q) + tl_idx(x, z, q), harmonic_expr(q, x, z, C)))
+    else:
+        w("\t(void)dx; (void)dy; (void)dz; (void)A;")
+    w("}")
+    # ---------------------------------------------------------------- M2M (traceless), orders 2..P, one child
+    w("template <> __device__ __forceinline__ void m2m_tl_accum<%d>(const float *__restrict__ Mc, float dx, float dy, float dz, float (&A)[%d])"
+      % (P, offL))
+    w("{")
+    if P >= 2:
+        emit_monomials(w, P)
+        emit_r2_powers(w, P // 2)
+        # TP{m}_{i}: full symmetric layout of tracelesspow_m(d) / m!
+        w("\tconst float TP%d = 1.0f;" % full(0, 0, 0))
+        for m in range(1, P + 1):
+            C = 1.0 / odfact(2 * m - 1) / fact(m)
+            for z in range(0, min(1, m) + 1):
+                for x in range(m - z, -1, -1):
+                    w("\tconst float TP%d = %s;" % (full(x, m - x - z, z), harmonic_expr(m, x, z, C)))
+            for z in range(2, m + 1):
+                for x in range(m - z, -1, -1):
+                    y = m - x - z
+                    w("\tconst float TP%d = -(TP%d + TP%d);" % (full(x, y, z), full(x + 2, y, z - 2), full(x, y + 2, z - 2)))
+        # F{i}: full layout of the child's multipoles (orders 0, 2..P-... all used orders), from the traceless tuple
+        for k in range(0, P + 1):
+            if k == 1:
+                continue
+            for z in range(0, min(1, k) + 1):
+                for x in range(k - z, -1, -1):
+                    w("\tconst float F%d = Mc[%d];" % (full(x, k - x - z, z), tl_off(k) + tl_idx(x, z, k)))
+            for z in range(2, k + 1):
+                for x in range(k - z, -1, -1):
+                    y = k - x - z
+                    w("\tconst float F%d = -(F%d + F%d);" % (full(x, y, z), full(x + 2, y, z - 2), full(x, y + 2, z - 2)))
+        for n in range(2, P + 1):
+            for z in range(0, 2):
+                for x in range(n - z, -1, -1):
+                    y = n - x - z
+                    expr = "A[%d]" % (tl_off(n) + tl_idx(x, z, n))
+                    for m in range(0, n + 1):
+                        if n - m == 1:
+                            continue   # the child's dipole is identically zero (expansion about the centre of charge)
+                        for k1 in range(0, min(x, m) + 1):
+                            for k3 in range(max(0, m - k1 - y), min(z, m - k1) + 1):
+                                k2 = m - k1 - k3
+                                expr = "fmaf(TP%d, F%d, %s)" % (full(k1, k2, k3), full(x - k1, y - k2, z - k3), expr)
+                    w("\tA[%d] = %s;" % (tl_off(n) + tl_idx(x, z, n), expr))
+    else:
+        w("\t(void)Mc; (void)dx; (void)dy; (void)dz; (void)A;")
+    w("}")
+    w("")
+
+
 def gen(P, out):
     w = out.append
     offM = sym_off(P)
@@ -202,6 +321,7 @@ def main():
     out = ["// GENERATED by gen_ops.py -- do not edit.  Straight-line P2M / M2M / L2L / L2P bodies, orders 1..%d." % pmax, ""]
     for P in range(1, pmax + 1):
         gen(P, out)
+        gen_oct(P, out)
     with open(path, "w") as f:
         f.write("\n".join(out) + "\n")
 

@@ -11,14 +11,7 @@
 
 namespace {
 
-template <int P> __device__ __forceinline__ void p2m_accum(float dx, float dy, float dz, float (&A)[(P * (P + 1) * (P + 2) / 6) > 0 ? (P * (P + 1) * (P + 2) / 6) : 1]);
-template <int P> __device__ __forceinline__ void p2m_store(const float (&A)[(P * (P + 1) * (P + 2) / 6) > 0 ? (P * (P + 1) * (P + 2) / 6) : 1], float *__restrict__ M);
-template <int P> __device__ __forceinline__ void m2m_accum(const float *__restrict__ Mc, float dx, float dy, float dz, float (&A)[(P * (P + 1) * (P + 2) / 6) > 0 ? (P * (P + 1) * (P + 2) / 6) : 1]);
-template <int P> __device__ __forceinline__ void m2m_store(const float (&A)[(P * (P + 1) * (P + 2) / 6) > 0 ? (P * (P + 1) * (P + 2) / 6) : 1], float *__restrict__ M);
-template <int P> __device__ __forceinline__ void l2l_body(const float (&Lp)[(P + 1) * (P + 1)], float dx, float dy, float dz, float (&O)[(P + 1) * (P + 1)]);
-template <int P> __device__ __forceinline__ void l2p_body(const float (&Lp)[(P + 1) * (P + 1)], float dx, float dy, float dz, float &fx, float &fy, float &fz);
-
-#include "fmm_ops_gen.inc"
+#include "fmm_ops.hpp"
 
 constexpr int kBlock = 256;
 constexpr int kTopNodes = 256;   // levels with <= this many nodes are fused into one workgroup

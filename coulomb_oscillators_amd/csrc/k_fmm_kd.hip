@@ -26,6 +26,7 @@
 //             with the scatter back to the caller's order.
 #include "nbco_internal.hpp"
 #include "fmm_tables.hpp"
+#include "k_p2p.hpp"
 #include <rocprim/rocprim.hpp>
 #include <cmath>
 #include <algorithm>
@@ -783,16 +784,6 @@ __global__ __launch_bounds__(kBlock) void list_starts_kernel(const uint64_t *__r
 	}
 }
 
-// LDS hand-off between lanes of ONE wave: DS operations of a wave execute in order, so only the compiler
-// has to be kept from reordering them (no s_barrier: the waves of a block work on different items; a
-// fence or __syncthreads would also drain vmcnt and with it any prefetched global data).
-__device__ __forceinline__ void wave_lds_sync()
-{
-	asm volatile("" ::: "memory");
-	__builtin_amdgcn_wave_barrier();
-	asm volatile("" ::: "memory");
-}
-
 // ---- directed lists by counting sort ---------------------------------------------------------------
 // count -> exclusive scan -> scatter (slot order inside a target is whatever the atomics give) ->
 // per-target sort of the (short) source ranges.  The last step makes the lists, and with them every
@@ -917,96 +908,6 @@ __global__ __launch_bounds__(kBlock) void p2p_chunk_fill_kernel(const int *__res
 	{
 		const int b = start[i], e = start[i + 1], o = off[i], n = off[i + 1] - o;
 		for (int k = 0; k < n; ++k) chunk[o + k] = make_int4(i, min(b + k * kP2PChunk, e), min(b + (k + 1) * kP2PChunk, e), 0);
-	}
-}
-
-// One wave per chunk.  TPL lanes cover the leaf's targets, the 64/TPL lane groups walk different source
-// leaves of the chunk concurrently.  Source descriptors are fetched once (one per lane) and handed out
-// with shuffles; each group's source tile is prefetched into registers while the previous tile is being
-// consumed, staged in a double-buffered LDS tile and read back as group-uniform ds_read_b128
-// broadcasts.  Slots beyond a source leaf hold a far point whose r^-3 underflows to exactly 0 (3e36 <
-// FLT_MAX, (3e36)^-3/2 ~ 2e-55 -> 0): the pair loop needs no predicate.
-#define P2P_PAIR(PX, PY, PZ)                                               \
-	{                                                                      \
-		float dx = pi.x - (PX), dy = pi.y - (PY), dz = pi.z - (PZ);        \
-		float r2 = fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, eps2)));         \
-		float ri = __builtin_amdgcn_rsqf(r2);                              \
-		float ri3 = ri * ri * ri;                                          \
-		ax = fmaf(dx, ri3, ax);                                            \
-		ay = fmaf(dy, ri3, ay);                                            \
-		az = fmaf(dz, ri3, az);                                            \
-	}
-
-constexpr int kP2PWaves = 4;   // waves (= chunks) per 256-thread block; 64-thread blocks would cap a CU at 8 waves
-
-template <int TPL>
-__global__ __launch_bounds__(64 * kP2PWaves) void p2p_kernel(TreeView t, const float4 *__restrict__ pos, const int2 *__restrict__ desc,
-                                                             const int4 *__restrict__ chunk, const int *__restrict__ nchunks_total,
-                                                             float eps2, int mlt_max, float4 *__restrict__ partial)
-{
-	constexpr int G = 64 / TPL;
-	// source tiles as packed xyz triplets: four sources are read with three ds_read_b128 and every loaded
-	// dword is used (a float4-per-source tile is narrowed to ds_read_b96 by hipcc, twice the LDS cycles)
-	__shared__ __attribute__((aligned(16))) float tile_all[kP2PWaves][2][G][3 * TPL];
-	const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane / TPL, li = lane % TPL;
-	const int cid = blockIdx.x * kP2PWaves + wv;
-	if (cid >= *nchunks_total) return;
-	float(*tile)[G][3 * TPL] = tile_all[wv];
-	const int4 ck = chunk[cid];
-	const int node = kd_beg(t.L) + ck.x;
-	const int it = t.index[node], mt = t.mult[node];
-	const int nent = ck.z - ck.y;
-	const int nchunk = (mlt_max + TPL - 1) / TPL;
-	const float4 far = make_float4(1.e18f, 1.e18f, 1.e18f, 0.f);
-	const int2 mine = (lane < nent) ? desc[ck.y + lane] : make_int2(0, 0);
-	const int ntile = (nent + G - 1) / G;
-	// tile (et, jc) covers entry et * G + g, source particles jc * TPL + li
-	auto fetch = [&](int et, int jc) -> float4 {
-		const int ent = et * G + g;
-		const int is = __shfl(mine.x, ent), ms = __shfl(mine.y, ent);
-		const int j = jc * TPL + li;
-		return (ent < nent && j < ms) ? pos[is + j] : far;
-	};
-
-	for (int tb = 0; tb < mt; tb += TPL)
-	{
-		const int ti = tb + li;
-		const float4 pi = pos[it + (ti < mt ? ti : mt - 1)];
-		float ax = 0.f, ay = 0.f, az = 0.f;
-		if (ntile > 0)
-		{
-			float4 cur = fetch(0, 0);
-			int b = 0;
-			for (int et = 0; et < ntile; ++et)
-				for (int jc = 0; jc < nchunk; ++jc)
-				{
-					tile[b][g][3 * li] = cur.x; tile[b][g][3 * li + 1] = cur.y; tile[b][g][3 * li + 2] = cur.z;
-					int jn = jc + 1, en = et;
-					if (jn == nchunk) { jn = 0; ++en; }
-					if (en < ntile) cur = fetch(en, jn);
-					wave_lds_sync();
-					const float4 *t4 = reinterpret_cast<const float4 *>(tile[b][g]);
-#pragma unroll 2
-					for (int q4 = 0; q4 < TPL / 4; ++q4)
-					{
-						const float4 A = t4[3 * q4], B = t4[3 * q4 + 1], C = t4[3 * q4 + 2];
-						P2P_PAIR(A.x, A.y, A.z)
-						P2P_PAIR(A.w, B.x, B.y)
-						P2P_PAIR(B.z, B.w, C.x)
-						P2P_PAIR(C.y, C.z, C.w)
-					}
-					wave_lds_sync();
-					b ^= 1;
-				}
-		}
-#pragma unroll
-		for (int o = TPL; o < 64; o <<= 1)
-		{
-			ax += __shfl_xor(ax, o);
-			ay += __shfl_xor(ay, o);
-			az += __shfl_xor(az, o);
-		}
-		if (g == 0 && ti < mt) partial[(size_t)cid * mlt_max + ti] = make_float4(ax, ay, az, 0.f);
 	}
 }
 
@@ -1296,15 +1197,6 @@ static int build_directed_list(nbco_ctx *c, const int2 *pairs, long long npairs,
 	return NBCO_OK;
 }
 
-template <int TPL>
-static void launch_p2p(nbco_ctx *c, const TreeView &tv, const float4 *pos, const int2 *desc, const int4 *chunk, const int *ntotal,
-                       long long max_chunks, int mlt_max, float4 *partial)
-{
-	int grid = (int)((max_chunks + kP2PWaves - 1) / kP2PWaves);
-	hipLaunchKernelGGL(p2p_kernel<TPL>, dim3(grid), dim3(64 * kP2PWaves), 0, c->stream, tv, pos, desc, chunk, ntotal, c->o.eps2, mlt_max,
-	                   partial);
-}
-
 // node arrays of a tree with ntot nodes carved out of `buf`
 static int kd_carve(nbco_ctx *c, DevBuf &buf, KdTreeDev &k, int ntot, int offM, int offL)
 {
@@ -1571,10 +1463,11 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		const int2 *pd = c->p2p_keys.as<int2>();   // the unsorted key buffer is reused for the descriptors
 		const int4 *pc = c->p2p_chunks.as<int4>();
 		const int *pt = c->p2p_chunk_off.as<int>() + nleaf;   // total number of chunks
-		if (mlt_max <= 8) launch_p2p<8>(c, tv, pos, pd, pc, pt, max_chunks, mlt_max, near);
-		else if (mlt_max <= 16) launch_p2p<16>(c, tv, pos, pd, pc, pt, max_chunks, mlt_max, near);
-		else if (mlt_max <= 32) launch_p2p<32>(c, tv, pos, pd, pc, pt, max_chunks, mlt_max, near);
-		else launch_p2p<64>(c, tv, pos, pd, pc, pt, max_chunks, mlt_max, near);
+		const int *ti = tv.index + beg, *tm = tv.mult + beg;   // target group = leaf
+		if (mlt_max <= 8) launch_p2p<8>(c, ti, tm, pos, pd, pc, pt, max_chunks, mlt_max, mlt_max, near);
+		else if (mlt_max <= 16) launch_p2p<16>(c, ti, tm, pos, pd, pc, pt, max_chunks, mlt_max, mlt_max, near);
+		else if (mlt_max <= 32) launch_p2p<32>(c, ti, tm, pos, pd, pc, pt, max_chunks, mlt_max, mlt_max, near);
+		else launch_p2p<64>(c, ti, tm, pos, pd, pc, pt, max_chunks, mlt_max, mlt_max, near);
 		NBCO_HIP(hipGetLastError());
 	}
 	// ---- M2L, L2L ---------------------------------------------------------------------------------------

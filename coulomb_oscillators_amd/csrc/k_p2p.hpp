@@ -1,0 +1,121 @@
+// k_p2p.hpp -- chunked near-field kernel shared by the kd-tree and the octree evaluators.
+// (pair body of fmm_p2p_interaction, fmm_cart3_kdtree.cuh:767-795 / p2p3_krnl, appel.cuh:320-366)
+#pragma once
+#include "nbco_internal.hpp"
+
+namespace {
+
+// LDS hand-off between lanes of ONE wave: DS operations of a wave execute in order, so only the compiler
+// has to be kept from reordering them (no s_barrier: the waves of a block work on different items; a
+// fence or __syncthreads would also drain vmcnt and with it any prefetched global data).
+__device__ __forceinline__ void wave_lds_sync()
+{
+	asm volatile("" ::: "memory");
+	__builtin_amdgcn_wave_barrier();
+	asm volatile("" ::: "memory");
+}
+
+// A work unit ("chunk") is (target group, range [y, z) of source descriptors).  A target group is up to TPL
+// consecutive particles (a kd leaf, or a slice of an octree cell), a source descriptor is (first particle,
+// count <= src_max).  One wave per chunk.  TPL lanes cover the targets, the 64/TPL lane groups walk different
+// source descriptors concurrently.  Descriptors are fetched 64 at a time (one per lane) and handed out
+// with shuffles; each group's source tile is prefetched into registers while the previous tile is being
+// consumed, staged in a double-buffered LDS tile and read back as group-uniform ds_read_b128
+// broadcasts.  Slots beyond a source range hold a far point whose r^-3 underflows to exactly 0 (3e36 <
+// FLT_MAX, (3e36)^-3/2 ~ 2e-55 -> 0): the pair loop needs no predicate.  The wave stores the partial sums of
+// its targets at partial[chunk * stride + target]; the consumer adds a group's chunks in list order (fixed
+// order: bit-reproducible, no atomics).
+#define P2P_PAIR(PX, PY, PZ)                                               \
+	{                                                                      \
+		float dx = pi.x - (PX), dy = pi.y - (PY), dz = pi.z - (PZ);        \
+		float r2 = fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, eps2)));         \
+		float ri = __builtin_amdgcn_rsqf(r2);                              \
+		float ri3 = ri * ri * ri;                                          \
+		ax = fmaf(dx, ri3, ax);                                            \
+		ay = fmaf(dy, ri3, ay);                                            \
+		az = fmaf(dz, ri3, az);                                            \
+	}
+
+constexpr int kP2PWaves = 4;   // waves (= chunks) per 256-thread block; 64-thread blocks would cap a CU at 8 waves
+
+template <int TPL>
+__global__ __launch_bounds__(64 * kP2PWaves) void p2p_kernel(const int *__restrict__ tgt_index, const int *__restrict__ tgt_mult,
+                                                             const float4 *__restrict__ pos, const int2 *__restrict__ desc,
+                                                             const int4 *__restrict__ chunk, const int *__restrict__ nchunks_total,
+                                                             float eps2, int src_max, int stride, float4 *__restrict__ partial)
+{
+	constexpr int G = 64 / TPL;
+	// source tiles as packed xyz triplets: four sources are read with three ds_read_b128 and every loaded
+	// dword is used (a float4-per-source tile is narrowed to ds_read_b96 by hipcc, twice the LDS cycles)
+	__shared__ __attribute__((aligned(16))) float tile_all[kP2PWaves][2][G][3 * TPL];
+	const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane / TPL, li = lane % TPL;
+	const int cid = blockIdx.x * kP2PWaves + wv;
+	if (cid >= *nchunks_total) return;
+	float(*tile)[G][3 * TPL] = tile_all[wv];
+	const int4 ck = chunk[cid];
+	const int it = tgt_index[ck.x], mt = tgt_mult[ck.x];
+	const int nchunk = (src_max + TPL - 1) / TPL;
+	const float4 far = make_float4(1.e18f, 1.e18f, 1.e18f, 0.f);
+
+	for (int tb = 0; tb < mt; tb += TPL)
+	{
+		const int ti = tb + li;
+		const float4 pi = pos[it + (ti < mt ? ti : mt - 1)];
+		float ax = 0.f, ay = 0.f, az = 0.f;
+		for (int eb = ck.y; eb < ck.z; eb += 64)
+		{
+			const int nent = min(64, ck.z - eb);
+			const int2 mine = (lane < nent) ? desc[eb + lane] : make_int2(0, 0);
+			const int ntile = (nent + G - 1) / G;
+			// tile (et, jc) covers descriptor et * G + g, source particles jc * TPL + li
+			auto fetch = [&](int et, int jc) -> float4 {
+				const int ent = et * G + g;
+				const int is = __shfl(mine.x, ent), ms = __shfl(mine.y, ent);
+				const int j = jc * TPL + li;
+				return (ent < nent && j < ms) ? pos[is + j] : far;
+			};
+			float4 cur = fetch(0, 0);
+			int b = 0;
+			for (int et = 0; et < ntile; ++et)
+				for (int jc = 0; jc < nchunk; ++jc)
+				{
+					tile[b][g][3 * li] = cur.x; tile[b][g][3 * li + 1] = cur.y; tile[b][g][3 * li + 2] = cur.z;
+					int jn = jc + 1, en = et;
+					if (jn == nchunk) { jn = 0; ++en; }
+					if (en < ntile) cur = fetch(en, jn);
+					wave_lds_sync();
+					const float4 *t4 = reinterpret_cast<const float4 *>(tile[b][g]);
+#pragma unroll 2
+					for (int q4 = 0; q4 < TPL / 4; ++q4)
+					{
+						const float4 A = t4[3 * q4], B = t4[3 * q4 + 1], C = t4[3 * q4 + 2];
+						P2P_PAIR(A.x, A.y, A.z)
+						P2P_PAIR(A.w, B.x, B.y)
+						P2P_PAIR(B.z, B.w, C.x)
+						P2P_PAIR(C.y, C.z, C.w)
+					}
+					wave_lds_sync();
+					b ^= 1;
+				}
+		}
+#pragma unroll
+		for (int o = TPL; o < 64; o <<= 1)
+		{
+			ax += __shfl_xor(ax, o);
+			ay += __shfl_xor(ay, o);
+			az += __shfl_xor(az, o);
+		}
+		if (g == 0 && ti < mt) partial[(size_t)cid * stride + ti] = make_float4(ax, ay, az, 0.f);
+	}
+}
+
+template <int TPL>
+static void launch_p2p(nbco_ctx *c, const int *tgt_index, const int *tgt_mult, const float4 *pos, const int2 *desc, const int4 *chunk,
+                       const int *ntotal, long long max_chunks, int src_max, int stride, float4 *partial)
+{
+	int grid = (int)((max_chunks + kP2PWaves - 1) / kP2PWaves);
+	hipLaunchKernelGGL(p2p_kernel<TPL>, dim3(grid), dim3(64 * kP2PWaves), 0, c->stream, tgt_index, tgt_mult, pos, desc, chunk, ntotal, c->o.eps2,
+	                   src_max, stride, partial);
+}
+
+} // namespace

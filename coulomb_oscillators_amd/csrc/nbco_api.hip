@@ -214,8 +214,23 @@ int nbco_fmm_kdtree(nbco_ctx *c, float *p, float *a, long long n, const float *p
 }
 int nbco_fmm_traceless(nbco_ctx *c, float *p, float *a, long long n, const float *param)
 {
-	(void)p; (void)a; (void)n; (void)param;
-	return c ? c->fail(NBCO_ERR_UNSUPPORTED, "nbco_fmm_traceless: the octree-traceless evaluator is not built yet") : NBCO_ERR_ARG;
+	if (!c || !p || !a) return c ? c->fail(NBCO_ERR_ARG, "nbco_fmm_traceless: null pointer") : NBCO_ERR_ARG;
+	NBCO_TRY(fmm_oct_traceless_eval(c, p, a, n, param));
+	return maybe_sync(c);
+}
+int nbco_oct_get_info(nbco_ctx *c, nbco_oct_info *out)
+{
+	if (!c || !out) return c ? c->fail(NBCO_ERR_ARG, "nbco_oct_get_info: null pointer") : NBCO_ERR_ARG;
+	if (!c->oct.valid) return c->fail(NBCO_ERR_ARG, "nbco_oct_get_info: no octree evaluation has run");
+	const OctTreeDev &o = c->oct;
+	out->L = o.L; out->ntot = o.ntot; out->order = o.order; out->tpl = o.tpl; out->n = o.n;
+	out->m2l_entries = o.m2l_entries; out->p2p_groups = o.p2p_groups; out->p2p_desc = o.p2p_desc; out->p2p_chunks = o.p2p_chunks;
+	return NBCO_OK;
+}
+int nbco_oct_copy(nbco_ctx *c, int which, void *host_dst, long long host_bytes)
+{
+	if (!c || !host_dst) return c ? c->fail(NBCO_ERR_ARG, "nbco_oct_copy: null pointer") : NBCO_ERR_ARG;
+	return oct_copy_out(c, which, host_dst, host_bytes);
 }
 
 int nbco_dist_layout_query(nbco_ctx *c, long long n_global, int world, int rank, nbco_dist_layout *out)

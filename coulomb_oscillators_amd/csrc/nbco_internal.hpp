@@ -51,6 +51,18 @@ struct KdTreeDev
 	int *mult = nullptr, *index = nullptr, *splitdim = nullptr;      // [ntot]
 };
 
+// uniform-octree state of the last nbco_fmm_traceless call (fmmTree of fmm_cart3_symmetric.cuh:24-30)
+struct OctTreeDev
+{
+	bool valid = false;
+	int L = 0, ntot = 0, order = 0, tpl = 0;
+	long long n = 0, m2l_entries = 0, p2p_groups = 0, p2p_desc = 0, p2p_chunks = 0;
+	float4 *csz = nullptr;
+	float *mpole = nullptr, *local = nullptr;
+	int *mult = nullptr, *index = nullptr;
+	uint32_t *keys = nullptr, *perm = nullptr;
+};
+
 struct nbco_ctx
 {
 	nbco_opts o;
@@ -77,6 +89,9 @@ struct nbco_ctx
 	DevBuf sel_hist, sel_nodes, sel_ties;   // selection build (k_kdselect.hip)
 	// multi-GPU kd-domain sharding: boxes / split axes of the global levels 0 .. d, the assembled global tree
 	DevBuf dist_top, dist_tree;
+	// octree-traceless evaluator (k_fmm_oct.hip)
+	DevBuf oct_tree, oct_groups;
+	OctTreeDev oct;
 	struct DistState
 	{
 		int world = 0, rank = 0, d = 0, L = 0;
@@ -145,6 +160,9 @@ int launch_energy(nbco_ctx *c, const float *buf, long long n, const float *param
 // k_fmm_kd.hip
 int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *param);
 int kd_copy_out(nbco_ctx *c, int which, void *host_dst, long long host_bytes);
+// k_fmm_oct.hip
+int fmm_oct_traceless_eval(nbco_ctx *c, float *p, float *a, long long n, const float *param);
+int oct_copy_out(nbco_ctx *c, int which, void *host_dst, long long host_bytes);
 // multi-GPU kd-domain sharding (k_fmm_kd.hip)
 int kd_dist_layout(nbco_ctx *c, long long n_global, int world, int rank, nbco_dist_layout *out);
 int kd_dist_partition(nbco_ctx *c, const float *state_all, long long n_global, int world, int rank, float *state_local);

@@ -39,6 +39,15 @@ class KdInfo(C.Structure):
                 ("rebuilt", C.c_int)]
 
 
+class OctInfo(C.Structure):
+    _fields_ = [("L", C.c_int), ("ntot", C.c_int), ("order", C.c_int), ("tpl", C.c_int), ("n", C.c_longlong),
+                ("m2l_entries", C.c_longlong), ("p2p_groups", C.c_longlong), ("p2p_desc", C.c_longlong),
+                ("p2p_chunks", C.c_longlong)]
+
+
+OCT_FIELDS = {"mult": 0, "index": 1, "center4": 2, "mpole": 3, "local": 4, "keys": 5, "perm": 6}
+
+
 class DistLayout(C.Structure):
     _fields_ = [("world", C.c_int), ("rank", C.c_int), ("d", C.c_int), ("L", C.c_int), ("L_local", C.c_int),
                 ("ntot_local", C.c_int), ("order", C.c_int), ("n_global", C.c_longlong), ("n_local", C.c_longlong),
@@ -97,6 +106,8 @@ def _load():
         "nbco_energy": [P, P, LL, P, C.POINTER(D)],
         "nbco_kd_get_info": [P, C.POINTER(KdInfo)],
         "nbco_kd_copy": [P, I, P, LL],
+        "nbco_oct_get_info": [P, C.POINTER(OctInfo)],
+        "nbco_oct_copy": [P, I, P, LL],
         "nbco_dist_layout_query": [P, LL, I, I, C.POINTER(DistLayout)],
         "nbco_dist_partition": [P, P, LL, I, I, P],
         "nbco_dist_local": [P, P, LL, P, P],
@@ -273,6 +284,24 @@ class Engine:
         out = np.empty(shape, dtype=dt)
         if out.size:
             self._chk(self.lib.nbco_kd_copy(self.ctx, KD_FIELDS[name], out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
+
+    # ---- octree introspection -----------------------------------------------------------------------
+    def oct_info(self):
+        info = OctInfo()
+        self._chk(self.lib.nbco_oct_get_info(self.ctx, C.byref(info)))
+        return info
+
+    def oct_array(self, name):
+        import numpy as np
+        info = self.oct_info()
+        off = (info.order + 1) ** 2
+        shapes = {"mult": ((info.ntot,), np.int32), "index": ((info.ntot,), np.int32), "center4": ((info.ntot, 4), np.float32),
+                  "mpole": ((info.ntot, off), np.float32), "local": ((info.ntot, off), np.float32),
+                  "keys": ((info.n,), np.uint32), "perm": ((info.n,), np.uint32)}
+        shape, dt = shapes[name]
+        out = np.empty(shape, dtype=dt)
+        self._chk(self.lib.nbco_oct_copy(self.ctx, OCT_FIELDS[name], out.ctypes.data_as(C.c_void_p), out.nbytes))
         return out
 
     # ---- profiling ------------------------------------------------------------------------------

@@ -138,6 +138,26 @@ enum {
 };
 int nbco_kd_copy(nbco_ctx *c, int which, void *host_dst, long long host_bytes);
 
+/* ---- octree-traceless evaluator introspection (fmmTree, fmm_cart3_symmetric.cuh:24-30) ---------------------
+ * Valid after nbco_fmm_traceless.  Cells are level-major (level l starts at (8^l - 1) / 7), row-major inside a
+ * level; tuples are traceless, (order + 1)^2 floats per cell (orders 0..order). */
+typedef struct nbco_oct_info {
+	int L, ntot, order;
+	int tpl;                /* target-group width of the near-field work units */
+	long long n;
+	long long m2l_entries;  /* directed (target, source) stencil entries with a non-empty source */
+	long long p2p_groups, p2p_desc, p2p_chunks;
+} nbco_oct_info;
+int nbco_oct_get_info(nbco_ctx *c, nbco_oct_info *out);
+enum {
+	NBCO_OCT_MULT = 0, NBCO_OCT_INDEX = 1,   /* int[ntot] (index: leaves only) */
+	NBCO_OCT_CENTER4 = 2,                    /* float[ntot][4]: centre xyz, 0 */
+	NBCO_OCT_MPOLE = 3, NBCO_OCT_LOCAL = 4,  /* float[ntot][(order+1)^2] */
+	NBCO_OCT_KEYS = 5,                       /* uint32[n]: sorted cell keys (appel.cuh:44-55) */
+	NBCO_OCT_PERM = 6                        /* uint32[n]: cell-order position -> caller's index */
+};
+int nbco_oct_copy(nbco_ctx *c, int which, void *host_dst, long long host_bytes);
+
 /* ---- multi-GPU: kd-domain sharding (the reference is single-GPU, the sharded tree is the
  *      balanced kd-tree of fmm_cart3_kdtree.cuh:109-137 whose level-log2(G) nodes hold N/G particles each) ----
  * One process per GPU, each with its own nbco_ctx.  This library never communicates: the caller moves

@@ -1152,6 +1152,14 @@ void oracle_oct_get_ints(int which, int* out)
 	std::memcpy(out, src[which]->data(), sizeof(int) * src[which]->size());
 }
 
+// which: 0 centre [ntot][3], 1 mpole [ntot][(p+1)^2], 2 local [ntot][(p+1)^2]
+void oracle_oct_get_reals(int which, real* out)
+{
+	if (which == 0) std::memcpy(out, g_oct.center.data(), sizeof(vec3) * g_oct.center.size());
+	else if (which == 1) std::memcpy(out, g_oct.mpole.data(), sizeof(real) * g_oct.mpole.size());
+	else std::memcpy(out, g_oct.local.data(), sizeof(real) * g_oct.local.size());
+}
+
 // The wrappers of main3.cu:47-69: evaluator + add_elastic(param+3).  kind: 0 direct3, 1 kd FMM,
 // 2 octree-traceless FMM, 3 direct2.
 static void eval_force(int kind, real* buf, int n, const real* param, const oracle_opts* o, int elastic)
@@ -1313,6 +1321,34 @@ void oracle_op_p2m(real* M, int p, const real* pts, int npts, const real* c)
 }
 void oracle_op_m2m(real* Mout, const real* Min, int p, const real* d)
 { for (int q = 2; q <= p - 1; ++q) m2m_acc(Mout + sym_off(q), Min, q, vec3{d[0], d[1], d[2]}); }
+// octree-traceless flavour: P2M orders 2..p (fmm_cart3_traceless.cuh:61-89), M2M orders 2..p (:110-168),
+// M2L with traceless multipoles (:251)
+void oracle_op_p2m_tl(real* M, int p, const real* pts, int npts, const real* c)
+{
+	for (int j = 0; j < npts; ++j)
+	{
+		vec3 d{pts[3 * j] - c[0], pts[3 * j + 1] - c[1], pts[3 * j + 2] - c[2]};
+		real r = std::sqrt(dot(d, d));
+		if (r != 0) d = d / r;
+		for (int q = 2; q <= p; ++q) p2m_traceless_acc(M + tl_off(q), q, d, r);
+	}
+}
+void oracle_op_m2m_tl(real* Mout, const real* Min, int p, const real* dvec)
+{
+	vec3 d{dvec[0], dvec[1], dvec[2]};
+	real r = std::sqrt(dot(d, d));
+	if (r != 0) d = d / r;
+	std::vector<real> temp(2 * p + 16);
+	for (int k = 2; k <= p; ++k) m2m_traceless_acc(Mout + tl_off(k), temp.data(), Min, k, d, r);
+}
+void oracle_op_m2l_tl(real* L, const real* M, int p, const real* dvec, real eps2)
+{
+	vec3 d{dvec[0], dvec[1], dvec[2]};
+	real r = std::sqrt(dot(d, d) + eps2);
+	d = d / r;
+	std::vector<real> temp(4 * p + 16);
+	m2l_tl_acc(L, temp.data(), M, p, d, r);
+}
 void oracle_op_m2l(real* L, const real* M, int p, const real* dvec, real eps2)
 {
 	vec3 d{dvec[0], dvec[1], dvec[2]};

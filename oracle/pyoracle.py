@@ -64,6 +64,8 @@ class Oracle:
         L.oracle_kd_get_ints.argtypes = [C.c_int, P]
         L.oracle_kd_get_reals.argtypes = [C.c_int, P]
         L.oracle_oct_get_ints.argtypes = [C.c_int, P]
+        L.oracle_oct_get_reals.argtypes = [C.c_int, P]
+        L.oracle_oct_get_reals.restype = None
         L.oracle_compute_force.argtypes = [C.c_int, P, C.c_int, P, C.POINTER(Opts), C.c_int]
         L.oracle_integrate.argtypes = [C.c_int, C.c_int, P, C.c_int, P, C.c_longdouble, C.c_longdouble,
                                        C.POINTER(Opts), C.c_int]
@@ -169,6 +171,15 @@ class Oracle:
         out = {"L": L.oracle_oct_L(), "ntot": ntot}
         for i, (k, m) in enumerate([("mult", ntot), ("index", ntot), ("keys", n), ("perm", n)]):
             a = np.empty(m, dtype=np.int32); L.oracle_oct_get_ints(i, self.ptr(a)); out[k] = a
+        return out
+
+    def oct_expansions(self, p):
+        """centre / mpole / local arrays of the last fmm_oct_traceless call (order p)"""
+        L = self.lib
+        ntot, off = L.oracle_oct_ntot(), (p + 1) ** 2
+        out = {}
+        for i, (k, shape) in enumerate([("center", (ntot, 3)), ("mpole", (ntot, off)), ("local", (ntot, off))]):
+            a = np.empty(shape, dtype=self.dtype); L.oracle_oct_get_reals(i, self.ptr(a)); out[k] = a
         return out
 
     def compute_force(self, kind, buf, param, elastic=True, **kw):

@@ -1,0 +1,182 @@
+"""GPU parity tests of the uniform-octree evaluator with traceless multipoles (nbco_fmm_traceless, through the C ABI)
+against the CPU oracle (fmm_cart3_traceless.cuh restated in oracle/nbco_oracle.cpp).
+
+Bar: integer cell keys, the sort permutation and the cell ranges bit-exact; positions / velocities left in the
+same (cell) order; expansions and accelerations within 1e-5 (nbutil.force_err) of the oracle."""
+import numpy as np
+import pytest
+
+from nbutil import force_err
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(x):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def state(o, n, kind):
+    if kind == "gauss":
+        return o.init_reference(n)
+    if kind == "cube":
+        return o.init_reference(n, test_mode=True)
+    rng = np.random.default_rng(99 + n)
+    buf = np.zeros((3, n, 3), dtype=np.float32)
+    buf[0] = rng.standard_normal((n, 3)).astype(np.float32) * np.array([1.0, 0.6, 0.3], dtype=np.float32)
+    buf[1] = rng.standard_normal((n, 3)).astype(np.float32)
+    return buf
+
+
+def run_gpu(engine, buf, par, n, **opts):
+    import torch
+    engine.set(**opts)
+    d = dev(buf[:2])
+    a = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+    engine.fmm_cart3_traceless(d, a, n, dev(par) if par is not None else None)
+    torch.cuda.synchronize()
+    return d.cpu().numpy(), a.cpu().numpy()
+
+
+@pytest.mark.parametrize("n,p,kind", [(4096, 6, "cube"), (4096, 6, "gauss"), (30001, 6, "blob"), (5000, 8, "cube"),
+                                      (20000, 4, "blob"), (700, 3, "cube"), (65536, 7, "blob")])
+def test_cells_bit_exact_and_forces(engine, oracle32, oracle64, n, p, kind):
+    o = oracle32
+    buf = state(o, n, kind)
+    par = o.params(n)
+    pv, want = o.fmm_oct_traceless(buf[:2], par, p=p, threads=8)
+    tree = o.oct_tree(n)
+    ex = o.oct_expansions(p)
+    got_pv, got = run_gpu(engine, buf, par, n, fmm_order=p)
+    info = engine.oct_info()
+    assert (info.L, info.ntot, info.order, info.n) == (tree["L"], tree["ntot"], p, n)
+    np.testing.assert_array_equal(engine.oct_array("keys").astype(np.int64), tree["keys"])
+    np.testing.assert_array_equal(engine.oct_array("perm").astype(np.int64), tree["perm"])
+    beg = ((1 << (3 * info.L)) - 1) // 7
+    np.testing.assert_array_equal(engine.oct_array("index")[beg:], tree["index"][beg:])
+    first = 9    # levels 0 and 1 carry nothing
+    np.testing.assert_array_equal(engine.oct_array("mult")[first:], tree["mult"][first:])
+    # state left in cell order, bit for bit
+    np.testing.assert_array_equal(got_pv, pv)
+    assert force_err(got, want) < 1e-5
+    # centres and expansions.  A cell of a clustered input holds thousands of particles and the P2M sums run in a
+    # different order (wave-strided partial sums here, one sequential fp32 sum in the oracle): the yardstick for the
+    # raw tuples is the fp64 oracle, against which the GPU must be as good as the fp32 oracle is.
+    c4 = engine.oct_array("center4")
+    scale = np.abs(ex["center"][first:]).max() + 1e-30
+    assert np.abs(c4[first:, :3] - ex["center"][first:]).max() / scale < 1e-6
+    occupied = tree["mult"][first:] > 0    # the oracle also pushes locals into empty cells; nobody reads them
+    o64 = oracle64
+    o64.fmm_oct_traceless(buf[:2].astype(np.float64), par.astype(np.float64), p=p, threads=8)
+    same_cells = np.array_equal(o64.oct_tree(n)["keys"], tree["keys"])
+    ex64 = o64.oct_expansions(p)
+    for name in ("mpole", "local"):
+        g, w = engine.oct_array(name)[first:][occupied], ex[name][first:][occupied]
+        sc = np.abs(w).max(axis=0, keepdims=True).clip(1e-30)
+        err = (np.abs(g - w) / sc).max()
+        if same_cells:
+            t = ex64[name][first:][occupied]
+            floor = (np.abs(w - t) / sc).max()
+            assert (np.abs(g - t) / sc).max() < 2 * floor + 2e-5, name
+        else:
+            assert err < 1e-3, name
+
+
+@pytest.mark.parametrize("p", [1, 2, 5])
+def test_low_orders(engine, oracle32, p):
+    """orders below 6: the reference's unrolled M2L contracts nothing; oracle and GPU implement the intent"""
+    o = oracle32
+    n = 3000
+    buf = state(o, n, "blob")
+    par = o.params(n)
+    _, want = o.fmm_oct_traceless(buf[:2], par, p=p, threads=8)
+    _, got = run_gpu(engine, buf, par, n, fmm_order=p)
+    assert force_err(got, want) < 1e-5
+
+
+def test_accuracy_against_direct_sum(engine, oracle32):
+    """the evaluator reproduces the reference's own accuracy (2.6e-4 mean relative error at
+    p = 6, N = 4096, the default Gaussian ball; same bound as tests/test_oracle_pins.py)"""
+    o = oracle32
+    n = 4096
+    buf = state(o, n, "gauss")
+    par = o.params(n)
+    got_pv, got = run_gpu(engine, buf, par, n, fmm_order=6)
+    ref = o.direct3(got_pv[0], par, threads=8)
+    assert o.mean_relerr(got, ref) < 8e-4
+
+
+def test_options_and_edges(engine, oracle32):
+    o = oracle32
+    # no collisions: far field only
+    n = 6000
+    buf = state(o, n, "blob")
+    par = o.params(n)
+    _, want = o.fmm_oct_traceless(buf[:2], par, p=6, threads=8, coll=False)
+    _, got = run_gpu(engine, buf, par, n, fmm_order=6, coll=0)
+    assert force_err(got, want) < 1e-5
+    # wider stencil
+    _, want = o.fmm_oct_traceless(buf[:2], par, p=6, threads=8, radius=2.0)
+    _, got = run_gpu(engine, buf, par, n, fmm_order=6, coll=1, tree_radius=2.0)
+    assert force_err(got, want) < 1e-5
+    # inhomogeneity factor raises the level count
+    _, want = o.fmm_oct_traceless(buf[:2], par, p=6, threads=8, dens_inhom=8.0)
+    _, got = run_gpu(engine, buf, par, n, fmm_order=6, tree_radius=1.0, dens_inhom=8.0)
+    assert engine.oct_info().L == o.oct_tree(n)["L"]
+    assert force_err(got, want) < 1e-5
+    engine.set(dens_inhom=1.0)
+    # tiny systems (two levels is the minimum), no rescale parameter
+    for n in (1, 2, 37):
+        buf = state(o, n, "blob")
+        _, want = o.fmm_oct_traceless(buf[:2], None, p=6, threads=1)
+        _, got = run_gpu(engine, buf, None, n, fmm_order=6)
+        assert np.isfinite(got).all()
+        assert force_err(got, want) < 1e-5
+    # coincident particles all land in one cell (softened self interactions, no NaN)
+    n = 300
+    buf = np.zeros((3, n, 3), dtype=np.float32)
+    buf[0, :, :] = 0.25
+    buf[0, :5] = np.arange(15, dtype=np.float32).reshape(5, 3)
+    _, want = o.fmm_oct_traceless(buf[:2], None, p=6, threads=1, eps2=1e-4)
+    _, got = run_gpu(engine, buf, None, n, fmm_order=6, eps2=1e-4)
+    assert np.isfinite(got).all()
+    assert force_err(got, want) < 1e-5
+    engine.set(eps2=1e-18)
+
+
+def test_unsupported_order_fails_loudly(engine):
+    import torch
+    from coulomb_oscillators_amd import EngineError
+    engine.set(fmm_order=10)
+    d = torch.zeros(2 * 3 * 100, device="cuda")
+    a = torch.zeros(3 * 100, device="cuda")
+    with pytest.raises(EngineError):
+        engine.fmm_cart3_traceless(d, a, 100, None)
+
+
+def test_integrate_with_octree_evaluator(engine, oracle32):
+    """leapfrog through nbco_integrate with the octree evaluator against the oracle's integrator"""
+    import torch
+    from coulomb_oscillators_amd import EVAL_FMM_TRACELESS, INTEG_LEAPFROG
+    from oracle import pyoracle as po
+    o = oracle32
+    n, p, dt = 4096, 6, 1e-3
+    buf = state(o, n, "cube")
+    par = o.params(n)
+    ref = buf.copy()
+    o.compute_force(po.KIND_FMM_OCT, ref, par, p=p, threads=8)
+    for _ in range(3):
+        o.integrate(po.SCHEME_LEAPFROG, po.KIND_FMM_OCT, ref, par, dt, p=p, threads=8)
+    engine.set(fmm_order=p)
+    d = dev(buf)
+    prm = dev(par)
+    engine.compute_force(EVAL_FMM_TRACELESS, d, n, prm)
+    for _ in range(3):
+        engine.integrate(INTEG_LEAPFROG, EVAL_FMM_TRACELESS, d, n, prm, dt)
+    torch.cuda.synchronize()
+    got = d.cpu().numpy()
+    # the cell order may differ after several steps only if a particle sits within rounding of a cell face; compare as sets
+    key = lambda x: np.lexsort((x[:, 2], x[:, 1], x[:, 0]))
+    ka, kb = key(got[0]), key(ref[0])
+    np.testing.assert_allclose(got[0][ka], ref[0][kb], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(got[1][ka], ref[1][kb], rtol=1e-4, atol=1e-6)
