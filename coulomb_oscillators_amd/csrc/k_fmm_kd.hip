@@ -4,26 +4,29 @@
 // driver: the tree is rebuilt every evaluation (opts.tree_steps = 1) and leaf-leaf
 // pairs go to P2P before the admissibility test (opts.m2l_first = 0).
 //
-// gfx950 design (one evaluation):
-//   build     positions packed to float4; per level one stable radix sort of a 64-bit composite key
-//             (node << 32 | order-preserving float bits) over all particles -- the formulation the
-//             reference's CPU path uses (:167-202) -- followed by a gather; node boxes by evalBox's
-//             rule.  Geometry that feeds admissibility decisions (leaf centroids, parent centres, box
-//             diagonals, distances) is evaluated without FMA contraction so that the interaction
-//             lists equal the oracle's bit for bit.
-//   P2M/M2M   one wave per node, one lane per multipole component, flattened term tables.
-//   traverse  level-synchronous expansion of the pair frontier (no recursion, no per-block stacks);
-//             each 256-thread block classifies 2048 pairs and reserves list space with one atomic per
-//             list.
-//   lists     the unordered pair lists are expanded to directed (target, source) keys and radix
-//             sorted, which gives every target node / leaf a contiguous, deterministic source list:
-//             P2P and M2L then run without float atomics and are bit-reproducible.
-//   P2P       one wave per target leaf, sub-wave groups over different source leaves, sources staged
-//             through LDS; same 13-issue pair body as the direct kernel.
-//   M2L/L2L   one wave per target node, one lane per local-expansion component, flattened term tables,
+// gfx950 design (one evaluation; DESIGN.md section 4 has the measured kernel table):
+//   build     positions packed to float4.  Levels whose nodes exceed 4096 particles: exact radix selection of the
+//             median + unordered partition + tie resolver (k_kdselect.hip), no sort.  The rest of every subtree is
+//             built by one workgroup in LDS (kd_subtree_kernel), which first restores the order the reference's chain
+//             of stable per-level sorts (:167-202) would have produced, so the result is bit-identical to the oracle's.
+//             Fallback after a tie overflow: one stable radix sort of the composite key
+//             (node << 32 | order-preserving float bits) per level.  Geometry that feeds admissibility decisions
+//             (leaf centroids, parent centres, box diagonals, distances) is evaluated without FMA contraction so
+//             that the interaction lists equal the oracle's bit for bit.
+//   P2M/M2M   generated straight-line bodies, one thread per leaf / node (k_farfield.hip); orders 9-10: one wave per
+//             node, one lane per multipole component, flattened term tables (kernels below).
+//   traverse  level-synchronous expansion of the pair frontier (no recursion, no per-block stacks), two tree levels
+//             per launch; list slots are reserved with one packed block scan and three atomics per block.
+//   lists     counting sort of the directed (target, source) entries by target + per-target rank sort: every target
+//             node / leaf gets a contiguous, deterministic source list, so P2P and M2L run without float atomics and
+//             are bit-reproducible.
+//   P2P       per-target lists cut into chunks of <= 16 source leaves, one wave per chunk (k_p2p.hpp).
+//   M2L/L2L   register-resident generated bodies (k_m2l.hip, k_farfield.hip); orders 9-10: table kernels below with
 //             dimensionless gradient tensors (no fp32 overflow for p = 10).
-//   L2P       one wave per leaf, one lane per particle; fused with the final rescale by param[0] and
-//             with the scatter back to the caller's order.
+//   L2P       one thread per particle; fused with the near-field sum, the final rescale by param[0] and the scatter
+//             back to the caller's order.
+//   multi-GPU kd-domain sharding: the same two stages (kd_build_upward on the own subtree, kd_interact on the
+//             assembled global tree, pruned to the own domain), see the section at the end of this file.
 #include "nbco_internal.hpp"
 #include "fmm_tables.hpp"
 #include "k_p2p.hpp"
