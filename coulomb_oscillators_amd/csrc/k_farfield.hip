@@ -77,7 +77,7 @@ __device__ inline void centre_of(int m0, int m1, const float *c0, const float *c
 #pragma clang fp contract(on)
 
 template <int P, bool AGENT>
-__device__ inline void m2m_node(float *center, float *mpole, int *mult, int k)
+__device__ inline void m2m_node(float *center, float *mpole, int *mult, int k, int write_geom)
 {
 	constexpr int offM = P * (P + 1) * (P + 2) / 6;
 	float c[3];
@@ -104,22 +104,98 @@ __device__ inline void m2m_node(float *center, float *mpole, int *mult, int k)
 	if (offM > 0) M[0] = (float)mlt;
 	if (offM > 1) { M[1] = 0.f; M[2] = 0.f; M[3] = 0.f; }
 	m2m_store<P>(A, M);
-	center[3 * k] = c[0]; center[3 * k + 1] = c[1]; center[3 * k + 2] = c[2];
-	mult[k] = mlt;
+	if (write_geom)
+	{
+		center[3 * k] = c[0]; center[3 * k + 1] = c[1]; center[3 * k + 2] = c[2];
+		mult[k] = mlt;
+	}
 }
 
+// write_geom = 0: centres and multiplicities were produced by the centres pass below (the same arithmetic), which lets
+// the traversal start while the multipoles are still being shifted on a second stream
 template <int P>
-__global__ __launch_bounds__(kBlock) void m2m_gen_kernel(float *center, float *mpole, int *mult, int l)
+__global__ __launch_bounds__(kBlock) void m2m_gen_kernel(float *center, float *mpole, int *mult, int l, int write_geom)
 {
 	const int i = blockIdx.x * kBlock + threadIdx.x;
 	if (i >= (1 << l)) return;
-	m2m_node<P, false>(center, mpole, mult, (1 << l) - 1 + i);
+	m2m_node<P, false>(center, mpole, mult, (1 << l) - 1 + i, write_geom);
+}
+
+// ---- centres pass: centre of charge + multiplicity of every internal node (fmm_cart3_kdtree.cuh:339-348) -------------
+// One workgroup per subtree of <= kBlock leaves walks its levels in LDS; a second launch (one workgroup) does the levels
+// above the subtree roots.
+__global__ __launch_bounds__(kBlock) void kd_centres_kernel(float *center, int *mult, int L, int lr)
+{
+	__shared__ float Cl[kBlock][3];
+	__shared__ int Nl[kBlock];
+	const int t = threadIdx.x, b = blockIdx.x;
+	const int nl = 1 << (L - lr);   // leaves of this subtree
+	if (t < nl)
+	{
+		const int leaf = (1 << L) - 1 + b * nl + t;
+		Cl[t][0] = center[3 * leaf]; Cl[t][1] = center[3 * leaf + 1]; Cl[t][2] = center[3 * leaf + 2];
+		Nl[t] = mult[leaf];
+	}
+	__syncthreads();
+	for (int l = L - 1; l >= lr; --l)
+	{
+		const int cnt = 1 << (l - lr);
+		float c[3] = {0.f, 0.f, 0.f};
+		int m0 = 0, m1 = 0;
+		if (t < cnt)
+		{
+			m0 = Nl[2 * t]; m1 = Nl[2 * t + 1];
+			centre_of(m0, m1, Cl[2 * t], Cl[2 * t + 1], c);
+		}
+		__syncthreads();
+		if (t < cnt)
+		{
+			const int node = (1 << l) - 1 + b * cnt + t;
+			Cl[t][0] = c[0]; Cl[t][1] = c[1]; Cl[t][2] = c[2];
+			Nl[t] = m0 + m1;
+			center[3 * node] = c[0]; center[3 * node + 1] = c[1]; center[3 * node + 2] = c[2];
+			mult[node] = m0 + m1;
+		}
+		__syncthreads();
+	}
+}
+__global__ __launch_bounds__(kBlock) void kd_centres_top_kernel(float *center, int *mult, int ltop)
+{
+	__shared__ float Cl[kBlock][3];
+	__shared__ int Nl[kBlock];
+	const int t = threadIdx.x;
+	for (int l = ltop; l >= 0; --l)
+	{
+		const int cnt = 1 << l;
+		float c[3] = {0.f, 0.f, 0.f};
+		int mlt = 0;
+		if (t < cnt)
+		{
+			if (l == ltop) parent_centre<false>(center, mult, (1 << l) - 1 + t, c, mlt);   // children in HBM
+			else
+			{
+				const int m0 = Nl[2 * t], m1 = Nl[2 * t + 1];
+				centre_of(m0, m1, Cl[2 * t], Cl[2 * t + 1], c);
+				mlt = m0 + m1;
+			}
+		}
+		__syncthreads();
+		if (t < cnt)
+		{
+			const int node = (1 << l) - 1 + t;
+			Cl[t][0] = c[0]; Cl[t][1] = c[1]; Cl[t][2] = c[2];
+			Nl[t] = mlt;
+			center[3 * node] = c[0]; center[3 * node + 1] = c[1]; center[3 * node + 2] = c[2];
+			mult[node] = mlt;
+		}
+		__syncthreads();
+	}
 }
 
 // levels ltop .. 0 in one workgroup.  The expansions, centres and multiplicities of the level just built stay
 // in LDS (node i of a level sits in slot i), so a level costs LDS latency instead of HBM round trips.
 template <int P>
-__global__ __launch_bounds__(kTopNodes) void m2m_top_kernel(float *center, float *mpole, int *mult, int ltop)
+__global__ __launch_bounds__(kTopNodes) void m2m_top_kernel(float *center, float *mpole, int *mult, int ltop, int write_geom)
 {
 	constexpr int offM = P * (P + 1) * (P + 2) / 6, offS = offM > 0 ? offM : 1;
 	extern __shared__ float lds[];
@@ -174,8 +250,11 @@ __global__ __launch_bounds__(kTopNodes) void m2m_top_kernel(float *center, float
 			if (offM > 0) Ms[0] = (float)mlt;
 			if (offM > 1) { Ms[1] = 0.f; Ms[2] = 0.f; Ms[3] = 0.f; }
 			m2m_store<P>(A, Ms);
-			center[3 * k] = c[0]; center[3 * k + 1] = c[1]; center[3 * k + 2] = c[2];
-			mult[k] = mlt;
+			if (write_geom)
+			{
+				center[3 * k] = c[0]; center[3 * k + 1] = c[1]; center[3 * k + 2] = c[2];
+				mult[k] = mlt;
+			}
 			Cl[3 * t] = c[0]; Cl[3 * t + 1] = c[1]; Cl[3 * t + 2] = c[2];
 			Nl[t] = mlt;
 		}
@@ -285,7 +364,7 @@ __global__ __launch_bounds__(kBlock) void l2p_gen_kernel(const float4 *__restric
 static int grid_for(long long n) { return (int)((n + kBlock - 1) / kBlock); }
 
 template <int P>
-static int run_upward(nbco_ctx *c, const float4 *pos, float *center, float *mpole, int *mult, const int *index, int L)
+static int run_upward(nbco_ctx *c, const float4 *pos, float *center, float *mpole, int *mult, const int *index, int L, int write_geom)
 {
 	const int nleaf = 1 << L, beg = nleaf - 1;
 	hipLaunchKernelGGL(p2m_gen_kernel<P>, dim3(grid_for(nleaf)), dim3(kBlock), 0, c->stream, pos, (const float *)center, (const int *)mult, index,
@@ -295,9 +374,10 @@ static int run_upward(nbco_ctx *c, const float4 *pos, float *center, float *mpol
 	while (top > 1 && (size_t)top * (offS + 4) * sizeof(float) > 60 * 1024) top >>= 1;   // LDS budget of the fused top kernel
 	int l = L - 1;
 	for (; l >= 0 && (1 << l) > top; --l)
-		hipLaunchKernelGGL(m2m_gen_kernel<P>, dim3(grid_for(1 << l)), dim3(kBlock), 0, c->stream, center, mpole, mult, l);
+		hipLaunchKernelGGL(m2m_gen_kernel<P>, dim3(grid_for(1 << l)), dim3(kBlock), 0, c->stream, center, mpole, mult, l, write_geom);
 	if (l >= 0)
-		hipLaunchKernelGGL(m2m_top_kernel<P>, dim3(1), dim3(kTopNodes), (size_t)(1 << l) * (offS + 4) * sizeof(float), c->stream, center, mpole, mult, l);
+		hipLaunchKernelGGL(m2m_top_kernel<P>, dim3(1), dim3(kTopNodes), (size_t)(1 << l) * (offS + 4) * sizeof(float), c->stream, center, mpole, mult, l,
+		                   write_geom);
 	NBCO_HIP(hipGetLastError());
 	return NBCO_OK;
 }
@@ -309,7 +389,7 @@ static int run_m2m_top(nbco_ctx *c, float *center, float *mpole, int *mult, int 
 	constexpr int offM = P * (P + 1) * (P + 2) / 6, offS = offM > 0 ? offM : 1;
 	if ((1 << ltop) > kTopNodes || (size_t)(1 << ltop) * (offS + 4) * sizeof(float) > 60 * 1024)
 		return c->fail(NBCO_ERR_UNSUPPORTED, "launch_m2m_top_gen: too many top levels");
-	hipLaunchKernelGGL(m2m_top_kernel<P>, dim3(1), dim3(kTopNodes), (size_t)(1 << ltop) * (offS + 4) * sizeof(float), c->stream, center, mpole, mult, ltop);
+	hipLaunchKernelGGL(m2m_top_kernel<P>, dim3(1), dim3(kTopNodes), (size_t)(1 << ltop) * (offS + 4) * sizeof(float), c->stream, center, mpole, mult, ltop, 1);
 	NBCO_HIP(hipGetLastError());
 	return NBCO_OK;
 }
@@ -355,9 +435,20 @@ static int run_l2p(nbco_ctx *c, const float4 *pos, const float *center, const fl
 	default: return c->fail(NBCO_ERR_UNSUPPORTED, "generated far-field operators exist for orders 1..8"); \
 	}
 
-int launch_upward_gen(nbco_ctx *c, int P, const float4 *pos, float *center, float *mpole, int *mult, const int *index, int L)
+// centres + multiplicities of all internal nodes from the leaves' (2 launches)
+int launch_kd_centres(nbco_ctx *c, float *center, int *mult, int L)
 {
-#define CALL(PP) run_upward<PP>(c, pos, center, mpole, mult, index, L)
+	if (L == 0) return NBCO_OK;
+	const int lr = L > 8 ? L - 8 : 0;
+	hipLaunchKernelGGL(kd_centres_kernel, dim3(1 << lr), dim3(kBlock), 0, c->stream, center, mult, L, lr);
+	if (lr > 0) hipLaunchKernelGGL(kd_centres_top_kernel, dim3(1), dim3(kBlock), 0, c->stream, center, mult, lr - 1);
+	NBCO_HIP(hipGetLastError());
+	return NBCO_OK;
+}
+
+int launch_upward_gen(nbco_ctx *c, int P, const float4 *pos, float *center, float *mpole, int *mult, const int *index, int L, int write_geom)
+{
+#define CALL(PP) run_upward<PP>(c, pos, center, mpole, mult, index, L, write_geom)
 	NBCO_DISPATCH_P(P, CALL)
 #undef CALL
 }

@@ -1183,15 +1183,15 @@ static int sort_keys_u64(nbco_ctx *c, uint64_t *kin, uint64_t *kout, long long n
 // directed, per-target sorted list of `pairs` (+ one self entry for each of the targets [self0, self0 + nself)) into
 // keys_out; start[0..T].  cnt[0..T) holds the per-target pair-entry counts accumulated by the traversal, fill[0..T) is zero.
 static int build_directed_list(nbco_ctx *c, const int2 *pairs, long long npairs, int sub, int self0, int nself, int ntargets, int shift,
-                               unsigned *cnt, unsigned *fill, int *start, uint64_t *keys_tmp, uint64_t *keys_out, const Dom dm)
+                               unsigned *cnt, unsigned *fill, int *start, uint64_t *keys_tmp, uint64_t *keys_out, const Dom dm, DevBuf &scan_tmp)
 {
 	hipStream_t st = c->stream;
 	if (nself > 0) hipLaunchKernelGGL(add_one_kernel, dim3(grid1d(nself)), dim3(kBlock), 0, st, cnt + self0, nself);
 	size_t bytes = 0;
 	NBCO_HIP(rocprim::exclusive_scan(nullptr, bytes, (int *)cnt, start, 0, (size_t)(ntargets + 1), rocprim::plus<int>(), st));
-	NBCO_TRY(c->reserve(c->sort_tmp, bytes));
-	bytes = c->sort_tmp.bytes;
-	NBCO_HIP(rocprim::exclusive_scan(c->sort_tmp.ptr, bytes, (int *)cnt, start, 0, (size_t)(ntargets + 1), rocprim::plus<int>(), st));
+	NBCO_TRY(c->reserve(scan_tmp, bytes));
+	bytes = scan_tmp.bytes;
+	NBCO_HIP(rocprim::exclusive_scan(scan_tmp.ptr, bytes, (int *)cnt, start, 0, (size_t)(ntargets + 1), rocprim::plus<int>(), st));
 	hipLaunchKernelGGL(list_fill_kernel, dim3(grid1d(npairs + nself)), dim3(kBlock), 0, st, pairs, npairs, sub, self0, nself, shift, (const int *)start,
 	                   fill, keys_tmp, dm);
 	hipLaunchKernelGGL(list_segsort_kernel, dim3((ntargets + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, (const int *)start, ntargets,
@@ -1273,6 +1273,7 @@ static int kd_build_upward(nbco_ctx *c, const float *p, long long n, int L, cons
 	const int ntot = (1 << (L + 1)) - 1, nleaf = 1 << L;
 	const int mlt_max = (int)((n - 1) / nleaf + 1);
 	hipStream_t st = c->stream;
+	NBCO_TRY(c->join_aux());   // e.g. the multipole chain of an evaluation that is being redone
 	{
 		KdTreeDev &k = c->kd;
 		NBCO_TRY(kd_carve(c, c->treebuf, k, ntot, tb.offM, tb.offL));
@@ -1316,18 +1317,25 @@ static int kd_build_upward(nbco_ctx *c, const float *p, long long n, int L, cons
 		hipLaunchKernelGGL(kd_leaf_kernel, dim3(grid1d(nleaf)), dim3(kBlock), 0, st, tv, pos, n);
 		NBCO_HIP(hipGetLastError());
 	}
+	if (P <= 8)
+	{
+		// centres of all nodes first (2 launches): that is all the traversal needs, so the multipole chain
+		// (P2M + M2M, generated register-resident bodies of k_farfield.hip) runs beside it on the second stream
+		NBCO_TRY(launch_kd_centres(c, tv.center, tv.mult, L));
+		hipLaunchKernelGGL(kd_csz_kernel, dim3(grid1d(ntot)), dim3(kBlock), 0, st, tv);
+		NBCO_TRY(c->fork_aux());
+		StreamScope on_aux(c, c->aux);
+		PhaseScope ph(c, NBCO_PH_P2M_M2M);
+		NBCO_TRY(launch_upward_gen(c, P, pos, tv.center, tv.mpole, tv.mult, tv.index, L, 0));
+	}
+	else
 	{
 		PhaseScope ph(c, NBCO_PH_P2M_M2M);
-		if (P <= 8)
-			NBCO_TRY(launch_upward_gen(c, P, pos, tv.center, tv.mpole, tv.mult, tv.index, L));   // generated register-resident bodies (k_farfield.hip)
-		else
-		{
-			hipLaunchKernelGGL(p2m_kernel, dim3(nleaf), dim3(64), 0, st, tv, tb, pos);
-			for (int l = L - 1; l >= 0; --l) hipLaunchKernelGGL(m2m_kernel, dim3(kd_cnt(l)), dim3(64), 0, st, tv, tb, l);
-		}
+		hipLaunchKernelGGL(p2m_kernel, dim3(nleaf), dim3(64), 0, st, tv, tb, pos);
+		for (int l = L - 1; l >= 0; --l) hipLaunchKernelGGL(m2m_kernel, dim3(kd_cnt(l)), dim3(64), 0, st, tv, tb, l);
 		hipLaunchKernelGGL(kd_csz_kernel, dim3(grid1d(ntot)), dim3(kBlock), 0, st, tv);
-		NBCO_HIP(hipGetLastError());
 	}
+	NBCO_HIP(hipGetLastError());
 	return NBCO_OK;
 }
 
@@ -1398,10 +1406,14 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 			// a node had more pivot ties than the selection build resolves (degenerate coordinates): nothing has
 			// been written to the caller's arrays yet, the caller redoes the evaluation with the sorting build
 			out.sel_overflow = 1;
+			NBCO_TRY(c->join_aux());
 			return NBCO_OK;
 		}
 		if (h_cnt[2] != 0)
+		{
+			NBCO_TRY(c->join_aux());
 			return c->fail(NBCO_ERR_CAPACITY, "dual tree traversal exceeded the list capacity (raise opts.list_factor)");
+		}
 	}
 	const long long np2p = h_cnt[0], nm2l = h_cnt[1];
 	out.np2p = np2p; out.nm2l = nm2l;
@@ -1418,11 +1430,24 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		NBCO_TRY(c->reserve(c->m2l_keys_alt, sizeof(uint64_t) * (size_t)(dm2l + 1)));
 		NBCO_TRY(c->reserve(c->p2p_start, sizeof(int) * (size_t)(nleaf + 2)));
 		NBCO_TRY(c->reserve(c->m2l_start, sizeof(int) * (size_t)(ntot + 2)));
+		// the M2L list does not depend on the P2P list: build it on the second stream (behind the multipole chain)
+		NBCO_TRY(c->fork_aux());
+		{
+			StreamScope on_aux(c, c->aux);
+			if (dm2l > 0)
+			{
+				unsigned *cm = c->list_cnt.as<unsigned>() + 2 * ((size_t)nleaf + 2);
+				NBCO_TRY(build_directed_list(c, c->m2l_list.as<int2>(), nm2l, 0, 0, 0, ntot, shift, cm, cm + ((size_t)ntot + 2), c->m2l_start.as<int>(),
+				                             c->m2l_keys.as<uint64_t>(), c->m2l_keys_alt.as<uint64_t>(), dm, c->scan_tmp_aux));
+			}
+			else
+				NBCO_HIP(hipMemsetAsync(c->m2l_start.ptr, 0, sizeof(int) * (size_t)(ntot + 2), c->stream));
+		}
 		if (dp2p > 0)
 		{
 			unsigned *cp = c->list_cnt.as<unsigned>();
 			NBCO_TRY(build_directed_list(c, c->p2p_list.as<int2>(), np2p, beg, self0, nself, nleaf, shift, cp, cp + ((size_t)nleaf + 2),
-			                             c->p2p_start.as<int>(), c->p2p_keys.as<uint64_t>(), c->p2p_keys_alt.as<uint64_t>(), dm));
+			                             c->p2p_start.as<int>(), c->p2p_keys.as<uint64_t>(), c->p2p_keys_alt.as<uint64_t>(), dm, c->sort_tmp));
 			const int *total = c->p2p_start.as<int>() + nleaf;
 			hipLaunchKernelGGL(pair_count_kernel, dim3(grid1d(dp2p, 256)), dim3(kBlock), 0, st, tv, (const uint64_t *)c->p2p_keys_alt.as<uint64_t>(),
 			                   total, shift, (unsigned long long *)(c->counters.as<int>() + 100));
@@ -1447,14 +1472,6 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 			hipLaunchKernelGGL(p2p_chunk_fill_kernel, dim3(grid1d(nleaf)), dim3(kBlock), 0, st, (const int *)c->p2p_start.as<int>(),
 			                   (const int *)c->p2p_chunk_off.as<int>(), nleaf, c->p2p_chunks.as<int4>());
 		}
-		if (dm2l > 0)
-		{
-			unsigned *cm = c->list_cnt.as<unsigned>() + 2 * ((size_t)nleaf + 2);
-			NBCO_TRY(build_directed_list(c, c->m2l_list.as<int2>(), nm2l, 0, 0, 0, ntot, shift, cm, cm + ((size_t)ntot + 2), c->m2l_start.as<int>(),
-			                             c->m2l_keys.as<uint64_t>(), c->m2l_keys_alt.as<uint64_t>(), dm));
-		}
-		else
-			NBCO_HIP(hipMemsetAsync(c->m2l_start.ptr, 0, sizeof(int) * (size_t)(ntot + 2), st));
 		NBCO_HIP(hipGetLastError());
 	}
 	// ---- P2P --------------------------------------------------------------------------------------------
@@ -1474,6 +1491,7 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		NBCO_HIP(hipGetLastError());
 	}
 	// ---- M2L, L2L ---------------------------------------------------------------------------------------
+	NBCO_TRY(c->join_aux());   // multipoles and the M2L list are complete
 	{
 		PhaseScope ph(c, NBCO_PH_M2L);
 		if (P <= 8)
@@ -1757,6 +1775,7 @@ int kd_dist_local(nbco_ctx *c, float *buf_local, long long n_local, void *nodes_
 		}
 	}
 	c->dist.rebuilt = rebuild;
+	NBCO_TRY(c->join_aux());   // the multipoles are about to leave the GPU
 	const int offM = sym_off(lay.order);
 	NBCO_HIP(hipMemcpyAsync(nodes_send, c->kd.csz, sizeof(float4) * (size_t)lay.ntot_local, hipMemcpyDeviceToDevice, st));
 	NBCO_HIP(hipMemcpyAsync((char *)nodes_send + sizeof(float4) * (size_t)lay.ntot_local, c->kd.mpole, sizeof(float) * (size_t)lay.ntot_local * offM,

@@ -39,6 +39,29 @@ void nbco_ctx::phase_end(int ph)
 	hipEventRecord(timers[ph].pending.back().second, stream);
 }
 
+int nbco_ctx::fork_aux()
+{
+	if (!aux)
+	{
+		NBCO_HIP_M(this, hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+		NBCO_HIP_M(this, hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+		NBCO_HIP_M(this, hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+	}
+	NBCO_HIP_M(this, hipEventRecord(ev_fork, stream));
+	NBCO_HIP_M(this, hipStreamWaitEvent(aux, ev_fork, 0));
+	aux_pending = true;
+	return NBCO_OK;
+}
+
+int nbco_ctx::join_aux()
+{
+	if (!aux_pending) return NBCO_OK;
+	NBCO_HIP_M(this, hipEventRecord(ev_join, aux));
+	NBCO_HIP_M(this, hipStreamWaitEvent(stream, ev_join, 0));
+	aux_pending = false;
+	return NBCO_OK;
+}
+
 static int check_opts(nbco_ctx *c, const nbco_opts *o)
 {
 	if (o->fmm_order < 1 || o->fmm_order > kMaxOrder) return c->fail(NBCO_ERR_ARG, "fmm_order must be in 1..10");
@@ -108,7 +131,11 @@ int nbco_destroy(nbco_ctx *c)
 	DevBuf *bufs[] = {&c->pos4, &c->pos4_alt, &c->part, &c->small, &c->tmp3, &c->keys, &c->keys_alt, &c->idx, &c->idx_alt,
 	                  &c->unsort, &c->unsort_alt, &c->sort_tmp, &c->treebuf, &c->frontier_a, &c->frontier_b, &c->p2p_list,
 	                  &c->m2l_list, &c->counters, &c->p2p_keys, &c->p2p_keys_alt, &c->m2l_keys, &c->m2l_keys_alt,
-	                  &c->p2p_start, &c->m2l_start, &c->tables, &c->p2p_chunk_cnt, &c->p2p_chunk_off, &c->p2p_chunks, &c->sel_hist, &c->sel_nodes, &c->sel_ties, &c->list_cnt};
+	                  &c->p2p_start, &c->m2l_start, &c->tables, &c->p2p_chunk_cnt, &c->p2p_chunk_off, &c->p2p_chunks, &c->sel_hist, &c->sel_nodes, &c->sel_ties, &c->list_cnt,
+	                  &c->dist_top, &c->dist_tree, &c->oct_tree, &c->oct_groups, &c->scan_tmp_aux};
+	if (c->aux) { hipStreamSynchronize(c->aux); hipStreamDestroy(c->aux); }
+	if (c->ev_fork) hipEventDestroy(c->ev_fork);
+	if (c->ev_join) hipEventDestroy(c->ev_join);
 	for (DevBuf *b : bufs)
 		if (b->ptr) hipFree(b->ptr);
 	for (auto &t : c->timers)

@@ -15,6 +15,12 @@
 		if (e_ != hipSuccess) return c->fail_hip(e_, #call, __FILE__, __LINE__);                 \
 	} while (0)
 
+#define NBCO_HIP_M(ctx_, call)                                                                   \
+	do {                                                                                         \
+		hipError_t e_ = (call);                                                                  \
+		if (e_ != hipSuccess) return (ctx_)->fail_hip(e_, #call, __FILE__, __LINE__);            \
+	} while (0)
+
 #define NBCO_TRY(call)                   \
 	do {                                 \
 		int rc_ = (call);                \
@@ -66,7 +72,15 @@ struct OctTreeDev
 struct nbco_ctx
 {
 	nbco_opts o;
-	hipStream_t stream = nullptr;
+	hipStream_t stream = nullptr;   // the stream work is enqueued on (the caller's, or `aux` inside a StreamScope)
+	// second stream for the chains that do not depend on each other (multipoles || traversal, M2L lists || P2P lists);
+	// created lazily, ordered against `stream` with events only
+	hipStream_t aux = nullptr;
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	bool aux_pending = false;
+	DevBuf scan_tmp_aux;
+	int fork_aux();   // aux waits for everything enqueued on `stream` so far
+	int join_aux();   // `stream` waits for everything enqueued on aux
 	std::string err;
 	int device = 0;
 	int num_cu = 256;
@@ -127,6 +141,15 @@ struct nbco_ctx
 	void phase_end(int ph);
 };
 
+// enqueue on the auxiliary stream for the lifetime of the scope (every launcher reads c->stream at call time)
+struct StreamScope
+{
+	nbco_ctx *c;
+	hipStream_t saved;
+	StreamScope(nbco_ctx *c_, hipStream_t s) : c(c_), saved(c_->stream) { c->stream = s; }
+	~StreamScope() { c->stream = saved; }
+};
+
 struct PhaseScope
 {
 	nbco_ctx *c;
@@ -173,7 +196,8 @@ int kd_select_begin(nbco_ctx *c, int l0);
 int kd_select_level(nbco_ctx *c, int l, long long n, const float4 *pos_in, const int *unsort_in, float4 *pos_out, int *unsort_out,
                     float *lbound, float *rbound, int *splitdim, int *index, int *flag);
 // k_farfield.hip
-int launch_upward_gen(nbco_ctx *c, int P, const float4 *pos, float *center, float *mpole, int *mult, const int *index, int L);
+int launch_upward_gen(nbco_ctx *c, int P, const float4 *pos, float *center, float *mpole, int *mult, const int *index, int L, int write_geom);
+int launch_kd_centres(nbco_ctx *c, float *center, int *mult, int L);
 int launch_downward_gen(nbco_ctx *c, int P, const float *center, float *local, int L, int dom_d, int dom_g);
 int launch_m2m_top_gen(nbco_ctx *c, int P, float *center, float *mpole, int *mult, int ltop);
 int launch_l2p_gen(nbco_ctx *c, int P, const float4 *pos, const float *center, const float *local, const float4 *near, const int *chunk_off,
