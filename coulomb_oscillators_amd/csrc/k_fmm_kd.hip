@@ -1443,6 +1443,31 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 			else
 				NBCO_HIP(hipMemsetAsync(c->m2l_start.ptr, 0, sizeof(int) * (size_t)(ntot + 2), c->stream));
 		}
+		// ... and the far field follows it there: M2L + L2L (aux) overlap the P2P list chain and the start of P2P
+		{
+			StreamScope on_aux(c, c->aux);
+			{
+				PhaseScope ph(c, NBCO_PH_M2L);
+				if (P <= 8)
+				{
+					// register-resident generated bodies, one interaction per lane (k_m2l.hip)
+					NBCO_HIP(hipMemsetAsync(tv.local, 0, sizeof(float) * (size_t)ntot * offL, c->stream));
+					if (dm2l > 0)
+						NBCO_TRY(launch_m2l_lanes(c, P, tv.csz, tv.mpole, tv.local, c->m2l_keys_alt.as<uint64_t>(), c->m2l_start.as<int>(), shift, ntot));
+				}
+				else
+					hipLaunchKernelGGL(m2l_kernel, dim3(ntot), dim3(64), 0, c->stream, tv, tb, (const uint64_t *)c->m2l_keys_alt.as<uint64_t>(),
+					                   (const int *)c->m2l_start.as<int>(), shift, c->o.eps2);
+				NBCO_HIP(hipGetLastError());
+			}
+			{
+				PhaseScope ph(c, NBCO_PH_L2L);
+				if (P <= 8) NBCO_TRY(launch_downward_gen(c, P, tv.center, tv.local, L, dm.d, dm.g));
+				else
+					for (int lc = 2; lc <= L; ++lc) hipLaunchKernelGGL(l2l_kernel, dim3(kd_cnt(lc)), dim3(64), 0, c->stream, tv, tb, lc);
+				NBCO_HIP(hipGetLastError());
+			}
+		}
 		if (dp2p > 0)
 		{
 			unsigned *cp = c->list_cnt.as<unsigned>();
@@ -1490,30 +1515,8 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		else launch_p2p<64>(c, ti, tm, pos, pd, pc, pt, max_chunks, mlt_max, mlt_max, near);
 		NBCO_HIP(hipGetLastError());
 	}
-	// ---- M2L, L2L ---------------------------------------------------------------------------------------
-	NBCO_TRY(c->join_aux());   // multipoles and the M2L list are complete
-	{
-		PhaseScope ph(c, NBCO_PH_M2L);
-		if (P <= 8)
-		{
-			// register-resident generated bodies, one interaction per lane (k_m2l.hip)
-			NBCO_HIP(hipMemsetAsync(tv.local, 0, sizeof(float) * (size_t)ntot * offL, st));
-			if (dm2l > 0)
-				NBCO_TRY(launch_m2l_lanes(c, P, tv.csz, tv.mpole, tv.local, c->m2l_keys_alt.as<uint64_t>(), c->m2l_start.as<int>(), shift, ntot));
-		}
-		else
-			hipLaunchKernelGGL(m2l_kernel, dim3(ntot), dim3(64), 0, st, tv, tb, (const uint64_t *)c->m2l_keys_alt.as<uint64_t>(),
-			                   (const int *)c->m2l_start.as<int>(), shift, c->o.eps2);
-		NBCO_HIP(hipGetLastError());
-	}
-	{
-		PhaseScope ph(c, NBCO_PH_L2L);
-		if (P <= 8) NBCO_TRY(launch_downward_gen(c, P, tv.center, tv.local, L, dm.d, dm.g));
-		else
-			for (int lc = 2; lc <= L; ++lc) hipLaunchKernelGGL(l2l_kernel, dim3(kd_cnt(lc)), dim3(64), 0, st, tv, tb, lc);
-		NBCO_HIP(hipGetLastError());
-	}
 	// ---- L2P + rescale + (un)sort -------------------------------------------------------------------------
+	NBCO_TRY(c->join_aux());   // far field (multipoles, M2L list, M2L, L2L) complete
 	{
 		PhaseScope ph(c, NBCO_PH_L2P);
 		size_t lds = (288 + (size_t)std::max(offM, 1) * 64) * sizeof(float);
