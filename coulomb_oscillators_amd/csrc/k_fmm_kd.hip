@@ -118,6 +118,7 @@ __device__ inline uint32_t ordered_bits(float f)
 	uint32_t u = __float_as_uint(f);
 	return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
+__device__ inline float unordered_bits(uint32_t o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o); }
 
 __global__ void kd_root_kernel(TreeView t, const float *__restrict__ minmax6)   // fmm_cart3_kdtree.cuh:89-97
 {
@@ -279,19 +280,32 @@ __device__ inline bool kd_admissible(const float4 c1, const float4 c2, int n1, i
 constexpr int kSubS = 4096;      // particles per subtree slice (LDS: 32 KB keys + 48 KB xyz + 16 KB permutation + 4 KB split dims)
 constexpr int kSubT = 1024;      // threads per workgroup
 constexpr int kSubE = kSubS / kSubT;
+constexpr int kSelSeg = 256;     // segments up to this size are sorted in one wave's registers; larger ones are split by selection
+constexpr int kSelNodes = kSubS / (2 * kSelSeg) * 2;   // nodes of the first level whose segments are kSelSeg long (16)
+constexpr int kSubTieCap = 64;   // pivot ties resolved per node; more -> flag, the caller falls back to the sorting build
+struct SubSel
+{
+	uint32_t prefix, minR;
+	int rank, neq, cntL, cntR, ntie;
+};
 
 __device__ inline float ld_agent(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline void st_agent(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const float4 *__restrict__ pos_in, const int *__restrict__ unsort_in,
                                                            float4 *__restrict__ pos_out, int *__restrict__ unsort_out, long long n, int l0,
-                                                           int canon)
+                                                           int canon, int *__restrict__ flag)
 {
 	__shared__ uint64_t keys[kSubS];
 	__shared__ int prio[3];
 	__shared__ float px[kSubS], py[kSubS], pz[kSubS];
 	__shared__ int orig[kSubS];
 	__shared__ unsigned char sdl[kSubS];   // split dimension of the current level's nodes of this subtree
+	// in-LDS selection levels (segments > kSelSeg): per node select state, tie lists and ancestor axes
+	__shared__ SubSel sel[kSelNodes];
+	__shared__ int tie_idx[kSelNodes][kSubTieCap];
+	__shared__ signed char anc[kSelNodes][3];      // distinct split axes of a node's ancestors, most recent first (-1: none)
+	__shared__ signed char anc_next[kSelNodes][3];
 	const int tid = threadIdx.x;
 	const long long j0 = blockIdx.x, m0 = 1LL << l0;
 	const long long s0 = (j0 == 0) ? 0 : (n * j0 - 1) / m0 + 1;
@@ -317,6 +331,7 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 			if (a != b[0] && a != b[1]) b[nb++] = a;
 		}
 		prio[0] = b[0]; prio[1] = b[1]; prio[2] = b[2];
+		anc[0][0] = (signed char)b[0]; anc[0][1] = (signed char)b[1]; anc[0][2] = (signed char)b[2];
 	}
 	__syncthreads();
 
@@ -425,32 +440,42 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 	};
 	auto coord = [&](int i, int a) { return a == 0 ? px[i] : (a == 1 ? py[i] : pz[i]); };
 
-	if (canon && l0 > 0)
-	{
-		// The selection passes above this level deliver the right particle SET in arbitrary order.  Put it
-		// into the order the reference's stable-sort chain would have left it in: by the parent's split
-		// coordinate, ties by the next distinct ancestor axes, then by original index.
-		const int b1 = prio[0], b2 = prio[1], b3 = prio[2];
+	// order (u before v) of two slice elements under the keys the stable-sort chain has applied so far: the ancestors'
+	// split coordinates, most recent first, then the original index
+	auto chain_less = [&](int u, int v, int b1, int b2, int b3) {
+		if (b1 >= 0) { const uint32_t a = ordered_bits(coord(u, b1)), b = ordered_bits(coord(v, b1)); if (a != b) return a < b; }
+		if (b2 >= 0) { const uint32_t a = ordered_bits(coord(u, b2)), b = ordered_bits(coord(v, b2)); if (a != b) return a < b; }
+		if (b3 >= 0) { const uint32_t a = ordered_bits(coord(u, b3)), b = ordered_bits(coord(v, b3)); if (a != b) return a < b; }
+		return orig[u] < orig[v];
+	};
+	// Sort every aligned block of `seg` elements into the order the reference's stable-sort chain would have left it in:
+	// by the parent's split coordinate, ties by the next distinct ancestor axes, then by original index.  anc_of(i)
+	// gives the ancestor axes of the node that element i belongs to.
+	auto canonical_sort = [&](int seg, auto anc_of) {
 		for (int i = tid; i < P2; i += kSubT)
-			keys[i] = i < cnt ? (((uint64_t)ordered_bits(coord(i, b1)) << 12) | (uint64_t)i) : ~0ull;
+		{
+			uint64_t k = ~0ull;
+			if (i < cnt)
+			{
+				const int b1 = anc_of(i, 0);
+				k = ((uint64_t)(i / seg) << 44) | ((uint64_t)(b1 >= 0 ? ordered_bits(coord(i, b1)) : 0u) << 12) | (uint64_t)i;
+			}
+			keys[i] = k;
+		}
 		__syncthreads();
-		bitonic(P2);
+		bitonic(seg);
 		permute();
 		for (int i = tid; i + 1 < cnt; i += kSubT)
 		{
-			const uint32_t k = ordered_bits(coord(i, b1));
-			if (ordered_bits(coord(i + 1, b1)) != k || (i > 0 && ordered_bits(coord(i - 1, b1)) == k)) continue;
+			const int b1 = anc_of(i, 0), b2 = anc_of(i, 1), b3 = anc_of(i, 2);
+			const int lo = (i / seg) * seg, hi = min(lo + seg, cnt);   // the run must not leave the node
+			const uint32_t k = b1 >= 0 ? ordered_bits(coord(i, b1)) : 0u;
+			auto key1 = [&](int q) { return b1 >= 0 ? ordered_bits(coord(q, b1)) : 0u; };
+			if (i + 1 >= hi || key1(i + 1) != k || (i > lo && key1(i - 1) == k)) continue;
 			int e = i + 1;   // run [i, e] of equal first keys: insertion sort by (b2, b3, original index)
-			while (e + 1 < cnt && ordered_bits(coord(e + 1, b1)) == k) ++e;
-			auto less = [&](int u, int v) {
-				const uint32_t u2 = b2 >= 0 ? ordered_bits(coord(u, b2)) : 0, v2 = b2 >= 0 ? ordered_bits(coord(v, b2)) : 0;
-				if (u2 != v2) return u2 < v2;
-				const uint32_t u3 = b3 >= 0 ? ordered_bits(coord(u, b3)) : 0, v3 = b3 >= 0 ? ordered_bits(coord(v, b3)) : 0;
-				if (u3 != v3) return u3 < v3;
-				return orig[u] < orig[v];
-			};
+			while (e + 1 < hi && key1(e + 1) == k) ++e;
 			for (int u = i + 1; u <= e; ++u)
-				for (int v = u; v > i && less(v, v - 1); --v)
+				for (int v = u; v > i && chain_less(v, v - 1, -1, b2, b3); --v)
 				{
 					float tx = px[v], ty = py[v], tz = pz[v];
 					int to = orig[v];
@@ -459,9 +484,186 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 				}
 		}
 		__syncthreads();
+	};
+
+	int s_begin = 0;   // first sub-level still to be built by sorting
+	const bool by_selection = canon && pow2 && P2 > kSelSeg && (t.L - l0) > 0;
+	if (by_selection)
+	{
+		// ---- levels whose node segments exceed kSelSeg: exact median selection + unordered partition in LDS ----------
+		// (8-bit radix select over the ordered split coordinate, 4 passes; the k smallest go left.  Elements equal
+		// to the pivot are ranked among themselves by the chain order above.)  The canonical order is restored
+		// afterwards, once, when the segments fit a wave.
+		uint32_t *hist = reinterpret_cast<uint32_t *>(keys);   // [nodes][256]
+		const int wv = tid >> 6, lane = tid & 63;
+		int s = 0;
+		for (; (P2 >> s) > kSelSeg && l0 + s < t.L; ++s)
+		{
+			const int l = l0 + s, nodes = 1 << s, seg = P2 >> s, half = seg >> 1, lseg = 31 - __clz(seg);
+			if (tid < nodes) sel[tid] = SubSel{0u, 0xFFFFFFFFu, half, 0, 0, 0, 0};
+			for (int q = tid; q < nodes * 256; q += kSubT) hist[q] = 0;
+			__syncthreads();
+			uint32_t key[kSubE];
+#pragma unroll
+			for (int e = 0; e < kSubE; ++e)
+			{
+				const int i = tid + e * kSubT;
+				key[e] = i < cnt ? ordered_bits(coord(i, sdl[i >> lseg])) : 0u;
+			}
+			for (int pass = 0; pass < 4; ++pass)
+			{
+				const int shift = 24 - 8 * pass;
+#pragma unroll
+				for (int e = 0; e < kSubE; ++e)
+				{
+					const int i = tid + e * kSubT;
+					if (i >= cnt) continue;
+					const int j = i >> lseg;
+					if (pass == 0 || (key[e] >> (shift + 8)) == sel[j].prefix) atomicAdd(&hist[j * 256 + ((key[e] >> shift) & 255u)], 1u);
+				}
+				__syncthreads();
+				if (wv < nodes)
+				{
+					// the wave of node wv: find the bin holding rank r (1-based among the remaining candidates)
+					const int j = wv, r = sel[j].rank;
+					uint32_t cb[4];
+					uint32_t sum = 0;
+#pragma unroll
+					for (int q = 0; q < 4; ++q) { cb[q] = hist[j * 256 + lane * 4 + q]; sum += cb[q]; hist[j * 256 + lane * 4 + q] = 0; }
+					uint32_t incl = sum;
+					for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+					uint32_t before = incl - sum;
+					if ((uint32_t)r > before && (uint32_t)r <= incl)
+					{
+#pragma unroll
+						for (int q = 0; q < 4; ++q)
+						{
+							if ((uint32_t)r > before && (uint32_t)r <= before + cb[q])
+							{
+								sel[j].prefix = (sel[j].prefix << 8) | (uint32_t)(lane * 4 + q);
+								sel[j].rank = r - (int)before;
+								sel[j].neq = (int)cb[q];
+							}
+							before += cb[q];
+						}
+					}
+				}
+				__syncthreads();
+			}
+			// classify: 0 left, 1 right, 2 pivot tie (side decided by its rank among the node's ties)
+			int side[kSubE];
+#pragma unroll
+			for (int e = 0; e < kSubE; ++e)
+			{
+				const int i = tid + e * kSubT;
+				side[e] = 0;
+				if (i >= cnt) continue;
+				const int j = i >> lseg;
+				const uint32_t pv = sel[j].prefix;
+				if (key[e] > pv) side[e] = 1;
+				else if (key[e] == pv && sel[j].rank < sel[j].neq)
+				{
+					side[e] = 2;
+					const int slot = atomicAdd(&sel[j].ntie, 1);
+					if (slot < kSubTieCap) tie_idx[j][slot] = i;
+				}
+			}
+			__syncthreads();
+			float rx[kSubE], ry[kSubE], rz[kSubE];
+			int ro[kSubE], dst[kSubE];
+#pragma unroll
+			for (int e = 0; e < kSubE; ++e)
+			{
+				const int i = tid + e * kSubT;
+				dst[e] = -1;
+				if (i >= cnt) continue;
+				const int j = i >> lseg;
+				if (side[e] == 2)
+				{
+					const int nt = min(sel[j].ntie, kSubTieCap);
+					int rk = 0;
+					for (int q = 0; q < nt; ++q)
+					{
+						const int o = tie_idx[j][q];
+						if (o != i && chain_less(o, i, anc[j][0], anc[j][1], anc[j][2])) ++rk;
+					}
+					side[e] = rk < sel[j].rank ? 0 : 1;
+				}
+				rx[e] = px[i]; ry[e] = py[i]; rz[e] = pz[i]; ro[e] = orig[i];
+				if (side[e] == 0) dst[e] = j * seg + atomicAdd(&sel[j].cntL, 1);
+				else
+				{
+					dst[e] = j * seg + half + atomicAdd(&sel[j].cntR, 1);
+					atomicMin(&sel[j].minR, key[e]);
+				}
+			}
+			__syncthreads();
+			if (tid < nodes && sel[tid].ntie > kSubTieCap) *flag = 1;   // unresolved ties: the host redoes the build by sorting
+#pragma unroll
+			for (int e = 0; e < kSubE; ++e)
+				if (dst[e] >= 0)
+				{
+					// a tie overflow can leave a side over-full; keep the stores inside the slice (the result is discarded)
+					const int d = min(max(dst[e], 0), cnt - 1);
+					px[d] = rx[e]; py[d] = ry[e]; pz[d] = rz[e]; orig[d] = ro[e];
+				}
+			__syncthreads();
+			// evalBox for the children (fmm_cart3_kdtree.cuh:109-137): the left child's upper face is the pivot (its last
+			// particle in sorted order), the right child's lower face its smallest coordinate
+			const long long m = 1LL << l, mc = m << 1, jbase = j0 << s;
+			const int nchild = 2 << s;
+			int sdc = 0;
+			if (tid < nchild)
+			{
+				const int cidx = tid, j = cidx >> 1;
+				const long long jc = (jbase << 1) + cidx;
+				const long long start = (jc == 0) ? 0 : (n * jc - 1) / mc + 1;
+				const int node = kd_beg(l + 1) + (int)jc, parent = (node - 1) >> 1, split = sdl[j];
+				float lb[3], rb[3];
+				for (int a = 0; a < 3; ++a) { lb[a] = ld_agent(&t.lbound[3 * parent + a]); rb[a] = ld_agent(&t.rbound[3 * parent + a]); }
+				if (cidx & 1) lb[split] = unordered_bits(sel[j].minR);
+				else rb[split] = unordered_bits(sel[j].prefix);
+				for (int a = 0; a < 3; ++a) { st_agent(&t.lbound[3 * node + a], lb[a]); st_agent(&t.rbound[3 * node + a], rb[a]); }
+				sdc = longest_axis(rb[0] - lb[0], rb[1] - lb[1], rb[2] - lb[2]);
+				t.splitdim[node] = sdc;
+				t.index[node] = (int)start;
+				// ancestor axes of the child: the parent's split axis first, then the parent's own list without it
+				int na = 0;
+				signed char out[3] = {-1, -1, -1};
+				out[na++] = (signed char)split;
+				for (int q = 0; q < 3 && na < 3; ++q)
+					if (anc[j][q] >= 0 && anc[j][q] != split) out[na++] = anc[j][q];
+				if (cidx < kSelNodes) { anc_next[cidx][0] = out[0]; anc_next[cidx][1] = out[1]; anc_next[cidx][2] = out[2]; }
+			}
+			__syncthreads();
+			if (tid < nchild)
+			{
+				sdl[tid] = (unsigned char)sdc;
+				if (tid < kSelNodes) { anc[tid][0] = anc_next[tid][0]; anc[tid][1] = anc_next[tid][1]; anc[tid][2] = anc_next[tid][2]; }
+			}
+			__syncthreads();
+		}
+		s_begin = s;
+		if (l0 + s_begin < t.L)
+		{
+			const int seg = P2 >> s_begin;   // every remaining node is an aligned block of `seg` elements with its own ancestors
+			canonical_sort(seg, [&](int i, int q) { return (int)anc[i / seg][q]; });
+		}
+		else
+		{
+			// the selection levels reached the leaves: restore the canonical order inside every leaf
+			const int seg = P2 >> s_begin;
+			canonical_sort(seg, [&](int i, int q) { return (int)anc[i / seg][q]; });
+		}
+	}
+	else if (canon && l0 > 0)
+	{
+		// The selection passes above this level deliver the right particle SET in arbitrary order: restore the order of
+		// the reference's stable-sort chain for the whole slice.
+		canonical_sort(P2, [&](int, int q) { return prio[q]; });
 	}
 
-	for (int l = l0; l < t.L; ++l)
+	for (int l = l0 + s_begin; l < t.L; ++l)
 	{
 		const int s = l - l0;                     // sub-level
 		const long long m = 1LL << l;
@@ -1306,7 +1508,7 @@ static int kd_build_upward(nbco_ctx *c, const float *p, long long n, int L, cons
 			NBCO_TRY(kd_build_top(c, tv, pos, pos_alt, unsort, unsort_alt, n, l0, use_select));
 			// the rest of every level-l0 subtree inside one workgroup's LDS
 			hipLaunchKernelGGL(kd_subtree_kernel, dim3(kd_cnt(l0)), dim3(kSubT), 0, st, tv, (const float4 *)pos, (const int *)unsort, pos_alt, unsort_alt, n, l0,
-			                   use_select ? 1 : 0);
+			                   use_select ? 1 : 0, c->counters.as<int>() + 110);
 			std::swap(pos, pos_alt);
 			std::swap(unsort, unsort_alt);
 			NBCO_HIP(hipGetLastError());
