@@ -280,8 +280,8 @@ __device__ inline bool kd_admissible(const float4 c1, const float4 c2, int n1, i
 constexpr int kSubS = 4096;      // particles per subtree slice (LDS: 32 KB keys + 48 KB xyz + 16 KB permutation + 4 KB split dims)
 constexpr int kSubT = 1024;      // threads per workgroup
 constexpr int kSubE = kSubS / kSubT;
-constexpr int kSelSeg = 256;     // segments up to this size are sorted in one wave's registers; larger ones are split by selection
-constexpr int kSelNodes = kSubS / (2 * kSelSeg) * 2;   // nodes of the first level whose segments are kSelSeg long (16)
+constexpr int kSelSeg = 32;      // segments up to this size are sorted in a wave's registers; larger ones are split by selection
+constexpr int kSelNodes = kSubS / kSelSeg;   // nodes of the first level whose segments are kSelSeg long (128)
 constexpr int kSubTieCap = 64;   // pivot ties resolved per node; more -> flag, the caller falls back to the sorting build
 struct SubSel
 {
@@ -302,10 +302,14 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 	__shared__ int orig[kSubS];
 	__shared__ unsigned char sdl[kSubS];   // split dimension of the current level's nodes of this subtree
 	// in-LDS selection levels (segments > kSelSeg): per node select state, tie lists and ancestor axes
-	__shared__ SubSel sel[kSelNodes];
-	__shared__ int tie_idx[kSelNodes][kSubTieCap];
+	__shared__ SubSel sel[kSelNodes / 2];                 // nodes that are split (their children number up to kSelNodes)
+	__shared__ int tie_idx[kSelNodes / 2][kSubTieCap];
 	__shared__ signed char anc[kSelNodes][3];      // distinct split axes of a node's ancestors, most recent first (-1: none)
 	__shared__ signed char anc_next[kSelNodes][3];
+	// selection keys are normalised to the node's box along its split axis (subtract the lower face, shift the span up to
+	// bit 31): order preserving, and the FIRST radix digit spreads over all bins instead of hammering one LDS counter
+	__shared__ uint32_t wmin[kSelNodes], wmin_next[kSelNodes];
+	__shared__ int wshl[kSelNodes], wshl_next[kSelNodes];
 	const int tid = threadIdx.x;
 	const long long j0 = blockIdx.x, m0 = 1LL << l0;
 	const long long s0 = (j0 == 0) ? 0 : (n * j0 - 1) / m0 + 1;
@@ -332,6 +336,9 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 		}
 		prio[0] = b[0]; prio[1] = b[1]; prio[2] = b[2];
 		anc[0][0] = (signed char)b[0]; anc[0][1] = (signed char)b[1]; anc[0][2] = (signed char)b[2];
+		const int root = kd_beg(l0) + (int)j0, a = t.splitdim[root];
+		const uint32_t lo = ordered_bits(t.lbound[3 * root + a]), span = ordered_bits(t.rbound[3 * root + a]) - lo;
+		wmin[0] = lo; wshl[0] = span ? __clz(span) : 0;
 	}
 	__syncthreads();
 
@@ -500,36 +507,45 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 		for (; (P2 >> s) > kSelSeg && l0 + s < t.L; ++s)
 		{
 			const int l = l0 + s, nodes = 1 << s, seg = P2 >> s, half = seg >> 1, lseg = 31 - __clz(seg);
+			// radix digits of 8 bits (4 passes) while the histograms of all nodes fit the 32 KB key buffer, 7 bits (5 passes) below
+			const int db = nodes <= 32 ? 8 : 7, bins = 1 << db, npass = (32 + db - 1) / db;
 			if (tid < nodes) sel[tid] = SubSel{0u, 0xFFFFFFFFu, half, 0, 0, 0, 0};
-			for (int q = tid; q < nodes * 256; q += kSubT) hist[q] = 0;
+			for (int q = tid; q < nodes * bins; q += kSubT) hist[q] = 0;
 			__syncthreads();
 			uint32_t key[kSubE];
 #pragma unroll
 			for (int e = 0; e < kSubE; ++e)
 			{
 				const int i = tid + e * kSubT;
-				key[e] = i < cnt ? ordered_bits(coord(i, sdl[i >> lseg])) : 0u;
+				const int j = i >> lseg;
+				key[e] = i < cnt ? (ordered_bits(coord(i, sdl[j])) - wmin[j]) << wshl[j] : 0u;
 			}
-			for (int pass = 0; pass < 4; ++pass)
+			for (int pass = 0; pass < npass; ++pass)
 			{
-				const int shift = 24 - 8 * pass;
+				const int hi = 32 - db * pass, lo = max(hi - db, 0), wd = hi - lo;
 #pragma unroll
 				for (int e = 0; e < kSubE; ++e)
 				{
 					const int i = tid + e * kSubT;
 					if (i >= cnt) continue;
 					const int j = i >> lseg;
-					if (pass == 0 || (key[e] >> (shift + 8)) == sel[j].prefix) atomicAdd(&hist[j * 256 + ((key[e] >> shift) & 255u)], 1u);
+					if (pass == 0 || (key[e] >> hi) == sel[j].prefix) atomicAdd(&hist[j * bins + ((key[e] >> lo) & ((1u << wd) - 1u))], 1u);
 				}
 				__syncthreads();
-				if (wv < nodes)
+				for (int j = wv; j < nodes; j += kSubT / 64)
 				{
-					// the wave of node wv: find the bin holding rank r (1-based among the remaining candidates)
-					const int j = wv, r = sel[j].rank;
+					// one wave per node: find the bin holding rank r (1-based among the remaining candidates)
+					const int r = sel[j].rank;
 					uint32_t cb[4];
 					uint32_t sum = 0;
 #pragma unroll
-					for (int q = 0; q < 4; ++q) { cb[q] = hist[j * 256 + lane * 4 + q]; sum += cb[q]; hist[j * 256 + lane * 4 + q] = 0; }
+					for (int q = 0; q < 4; ++q)
+					{
+						const int bin = lane * 4 + q;
+						cb[q] = bin < bins ? hist[j * bins + bin] : 0u;
+						if (bin < bins) hist[j * bins + bin] = 0;
+						sum += cb[q];
+					}
 					uint32_t incl = sum;
 					for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o); if (lane >= o) incl += y; }
 					uint32_t before = incl - sum;
@@ -540,7 +556,7 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 						{
 							if ((uint32_t)r > before && (uint32_t)r <= before + cb[q])
 							{
-								sel[j].prefix = (sel[j].prefix << 8) | (uint32_t)(lane * 4 + q);
+								sel[j].prefix = (sel[j].prefix << wd) | (uint32_t)(lane * 4 + q);
 								sel[j].rank = r - (int)before;
 								sel[j].neq = (int)cb[q];
 							}
@@ -590,12 +606,28 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 					side[e] = rk < sel[j].rank ? 0 : 1;
 				}
 				rx[e] = px[i]; ry[e] = py[i]; rz[e] = pz[i]; ro[e] = orig[i];
-				if (side[e] == 0) dst[e] = j * seg + atomicAdd(&sel[j].cntL, 1);
-				else
+			}
+			// slots: the 64 lanes of a wave hold consecutive elements of ONE node (segments are >= 64 long), so one LDS atomic
+			// per wave and side reserves the slots and a ballot prefix hands them out
+#pragma unroll
+			for (int e = 0; e < kSubE; ++e)
+			{
+				const int i = tid + e * kSubT;
+				const bool on = i < cnt;
+				const int j = on ? (i >> lseg) : 0;
+				const uint64_t mL = __ballot(on && side[e] == 0), mR = __ballot(on && side[e] != 0);
+				const uint64_t below = (1ull << lane) - 1ull;
+				int baseL = 0, baseR = 0;
+				uint32_t kmin = (on && side[e] != 0) ? key[e] : 0xFFFFFFFFu;
+				for (int o = 32; o > 0; o >>= 1) kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o));
+				const int leader = __ffsll((unsigned long long)(mL | mR)) - 1;
+				if (lane == leader)
 				{
-					dst[e] = j * seg + half + atomicAdd(&sel[j].cntR, 1);
-					atomicMin(&sel[j].minR, key[e]);
+					if (mL) baseL = atomicAdd(&sel[j].cntL, __popcll(mL));
+					if (mR) { baseR = atomicAdd(&sel[j].cntR, __popcll(mR)); atomicMin(&sel[j].minR, kmin); }
 				}
+				if (leader >= 0) { baseL = __shfl(baseL, leader); baseR = __shfl(baseR, leader); }
+				if (on) dst[e] = side[e] == 0 ? j * seg + baseL + __popcll(mL & below) : j * seg + half + baseR + __popcll(mR & below);
 			}
 			__syncthreads();
 			if (tid < nodes && sel[tid].ntie > kSubTieCap) *flag = 1;   // unresolved ties: the host redoes the build by sorting
@@ -621,8 +653,8 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 				const int node = kd_beg(l + 1) + (int)jc, parent = (node - 1) >> 1, split = sdl[j];
 				float lb[3], rb[3];
 				for (int a = 0; a < 3; ++a) { lb[a] = ld_agent(&t.lbound[3 * parent + a]); rb[a] = ld_agent(&t.rbound[3 * parent + a]); }
-				if (cidx & 1) lb[split] = unordered_bits(sel[j].minR);
-				else rb[split] = unordered_bits(sel[j].prefix);
+				if (cidx & 1) lb[split] = unordered_bits((sel[j].minR >> wshl[j]) + wmin[j]);
+				else rb[split] = unordered_bits((sel[j].prefix >> wshl[j]) + wmin[j]);
 				for (int a = 0; a < 3; ++a) { st_agent(&t.lbound[3 * node + a], lb[a]); st_agent(&t.rbound[3 * node + a], rb[a]); }
 				sdc = longest_axis(rb[0] - lb[0], rb[1] - lb[1], rb[2] - lb[2]);
 				t.splitdim[node] = sdc;
@@ -633,28 +665,30 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 				out[na++] = (signed char)split;
 				for (int q = 0; q < 3 && na < 3; ++q)
 					if (anc[j][q] >= 0 && anc[j][q] != split) out[na++] = anc[j][q];
-				if (cidx < kSelNodes) { anc_next[cidx][0] = out[0]; anc_next[cidx][1] = out[1]; anc_next[cidx][2] = out[2]; }
+				if (cidx < kSelNodes)
+				{
+					anc_next[cidx][0] = out[0]; anc_next[cidx][1] = out[1]; anc_next[cidx][2] = out[2];
+					const uint32_t lo = ordered_bits(lb[sdc]), span = ordered_bits(rb[sdc]) - lo;
+					wmin_next[cidx] = lo; wshl_next[cidx] = span ? __clz(span) : 0;
+				}
 			}
 			__syncthreads();
 			if (tid < nchild)
 			{
 				sdl[tid] = (unsigned char)sdc;
-				if (tid < kSelNodes) { anc[tid][0] = anc_next[tid][0]; anc[tid][1] = anc_next[tid][1]; anc[tid][2] = anc_next[tid][2]; }
+				if (tid < kSelNodes)
+				{
+					anc[tid][0] = anc_next[tid][0]; anc[tid][1] = anc_next[tid][1]; anc[tid][2] = anc_next[tid][2];
+					wmin[tid] = wmin_next[tid]; wshl[tid] = wshl_next[tid];
+				}
 			}
 			__syncthreads();
 		}
 		s_begin = s;
-		if (l0 + s_begin < t.L)
-		{
-			const int seg = P2 >> s_begin;   // every remaining node is an aligned block of `seg` elements with its own ancestors
-			canonical_sort(seg, [&](int i, int q) { return (int)anc[i / seg][q]; });
-		}
-		else
-		{
-			// the selection levels reached the leaves: restore the canonical order inside every leaf
-			const int seg = P2 >> s_begin;
-			canonical_sort(seg, [&](int i, int q) { return (int)anc[i / seg][q]; });
-		}
+		// every remaining node (or leaf, if the selection levels reached the bottom) is an aligned block of `seg` elements
+		// with its own ancestors: restore the canonical order inside each
+		const int seg = P2 >> s_begin;
+		canonical_sort(seg, [&](int i, int q) { return (int)anc[i / seg][q]; });
 	}
 	else if (canon && l0 > 0)
 	{
