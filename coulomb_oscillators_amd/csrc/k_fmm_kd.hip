@@ -1032,10 +1032,11 @@ __global__ __launch_bounds__(kBlock) void add_one_kernel(unsigned *__restrict__ 
 	for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) v[i] += 1u;
 }
 
-__global__ __launch_bounds__(kBlock) void list_fill_kernel(const int2 *__restrict__ pairs, long long npairs, int sub, int self0, int nself,
-                                                           int shift, const int *__restrict__ start, unsigned *__restrict__ fill,
-                                                           uint64_t *__restrict__ keys, const Dom dm)
+__global__ __launch_bounds__(kBlock) void list_fill_kernel(const int2 *__restrict__ pairs, const int *__restrict__ npairs_ptr, long long cap, int sub,
+                                                           int self0, int nself, int shift, const int *__restrict__ start,
+                                                           unsigned *__restrict__ fill, uint64_t *__restrict__ keys, const Dom dm)
 {
+	const long long npairs = min((long long)*npairs_ptr, cap);   // the pair count never leaves the device
 	const long long total = npairs + nself;
 	for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock)
 	{
@@ -1418,8 +1419,9 @@ static int sort_keys_u64(nbco_ctx *c, uint64_t *kin, uint64_t *kout, long long n
 
 // directed, per-target sorted list of `pairs` (+ one self entry for each of the targets [self0, self0 + nself)) into
 // keys_out; start[0..T].  cnt[0..T) holds the per-target pair-entry counts accumulated by the traversal, fill[0..T) is zero.
-static int build_directed_list(nbco_ctx *c, const int2 *pairs, long long npairs, int sub, int self0, int nself, int ntargets, int shift,
-                               unsigned *cnt, unsigned *fill, int *start, uint64_t *keys_tmp, uint64_t *keys_out, const Dom dm, DevBuf &scan_tmp)
+static int build_directed_list(nbco_ctx *c, const int2 *pairs, const int *npairs_dev, long long cap, long long npairs_hint, int sub, int self0, int nself,
+                               int ntargets, int shift, unsigned *cnt, unsigned *fill, int *start, uint64_t *keys_tmp, uint64_t *keys_out, const Dom dm,
+                               DevBuf &scan_tmp)
 {
 	hipStream_t st = c->stream;
 	if (nself > 0) hipLaunchKernelGGL(add_one_kernel, dim3(grid1d(nself)), dim3(kBlock), 0, st, cnt + self0, nself);
@@ -1428,8 +1430,8 @@ static int build_directed_list(nbco_ctx *c, const int2 *pairs, long long npairs,
 	NBCO_TRY(c->reserve(scan_tmp, bytes));
 	bytes = scan_tmp.bytes;
 	NBCO_HIP(rocprim::exclusive_scan(scan_tmp.ptr, bytes, (int *)cnt, start, 0, (size_t)(ntargets + 1), rocprim::plus<int>(), st));
-	hipLaunchKernelGGL(list_fill_kernel, dim3(grid1d(npairs + nself)), dim3(kBlock), 0, st, pairs, npairs, sub, self0, nself, shift, (const int *)start,
-	                   fill, keys_tmp, dm);
+	hipLaunchKernelGGL(list_fill_kernel, dim3(grid1d(npairs_hint + nself)), dim3(kBlock), 0, st, pairs, npairs_dev, cap, sub, self0, nself, shift,
+	                   (const int *)start, fill, keys_tmp, dm);
 	hipLaunchKernelGGL(list_segsort_kernel, dim3((ntargets + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, (const int *)start, ntargets,
 	                   (const uint64_t *)keys_tmp, keys_out);
 	NBCO_HIP(hipGetLastError());
@@ -1605,7 +1607,6 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 	c->list_cap = cap;
 
 	// ---- dual tree traversal ----------------------------------------------------------------------------
-	int h_cnt[4] = {0, 0, 0, 0};
 	{
 		PhaseScope ph(c, NBCO_PH_TRAVERSE);
 		AdmTab tab;
@@ -1634,50 +1635,38 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 			std::swap(fa, fb);
 		}
 		NBCO_HIP(hipGetLastError());
-		NBCO_HIP(hipMemcpyAsync(h_cnt, ctr, sizeof(int) * 3, hipMemcpyDeviceToHost, st));
-		NBCO_HIP(hipMemcpyAsync(&h_cnt[3], ctr + 110, sizeof(int), hipMemcpyDeviceToHost, st));
-		NBCO_HIP(hipStreamSynchronize(st));
-		if (h_cnt[3] != 0)
-		{
-			// a node had more pivot ties than the selection build resolves (degenerate coordinates): nothing has
-			// been written to the caller's arrays yet, the caller redoes the evaluation with the sorting build
-			out.sel_overflow = 1;
-			NBCO_TRY(c->join_aux());
-			return NBCO_OK;
-		}
-		if (h_cnt[2] != 0)
-		{
-			NBCO_TRY(c->join_aux());
-			return c->fail(NBCO_ERR_CAPACITY, "dual tree traversal exceeded the list capacity (raise opts.list_factor)");
-		}
+		// counts and flags go to pinned host memory behind the traversal; the host looks at them only after it has
+		// enqueued the rest of the evaluation (every later kernel takes its counts from the device), so the GPU never
+		// waits for a host round trip
+		NBCO_TRY(c->flags_begin());
+		NBCO_HIP(hipMemcpyAsync(c->h_flags, ctr, sizeof(int) * 3, hipMemcpyDeviceToHost, st));
+		NBCO_HIP(hipMemcpyAsync(c->h_flags + 3, ctr + 110, sizeof(int), hipMemcpyDeviceToHost, st));
+		NBCO_HIP(hipEventRecord(c->ev_flags, st));
 	}
-	const long long np2p = h_cnt[0], nm2l = h_cnt[1];
-	out.np2p = np2p; out.nm2l = nm2l;
+	const int *np2p_dev = c->counters.as<int>(), *nm2l_dev = np2p_dev + 1;
 	const int shift = L + 1;
-	// upper bounds of the directed entry counts (exact for a single domain); the exact totals stay on the device
-	const long long dp2p = c->o.coll ? 2 * np2p + nself : 0, dm2l = 2 * nm2l;
-	long long max_chunks = 0;
+	// capacities (the traversal never writes more than `cap` pairs) and launch-size hints from the previous evaluation
+	const long long dp2p_cap = c->o.coll ? 2 * cap + nself : 0, dm2l_cap = 2 * cap;
+	const long long np2p_hint = c->hint_np2p > 0 ? std::min(cap, c->hint_np2p + c->hint_np2p / 4 + 1024) : cap;
+	const long long nm2l_hint = c->hint_nm2l > 0 ? std::min(cap, c->hint_nm2l + c->hint_nm2l / 4 + 1024) : cap;
+	const long long dp2p_hint = 2 * np2p_hint + nself;
+	const long long max_chunks = c->o.coll ? dp2p_cap / kP2PChunk + nself : 0, chunks_hint = dp2p_hint / kP2PChunk + nself;
 	// ---- directed sorted lists --------------------------------------------------------------------------
 	{
 		PhaseScope ph(c, NBCO_PH_LISTS);
-		NBCO_TRY(c->reserve(c->p2p_keys, sizeof(uint64_t) * (size_t)(dp2p + 1)));
-		NBCO_TRY(c->reserve(c->p2p_keys_alt, sizeof(uint64_t) * (size_t)(dp2p + 1)));
-		NBCO_TRY(c->reserve(c->m2l_keys, sizeof(uint64_t) * (size_t)(dm2l + 1)));
-		NBCO_TRY(c->reserve(c->m2l_keys_alt, sizeof(uint64_t) * (size_t)(dm2l + 1)));
+		NBCO_TRY(c->reserve(c->p2p_keys, sizeof(uint64_t) * (size_t)(dp2p_cap + 1)));
+		NBCO_TRY(c->reserve(c->p2p_keys_alt, sizeof(uint64_t) * (size_t)(dp2p_cap + 1)));
+		NBCO_TRY(c->reserve(c->m2l_keys, sizeof(uint64_t) * (size_t)(dm2l_cap + 1)));
+		NBCO_TRY(c->reserve(c->m2l_keys_alt, sizeof(uint64_t) * (size_t)(dm2l_cap + 1)));
 		NBCO_TRY(c->reserve(c->p2p_start, sizeof(int) * (size_t)(nleaf + 2)));
 		NBCO_TRY(c->reserve(c->m2l_start, sizeof(int) * (size_t)(ntot + 2)));
 		// the M2L list does not depend on the P2P list: build it on the second stream (behind the multipole chain)
 		NBCO_TRY(c->fork_aux());
 		{
 			StreamScope on_aux(c, c->aux);
-			if (dm2l > 0)
-			{
-				unsigned *cm = c->list_cnt.as<unsigned>() + 2 * ((size_t)nleaf + 2);
-				NBCO_TRY(build_directed_list(c, c->m2l_list.as<int2>(), nm2l, 0, 0, 0, ntot, shift, cm, cm + ((size_t)ntot + 2), c->m2l_start.as<int>(),
-				                             c->m2l_keys.as<uint64_t>(), c->m2l_keys_alt.as<uint64_t>(), dm, c->scan_tmp_aux));
-			}
-			else
-				NBCO_HIP(hipMemsetAsync(c->m2l_start.ptr, 0, sizeof(int) * (size_t)(ntot + 2), c->stream));
+			unsigned *cm = c->list_cnt.as<unsigned>() + 2 * ((size_t)nleaf + 2);
+			NBCO_TRY(build_directed_list(c, c->m2l_list.as<int2>(), nm2l_dev, cap, nm2l_hint, 0, 0, 0, ntot, shift, cm, cm + ((size_t)ntot + 2),
+			                             c->m2l_start.as<int>(), c->m2l_keys.as<uint64_t>(), c->m2l_keys_alt.as<uint64_t>(), dm, c->scan_tmp_aux));
 		}
 		// ... and the far field follows it there: M2L + L2L (aux) overlap the P2P list chain and the start of P2P
 		{
@@ -1688,8 +1677,7 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 				{
 					// register-resident generated bodies, one interaction per lane (k_m2l.hip)
 					NBCO_HIP(hipMemsetAsync(tv.local, 0, sizeof(float) * (size_t)ntot * offL, c->stream));
-					if (dm2l > 0)
-						NBCO_TRY(launch_m2l_lanes(c, P, tv.csz, tv.mpole, tv.local, c->m2l_keys_alt.as<uint64_t>(), c->m2l_start.as<int>(), shift, ntot));
+					NBCO_TRY(launch_m2l_lanes(c, P, tv.csz, tv.mpole, tv.local, c->m2l_keys_alt.as<uint64_t>(), c->m2l_start.as<int>(), shift, ntot));
 				}
 				else
 					hipLaunchKernelGGL(m2l_kernel, dim3(ntot), dim3(64), 0, c->stream, tv, tb, (const uint64_t *)c->m2l_keys_alt.as<uint64_t>(),
@@ -1704,18 +1692,17 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 				NBCO_HIP(hipGetLastError());
 			}
 		}
-		if (dp2p > 0)
+		if (c->o.coll)
 		{
 			unsigned *cp = c->list_cnt.as<unsigned>();
-			NBCO_TRY(build_directed_list(c, c->p2p_list.as<int2>(), np2p, beg, self0, nself, nleaf, shift, cp, cp + ((size_t)nleaf + 2),
+			NBCO_TRY(build_directed_list(c, c->p2p_list.as<int2>(), np2p_dev, cap, np2p_hint, beg, self0, nself, nleaf, shift, cp, cp + ((size_t)nleaf + 2),
 			                             c->p2p_start.as<int>(), c->p2p_keys.as<uint64_t>(), c->p2p_keys_alt.as<uint64_t>(), dm, c->sort_tmp));
 			const int *total = c->p2p_start.as<int>() + nleaf;
-			hipLaunchKernelGGL(pair_count_kernel, dim3(grid1d(dp2p, 256)), dim3(kBlock), 0, st, tv, (const uint64_t *)c->p2p_keys_alt.as<uint64_t>(),
+			hipLaunchKernelGGL(pair_count_kernel, dim3(grid1d(dp2p_hint, 256)), dim3(kBlock), 0, st, tv, (const uint64_t *)c->p2p_keys_alt.as<uint64_t>(),
 			                   total, shift, (unsigned long long *)(c->counters.as<int>() + 100));
-			hipLaunchKernelGGL(p2p_srcdesc_kernel, dim3(grid1d(dp2p)), dim3(kBlock), 0, st, tv, (const uint64_t *)c->p2p_keys_alt.as<uint64_t>(), total,
+			hipLaunchKernelGGL(p2p_srcdesc_kernel, dim3(grid1d(dp2p_hint)), dim3(kBlock), 0, st, tv, (const uint64_t *)c->p2p_keys_alt.as<uint64_t>(), total,
 			                   shift, c->p2p_keys.as<int2>());
 			// chunked work units: counts -> exclusive scan -> descriptors
-			max_chunks = dp2p / kP2PChunk + nself;
 			NBCO_TRY(c->reserve(c->p2p_chunk_cnt, sizeof(int) * (size_t)(nleaf + 2)));
 			NBCO_TRY(c->reserve(c->p2p_chunk_off, sizeof(int) * (size_t)(nleaf + 2)));
 			NBCO_TRY(c->reserve(c->p2p_chunks, sizeof(int4) * (size_t)max_chunks));
@@ -1736,19 +1723,19 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		NBCO_HIP(hipGetLastError());
 	}
 	// ---- P2P --------------------------------------------------------------------------------------------
-	if (dp2p > 0) NBCO_TRY(c->reserve(c->part, sizeof(float4) * (size_t)max_chunks * (size_t)mlt_max));
+	if (c->o.coll) NBCO_TRY(c->reserve(c->part, sizeof(float4) * (size_t)max_chunks * (size_t)mlt_max));
 	float4 *near = c->part.as<float4>();
-	if (dp2p > 0)
+	if (c->o.coll)
 	{
 		PhaseScope ph(c, NBCO_PH_P2P);
 		const int2 *pd = c->p2p_keys.as<int2>();   // the unsorted key buffer is reused for the descriptors
 		const int4 *pc = c->p2p_chunks.as<int4>();
 		const int *pt = c->p2p_chunk_off.as<int>() + nleaf;   // total number of chunks
 		const int *ti = tv.index + beg, *tm = tv.mult + beg;   // target group = leaf
-		if (mlt_max <= 8) launch_p2p<8>(c, ti, tm, pos, pd, pc, pt, max_chunks, mlt_max, mlt_max, near);
-		else if (mlt_max <= 16) launch_p2p<16>(c, ti, tm, pos, pd, pc, pt, max_chunks, mlt_max, mlt_max, near);
-		else if (mlt_max <= 32) launch_p2p<32>(c, ti, tm, pos, pd, pc, pt, max_chunks, mlt_max, mlt_max, near);
-		else launch_p2p<64>(c, ti, tm, pos, pd, pc, pt, max_chunks, mlt_max, mlt_max, near);
+		if (mlt_max <= 8) launch_p2p<8>(c, ti, tm, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near);
+		else if (mlt_max <= 16) launch_p2p<16>(c, ti, tm, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near);
+		else if (mlt_max <= 32) launch_p2p<32>(c, ti, tm, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near);
+		else launch_p2p<64>(c, ti, tm, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near);
 		NBCO_HIP(hipGetLastError());
 	}
 	// ---- L2P + rescale + (un)sort -------------------------------------------------------------------------
@@ -1758,12 +1745,26 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		size_t lds = (288 + (size_t)std::max(offM, 1) * 64) * sizeof(float);
 		if (P <= 8)
 			NBCO_TRY(launch_l2p_gen(c, P, pos, tv.center, tv.local, near, c->p2p_chunk_off.as<int>(), tv.index, mlt_max, unsort, c->o.unsort ? 1 : 0,
-			                        param, a, dp2p > 0 ? 1 : 0, n, L, own0, own_n));
+			                        param, a, c->o.coll ? 1 : 0, n, L, own0, own_n));
 		else
 			hipLaunchKernelGGL(l2p_kernel, dim3(nleaf), dim3(64), lds, st, tv, tb, (const float4 *)pos, (const float4 *)near,
-			                   (const int *)c->p2p_chunk_off.as<int>(), mlt_max, (const int *)unsort, c->o.unsort ? 1 : 0, param, a, dp2p > 0 ? 1 : 0);
+			                   (const int *)c->p2p_chunk_off.as<int>(), mlt_max, (const int *)unsort, c->o.unsort ? 1 : 0, param, a, c->o.coll ? 1 : 0);
 		NBCO_HIP(hipGetLastError());
 	}
+	// ---- now look at what the traversal reported (long finished: the GPU is busy with the work queued above) ----------
+	NBCO_HIP(hipEventSynchronize(c->ev_flags));
+	const int *h = c->h_flags;
+	if (h[3] != 0)
+	{
+		// a node had more pivot ties than the selection build resolves (degenerate coordinates): everything queued so
+		// far ran on a tree that is not the reference's, but only the acceleration array has been written -- the caller
+		// redoes the evaluation with the sorting build
+		out.sel_overflow = 1;
+		return NBCO_OK;
+	}
+	if (h[2] != 0) return c->fail(NBCO_ERR_CAPACITY, "dual tree traversal exceeded the list capacity (raise opts.list_factor)");
+	out.np2p = h[0]; out.nm2l = h[1];
+	c->hint_np2p = h[0]; c->hint_nm2l = h[1];
 	return NBCO_OK;
 }
 
@@ -1999,7 +2000,7 @@ int kd_dist_local(nbco_ctx *c, float *buf_local, long long n_local, void *nodes_
 	hipLaunchKernelGGL(dist_root6_kernel, dim3(1), dim3(64), 0, st, (const float *)top.lbound, (const float *)top.rbound, (1 << d) - 1 + lay.rank, root6);
 	bool rebuild = false;
 	NBCO_TRY(kd_build_upward(c, buf_local, n_local, lay.L_local, root6, rebuild));
-	if (rebuild && !c->force_sort_build && n_local > kSubS)
+	if (rebuild && !c->force_sort_build)
 	{
 		// A tie overflow of the selection build has to be caught BEFORE the exchange (the other domains are
 		// about to consume these nodes); the retry with the sorting build is purely local.

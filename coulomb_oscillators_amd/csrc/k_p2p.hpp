@@ -49,9 +49,10 @@ __global__ __launch_bounds__(64 * kP2PWaves) void p2p_kernel(const int *__restri
 	// dword is used (a float4-per-source tile is narrowed to ds_read_b96 by hipcc, twice the LDS cycles)
 	__shared__ __attribute__((aligned(16))) float tile_all[kP2PWaves][2][G][3 * TPL];
 	const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane / TPL, li = lane % TPL;
-	const int cid = blockIdx.x * kP2PWaves + wv;
-	if (cid >= *nchunks_total) return;
 	float(*tile)[G][3 * TPL] = tile_all[wv];
+	const int total = *nchunks_total;   // the grid is sized from a host-side estimate: stride over the real count
+	for (int cid = blockIdx.x * kP2PWaves + wv; cid < total; cid += gridDim.x * kP2PWaves)
+	{
 	const int4 ck = chunk[cid];
 	const int it = tgt_index[ck.x], mt = tgt_mult[ck.x];
 	const int nchunk = (src_max + TPL - 1) / TPL;
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(64 * kP2PWaves) void p2p_kernel(const int *__restri
 			az += __shfl_xor(az, o);
 		}
 		if (g == 0 && ti < mt) partial[(size_t)cid * stride + ti] = make_float4(ax, ay, az, 0.f);
+	}
 	}
 }
 

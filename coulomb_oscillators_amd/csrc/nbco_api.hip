@@ -53,6 +53,16 @@ int nbco_ctx::fork_aux()
 	return NBCO_OK;
 }
 
+int nbco_ctx::flags_begin()
+{
+	if (!h_flags)
+	{
+		NBCO_HIP_M(this, hipHostMalloc((void **)&h_flags, 64 * sizeof(int), hipHostMallocDefault));
+		NBCO_HIP_M(this, hipEventCreateWithFlags(&ev_flags, hipEventDisableTiming));
+	}
+	return NBCO_OK;
+}
+
 int nbco_ctx::join_aux()
 {
 	if (!aux_pending) return NBCO_OK;
@@ -136,6 +146,8 @@ int nbco_destroy(nbco_ctx *c)
 	if (c->aux) { hipStreamSynchronize(c->aux); hipStreamDestroy(c->aux); }
 	if (c->ev_fork) hipEventDestroy(c->ev_fork);
 	if (c->ev_join) hipEventDestroy(c->ev_join);
+	if (c->ev_flags) hipEventDestroy(c->ev_flags);
+	if (c->h_flags) hipHostFree(c->h_flags);
 	for (DevBuf *b : bufs)
 		if (b->ptr) hipFree(b->ptr);
 	for (auto &t : c->timers)

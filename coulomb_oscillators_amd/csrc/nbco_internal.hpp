@@ -78,6 +78,11 @@ struct nbco_ctx
 	hipStream_t aux = nullptr;
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	bool aux_pending = false;
+	// traversal counts / flags land in pinned host memory; looked at after the rest of the evaluation is enqueued
+	int *h_flags = nullptr;
+	hipEvent_t ev_flags = nullptr;
+	long long hint_np2p = 0, hint_nm2l = 0;   // list sizes of the previous evaluation (launch-size hints only)
+	int flags_begin();
 	DevBuf scan_tmp_aux;
 	int fork_aux();   // aux waits for everything enqueued on `stream` so far
 	int join_aux();   // `stream` waits for everything enqueued on aux
