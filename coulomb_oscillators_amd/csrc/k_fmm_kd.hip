@@ -1058,9 +1058,24 @@ __global__ __launch_bounds__(kBlock) void list_fill_kernel(const int2 *__restric
 // one wave per target: rank sort of its source range (distinct keys); ranges of up to kSegLds entries are
 // staged in LDS, longer ones (not seen in practice) are ranked straight from global memory
 constexpr int kSegLds = 512;
+constexpr int kP2PChunk = 16;   // source leaves per near-field work unit (see the P2P section)
+// DESC: the list is the P2P list -- also emit the source descriptor (first particle, multiplicity) of every sorted entry
+// and the number of chunks of every target, so the pair kernel does no dependent index -> mult -> position loads
+template <bool DESC>
 __global__ __launch_bounds__(kBlock) void list_segsort_kernel(const int *__restrict__ start, int ntargets, const uint64_t *__restrict__ in,
-                                                              uint64_t *__restrict__ out)
+                                                              uint64_t *__restrict__ out, int shift, const int *__restrict__ leaf_index,
+                                                              const int *__restrict__ leaf_mult, int2 *__restrict__ desc,
+                                                              int *__restrict__ chunk_cnt)
 {
+	const uint64_t smask = (1ull << shift) - 1;
+	auto emit = [&](int slot, uint64_t key) {
+		out[slot] = key;
+		if (DESC)
+		{
+			const int src = (int)(key & smask);
+			desc[slot] = make_int2(leaf_index[src], leaf_mult[src]);
+		}
+	};
 	__shared__ uint64_t stage[kBlock / 64][kSegLds];
 	const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	for (int t = blockIdx.x * (kBlock / 64) + wv; t < ntargets; t += gridDim.x * (kBlock / 64))
@@ -1071,7 +1086,8 @@ __global__ __launch_bounds__(kBlock) void list_segsort_kernel(const int *__restr
 			const uint64_t key = lane < cnt ? in[s + lane] : ~0ull;
 			int rank = 0;
 			for (int q = 0; q < cnt; ++q) rank += __shfl(key, q) < key ? 1 : 0;
-			if (lane < cnt) out[s + rank] = key;
+			if (lane < cnt) emit(s + rank, key);
+			if (DESC && lane == 0) chunk_cnt[t] = (cnt + kP2PChunk - 1) / kP2PChunk;   // leaves of other domains have no entries
 		}
 		else if (cnt <= kSegLds)
 		{
@@ -1082,65 +1098,47 @@ __global__ __launch_bounds__(kBlock) void list_segsort_kernel(const int *__restr
 				const uint64_t key = stage[wv][i];
 				int rank = 0;
 				for (int q = 0; q < cnt; ++q) rank += stage[wv][q] < key ? 1 : 0;
-				out[s + rank] = key;
+				emit(s + rank, key);
 			}
+			if (DESC && lane == 0) chunk_cnt[t] = (cnt + kP2PChunk - 1) / kP2PChunk;
 			wave_lds_sync();
 		}
 		else
+		{
 			for (int i = lane; i < cnt; i += 64)
 			{
 				const uint64_t key = in[s + i];
 				int rank = 0;
 				for (int q = 0; q < cnt; ++q) rank += in[s + q] < key ? 1 : 0;
-				out[s + rank] = key;
+				emit(s + rank, key);
 			}
+			if (DESC && lane == 0) chunk_cnt[t] = (cnt + kP2PChunk - 1) / kP2PChunk;
+		}
 	}
+	if (DESC && blockIdx.x == 0 && threadIdx.x == 0) chunk_cnt[ntargets] = 0;   // closes the exclusive scan
 }
 
 // directed pair interactions = sum over the directed P2P entries of mult[target] * mult[source]
 // (the self entries contribute mult^2), SURVEY 8(d)
-__global__ __launch_bounds__(kBlock) void pair_count_kernel(TreeView t, const uint64_t *__restrict__ keys, const int *__restrict__ count_ptr,
-                                                            int shift, unsigned long long *__restrict__ out)
+__global__ __launch_bounds__(kBlock) void pair_count_kernel(const int *__restrict__ leaf_mult, const uint64_t *__restrict__ keys,
+                                                            const int *__restrict__ count_ptr, int shift, unsigned long long *__restrict__ out)
 {
 	const long long count = *count_ptr;
 	const uint64_t mask = (1ull << shift) - 1;
-	const int beg = kd_beg(t.L);
 	unsigned long long s = 0;
 	for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < count; i += (long long)gridDim.x * kBlock)
-		s += (unsigned long long)t.mult[beg + (int)(keys[i] >> shift)] * (unsigned long long)t.mult[beg + (int)(keys[i] & mask)];
+		s += (unsigned long long)leaf_mult[(int)(keys[i] >> shift)] * (unsigned long long)leaf_mult[(int)(keys[i] & mask)];
 	for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
 	if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
 }
 
 // ---- P2P ---------------------------------------------------------------------------------------------
-// source descriptors of the sorted directed list: first particle and multiplicity of every source leaf,
-// so the pair kernel does no dependent index -> mult -> position loads
-__global__ __launch_bounds__(kBlock) void p2p_srcdesc_kernel(TreeView t, const uint64_t *__restrict__ keys, const int *__restrict__ count_ptr,
-                                                             int shift, int2 *__restrict__ desc)
-{
-	const long long count = *count_ptr;
-	const uint64_t mask = (1ull << shift) - 1;
-	const int beg = kd_beg(t.L);
-	for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < count; i += (long long)gridDim.x * kBlock)
-	{
-		const int src = beg + (int)(keys[i] & mask);
-		desc[i] = make_int2(t.index[src], t.mult[src]);
-	}
-}
-
 // Work units.  The number of source leaves per target leaf is very uneven (Gaussian ball, N = 1M: mean 17,
 // max > 250), so one wave per target leaf leaves a tail as long as the rest of the kernel.  Every
 // target leaf's sorted source range is therefore cut into chunks of at most kP2PChunk entries; a wave
 // evaluates one chunk and stores the partial sums of its 32 targets, and the L2P kernel adds a leaf's
-// chunks in list order (fixed order: still bit-reproducible, still no atomics).
-constexpr int kP2PChunk = 16;
-
-__global__ __launch_bounds__(kBlock) void p2p_chunk_count_kernel(const int *__restrict__ start, int nleaf, int *__restrict__ cnt)
-{
-	for (int i = blockIdx.x * kBlock + threadIdx.x; i <= nleaf; i += gridDim.x * kBlock)
-		cnt[i] = i < nleaf ? (start[i + 1] - start[i] + kP2PChunk - 1) / kP2PChunk : 0;   // leaves of other domains have no entries
-}
-
+// chunks in list order (fixed order: still bit-reproducible, still no atomics).  Source descriptors and chunk
+// counts come out of the per-target sort (list_segsort_kernel<true>).
 __global__ __launch_bounds__(kBlock) void p2p_chunk_fill_kernel(const int *__restrict__ start, const int *__restrict__ off, int nleaf,
                                                                 int4 *__restrict__ chunk)
 {
@@ -1421,7 +1419,8 @@ static int sort_keys_u64(nbco_ctx *c, uint64_t *kin, uint64_t *kout, long long n
 // keys_out; start[0..T].  cnt[0..T) holds the per-target pair-entry counts accumulated by the traversal, fill[0..T) is zero.
 static int build_directed_list(nbco_ctx *c, const int2 *pairs, const int *npairs_dev, long long cap, long long npairs_hint, int sub, int self0, int nself,
                                int ntargets, int shift, unsigned *cnt, unsigned *fill, int *start, uint64_t *keys_tmp, uint64_t *keys_out, const Dom dm,
-                               DevBuf &scan_tmp)
+                               DevBuf &scan_tmp, const int *leaf_index = nullptr, const int *leaf_mult = nullptr, int2 *desc = nullptr,
+                               int *chunk_cnt = nullptr)
 {
 	hipStream_t st = c->stream;
 	if (nself > 0) hipLaunchKernelGGL(add_one_kernel, dim3(grid1d(nself)), dim3(kBlock), 0, st, cnt + self0, nself);
@@ -1432,8 +1431,13 @@ static int build_directed_list(nbco_ctx *c, const int2 *pairs, const int *npairs
 	NBCO_HIP(rocprim::exclusive_scan(scan_tmp.ptr, bytes, (int *)cnt, start, 0, (size_t)(ntargets + 1), rocprim::plus<int>(), st));
 	hipLaunchKernelGGL(list_fill_kernel, dim3(grid1d(npairs_hint + nself)), dim3(kBlock), 0, st, pairs, npairs_dev, cap, sub, self0, nself, shift,
 	                   (const int *)start, fill, keys_tmp, dm);
-	hipLaunchKernelGGL(list_segsort_kernel, dim3((ntargets + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, (const int *)start, ntargets,
-	                   (const uint64_t *)keys_tmp, keys_out);
+	if (desc)
+		hipLaunchKernelGGL(list_segsort_kernel<true>, dim3((ntargets + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, (const int *)start, ntargets,
+		                   (const uint64_t *)keys_tmp, keys_out, shift, leaf_index, leaf_mult, desc, chunk_cnt);
+	else
+		hipLaunchKernelGGL(list_segsort_kernel<false>, dim3((ntargets + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, (const int *)start,
+		                   ntargets, (const uint64_t *)keys_tmp, keys_out, shift, (const int *)nullptr, (const int *)nullptr, (int2 *)nullptr,
+		                   (int *)nullptr);
 	NBCO_HIP(hipGetLastError());
 	return NBCO_OK;
 }
@@ -1660,17 +1664,42 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		NBCO_TRY(c->reserve(c->m2l_keys_alt, sizeof(uint64_t) * (size_t)(dm2l_cap + 1)));
 		NBCO_TRY(c->reserve(c->p2p_start, sizeof(int) * (size_t)(nleaf + 2)));
 		NBCO_TRY(c->reserve(c->m2l_start, sizeof(int) * (size_t)(ntot + 2)));
-		// the M2L list does not depend on the P2P list: build it on the second stream (behind the multipole chain)
-		NBCO_TRY(c->fork_aux());
+		// critical path first (the host needs several microseconds per launch): the P2P list chain on the main stream;
+		// the far-field chain on the second stream only has to wait for the traversal (marked here)
+		NBCO_TRY(c->fork_mark());
+		if (c->o.coll)
+		{
+			unsigned *cp = c->list_cnt.as<unsigned>();
+			NBCO_TRY(c->reserve(c->p2p_desc, sizeof(int2) * (size_t)(dp2p_cap + 1)));
+			NBCO_TRY(c->reserve(c->p2p_chunk_cnt, sizeof(int) * (size_t)(nleaf + 2)));
+			NBCO_TRY(c->reserve(c->p2p_chunk_off, sizeof(int) * (size_t)(nleaf + 2)));
+			NBCO_TRY(c->reserve(c->p2p_chunks, sizeof(int4) * (size_t)max_chunks));
+			NBCO_TRY(build_directed_list(c, c->p2p_list.as<int2>(), np2p_dev, cap, np2p_hint, beg, self0, nself, nleaf, shift, cp, cp + ((size_t)nleaf + 2),
+			                             c->p2p_start.as<int>(), c->p2p_keys.as<uint64_t>(), c->p2p_keys_alt.as<uint64_t>(), dm, c->sort_tmp,
+			                             tv.index + beg, tv.mult + beg, c->p2p_desc.as<int2>(), c->p2p_chunk_cnt.as<int>()));
+			// chunked work units: (counts from the sort) -> exclusive scan -> descriptors
+			{
+				size_t bytes = 0;
+				NBCO_HIP(rocprim::exclusive_scan(nullptr, bytes, c->p2p_chunk_cnt.as<int>(), c->p2p_chunk_off.as<int>(), 0, (size_t)(nleaf + 1),
+				                                 rocprim::plus<int>(), st));
+				NBCO_TRY(c->reserve(c->sort_tmp, bytes));
+				bytes = c->sort_tmp.bytes;
+				NBCO_HIP(rocprim::exclusive_scan(c->sort_tmp.ptr, bytes, c->p2p_chunk_cnt.as<int>(), c->p2p_chunk_off.as<int>(), 0,
+				                                 (size_t)(nleaf + 1), rocprim::plus<int>(), st));
+			}
+			hipLaunchKernelGGL(p2p_chunk_fill_kernel, dim3(grid1d(nleaf)), dim3(kBlock), 0, st, (const int *)c->p2p_start.as<int>(),
+			                   (const int *)c->p2p_chunk_off.as<int>(), nleaf, c->p2p_chunks.as<int4>());
+			// remembered for nbco_kd_get_info (the directed pair count is evaluated on demand)
+			c->pc_mult = tv.mult + beg; c->pc_shift = shift; c->pc_total = c->p2p_start.as<int>() + nleaf;
+		}
+		// the far field does not depend on the P2P list: M2L list, M2L and L2L run on the second stream, behind the
+		// multipole chain, and overlap the P2P list chain and the start of P2P
+		NBCO_TRY(c->fork_wait());
 		{
 			StreamScope on_aux(c, c->aux);
 			unsigned *cm = c->list_cnt.as<unsigned>() + 2 * ((size_t)nleaf + 2);
 			NBCO_TRY(build_directed_list(c, c->m2l_list.as<int2>(), nm2l_dev, cap, nm2l_hint, 0, 0, 0, ntot, shift, cm, cm + ((size_t)ntot + 2),
 			                             c->m2l_start.as<int>(), c->m2l_keys.as<uint64_t>(), c->m2l_keys_alt.as<uint64_t>(), dm, c->scan_tmp_aux));
-		}
-		// ... and the far field follows it there: M2L + L2L (aux) overlap the P2P list chain and the start of P2P
-		{
-			StreamScope on_aux(c, c->aux);
 			{
 				PhaseScope ph(c, NBCO_PH_M2L);
 				if (P <= 8)
@@ -1692,34 +1721,6 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 				NBCO_HIP(hipGetLastError());
 			}
 		}
-		if (c->o.coll)
-		{
-			unsigned *cp = c->list_cnt.as<unsigned>();
-			NBCO_TRY(build_directed_list(c, c->p2p_list.as<int2>(), np2p_dev, cap, np2p_hint, beg, self0, nself, nleaf, shift, cp, cp + ((size_t)nleaf + 2),
-			                             c->p2p_start.as<int>(), c->p2p_keys.as<uint64_t>(), c->p2p_keys_alt.as<uint64_t>(), dm, c->sort_tmp));
-			const int *total = c->p2p_start.as<int>() + nleaf;
-			hipLaunchKernelGGL(pair_count_kernel, dim3(grid1d(dp2p_hint, 256)), dim3(kBlock), 0, st, tv, (const uint64_t *)c->p2p_keys_alt.as<uint64_t>(),
-			                   total, shift, (unsigned long long *)(c->counters.as<int>() + 100));
-			hipLaunchKernelGGL(p2p_srcdesc_kernel, dim3(grid1d(dp2p_hint)), dim3(kBlock), 0, st, tv, (const uint64_t *)c->p2p_keys_alt.as<uint64_t>(), total,
-			                   shift, c->p2p_keys.as<int2>());
-			// chunked work units: counts -> exclusive scan -> descriptors
-			NBCO_TRY(c->reserve(c->p2p_chunk_cnt, sizeof(int) * (size_t)(nleaf + 2)));
-			NBCO_TRY(c->reserve(c->p2p_chunk_off, sizeof(int) * (size_t)(nleaf + 2)));
-			NBCO_TRY(c->reserve(c->p2p_chunks, sizeof(int4) * (size_t)max_chunks));
-			hipLaunchKernelGGL(p2p_chunk_count_kernel, dim3(grid1d(nleaf + 1)), dim3(kBlock), 0, st, (const int *)c->p2p_start.as<int>(), nleaf,
-			                   c->p2p_chunk_cnt.as<int>());
-			{
-				size_t bytes = 0;
-				NBCO_HIP(rocprim::exclusive_scan(nullptr, bytes, c->p2p_chunk_cnt.as<int>(), c->p2p_chunk_off.as<int>(), 0, (size_t)(nleaf + 1),
-				                                 rocprim::plus<int>(), st));
-				NBCO_TRY(c->reserve(c->sort_tmp, bytes));
-				bytes = c->sort_tmp.bytes;
-				NBCO_HIP(rocprim::exclusive_scan(c->sort_tmp.ptr, bytes, c->p2p_chunk_cnt.as<int>(), c->p2p_chunk_off.as<int>(), 0,
-				                                 (size_t)(nleaf + 1), rocprim::plus<int>(), st));
-			}
-			hipLaunchKernelGGL(p2p_chunk_fill_kernel, dim3(grid1d(nleaf)), dim3(kBlock), 0, st, (const int *)c->p2p_start.as<int>(),
-			                   (const int *)c->p2p_chunk_off.as<int>(), nleaf, c->p2p_chunks.as<int4>());
-		}
 		NBCO_HIP(hipGetLastError());
 	}
 	// ---- P2P --------------------------------------------------------------------------------------------
@@ -1728,7 +1729,7 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 	if (c->o.coll)
 	{
 		PhaseScope ph(c, NBCO_PH_P2P);
-		const int2 *pd = c->p2p_keys.as<int2>();   // the unsorted key buffer is reused for the descriptors
+		const int2 *pd = c->p2p_desc.as<int2>();
 		const int4 *pc = c->p2p_chunks.as<int4>();
 		const int *pt = c->p2p_chunk_off.as<int>() + nleaf;   // total number of chunks
 		const int *ti = tv.index + beg, *tm = tv.mult + beg;   // target group = leaf
@@ -2069,6 +2070,22 @@ int kd_dist_finish(nbco_ctx *c, const void *nodes_all, const void *pos_all, floa
 	info.L = L; info.ntot = ntot; info.order = P; info.mlt_max = g.mlt_max; info.n = N;
 	info.p2p_pairs = cnt.np2p; info.m2l_pairs = cnt.nm2l; info.rebuilt = c->dist.rebuilt ? 1 : 0;
 	info.directed_p2p = -1;
+	return NBCO_OK;
+}
+
+// directed pair interactions of the last evaluation (nbco_kd_get_info): sum over the sorted P2P entries
+int kd_count_pairs(nbco_ctx *c, long long *out)
+{
+	if (!c->pc_mult || !c->p2p_keys_alt.ptr) { *out = 0; return NBCO_OK; }
+	unsigned long long *ctr = (unsigned long long *)(c->counters.as<int>() + 100);
+	NBCO_HIP(hipMemsetAsync(ctr, 0, sizeof(unsigned long long), c->stream));
+	hipLaunchKernelGGL(pair_count_kernel, dim3(1024), dim3(kBlock), 0, c->stream, c->pc_mult, (const uint64_t *)c->p2p_keys_alt.as<uint64_t>(), c->pc_total,
+	                   c->pc_shift, ctr);
+	NBCO_HIP(hipGetLastError());
+	unsigned long long v = 0;
+	NBCO_HIP(hipMemcpyAsync(&v, ctr, sizeof v, hipMemcpyDeviceToHost, c->stream));
+	NBCO_HIP(hipStreamSynchronize(c->stream));
+	*out = (long long)v;
 	return NBCO_OK;
 }
 

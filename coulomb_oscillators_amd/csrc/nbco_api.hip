@@ -39,7 +39,7 @@ void nbco_ctx::phase_end(int ph)
 	hipEventRecord(timers[ph].pending.back().second, stream);
 }
 
-int nbco_ctx::fork_aux()
+int nbco_ctx::fork_mark()
 {
 	if (!aux)
 	{
@@ -48,9 +48,20 @@ int nbco_ctx::fork_aux()
 		NBCO_HIP_M(this, hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
 	}
 	NBCO_HIP_M(this, hipEventRecord(ev_fork, stream));
+	return NBCO_OK;
+}
+
+int nbco_ctx::fork_wait()
+{
 	NBCO_HIP_M(this, hipStreamWaitEvent(aux, ev_fork, 0));
 	aux_pending = true;
 	return NBCO_OK;
+}
+
+int nbco_ctx::fork_aux()
+{
+	NBCO_TRY(fork_mark());
+	return fork_wait();
 }
 
 int nbco_ctx::flags_begin()
@@ -142,7 +153,7 @@ int nbco_destroy(nbco_ctx *c)
 	                  &c->unsort, &c->unsort_alt, &c->sort_tmp, &c->treebuf, &c->frontier_a, &c->frontier_b, &c->p2p_list,
 	                  &c->m2l_list, &c->counters, &c->p2p_keys, &c->p2p_keys_alt, &c->m2l_keys, &c->m2l_keys_alt,
 	                  &c->p2p_start, &c->m2l_start, &c->tables, &c->p2p_chunk_cnt, &c->p2p_chunk_off, &c->p2p_chunks, &c->sel_hist, &c->sel_nodes, &c->sel_ties, &c->list_cnt,
-	                  &c->dist_top, &c->dist_tree, &c->oct_tree, &c->oct_groups, &c->scan_tmp_aux};
+	                  &c->dist_top, &c->dist_tree, &c->oct_tree, &c->oct_groups, &c->scan_tmp_aux, &c->p2p_desc};
 	if (c->aux) { hipStreamSynchronize(c->aux); hipStreamDestroy(c->aux); }
 	if (c->ev_fork) hipEventDestroy(c->ev_fork);
 	if (c->ev_join) hipEventDestroy(c->ev_join);
@@ -418,10 +429,9 @@ int nbco_kd_get_info(nbco_ctx *c, nbco_kd_info *info)
 	if (!c || !info) return NBCO_ERR_ARG;
 	if (c->info.directed_p2p < 0 && c->counters.ptr && c->tree_valid)
 	{
-		unsigned long long v = 0;
-		NBCO_HIP(hipStreamSynchronize(c->stream));
-		NBCO_HIP(hipMemcpy(&v, c->counters.as<int>() + 100, sizeof v, hipMemcpyDeviceToHost));
-		c->info.directed_p2p = (long long)v;
+		long long v = 0;
+		NBCO_TRY(kd_count_pairs(c, &v));   // one small kernel over the sorted P2P list of the last evaluation
+		c->info.directed_p2p = v;
 	}
 	*info = c->info;
 	return NBCO_OK;

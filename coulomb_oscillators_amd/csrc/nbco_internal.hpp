@@ -85,6 +85,8 @@ struct nbco_ctx
 	int flags_begin();
 	DevBuf scan_tmp_aux;
 	int fork_aux();   // aux waits for everything enqueued on `stream` so far
+	int fork_mark();  // remember this point of `stream` ...
+	int fork_wait();  // ... and let aux wait for it (called after more work has been enqueued on `stream`)
 	int join_aux();   // `stream` waits for everything enqueued on aux
 	std::string err;
 	int device = 0;
@@ -103,7 +105,9 @@ struct nbco_ctx
 	// traversal and interaction lists
 	DevBuf frontier_a, frontier_b, p2p_list, m2l_list, counters;
 	DevBuf p2p_keys, p2p_keys_alt, m2l_keys, m2l_keys_alt, p2p_start, m2l_start;
-	DevBuf p2p_chunk_cnt, p2p_chunk_off, p2p_chunks;
+	DevBuf p2p_chunk_cnt, p2p_chunk_off, p2p_chunks, p2p_desc;
+	const int *pc_mult = nullptr, *pc_total = nullptr;   // inputs of the on-demand directed pair count
+	int pc_shift = 0;
 	DevBuf list_cnt;
 	DevBuf sel_hist, sel_nodes, sel_ties;   // selection build (k_kdselect.hip)
 	// multi-GPU kd-domain sharding: boxes / split axes of the global levels 0 .. d, the assembled global tree
@@ -188,6 +192,7 @@ int launch_energy(nbco_ctx *c, const float *buf, long long n, const float *param
 // k_fmm_kd.hip
 int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *param);
 int kd_copy_out(nbco_ctx *c, int which, void *host_dst, long long host_bytes);
+int kd_count_pairs(nbco_ctx *c, long long *out);
 // k_fmm_oct.hip
 int fmm_oct_traceless_eval(nbco_ctx *c, float *p, float *a, long long n, const float *param);
 int oct_copy_out(nbco_ctx *c, int which, void *host_dst, long long host_bytes);
