@@ -42,7 +42,8 @@ def parse():
                     help="multi-GPU: force evaluations between two re-partitions of the kd-domains (top log2(G) splits)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL (one rank per GPU); gloo = rehearsal with several ranks sharing one card")
-    ap.add_argument("--workload", default="fmm_kd", choices=["fmm_kd", "direct"])
+    ap.add_argument("--workload", default="fmm_kd", choices=["fmm_kd", "fmm_oct", "direct"],
+                    help="fmm_kd: kd-tree FMM (the nbco3 path, default); fmm_oct: uniform octree with traceless multipoles; direct: O(N^2)")
     ap.add_argument("--dt", type=float, default=5e-4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=6)
@@ -101,7 +102,8 @@ def main():
     args = parse()
     import torch
     import torch.distributed as dist
-    from coulomb_oscillators_amd import Engine, EVAL_DIRECT, EVAL_FMM_KDTREE, INTEG_LEAPFROG, DomainRun, TorchComm
+    from coulomb_oscillators_amd import (Engine, EVAL_DIRECT, EVAL_FMM_KDTREE, EVAL_FMM_TRACELESS, INTEG_LEAPFROG, DomainRun,
+                                         TorchComm)
     from oracle import pyoracle as po          # initial conditions only (reference RNG stream) + cpu_baseline
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,9 +130,9 @@ def main():
     d = torch.from_numpy(buf).cuda()
     prm = torch.from_numpy(par).cuda()
 
-    kind = EVAL_FMM_KDTREE if args.workload == "fmm_kd" else EVAL_DIRECT
+    kind = {"fmm_kd": EVAL_FMM_KDTREE, "fmm_oct": EVAL_FMM_TRACELESS, "direct": EVAL_DIRECT}[args.workload]
     eng = Engine(fmm_order=args.order, unsort=0, tree_steps=args.tree_steps, sync=0)
-    dom = "p2p" if args.workload == "fmm_kd" else "direct"
+    dom = "direct" if args.workload == "direct" else "p2p"
     run = None
     if sharded:
         run = DomainRun(eng, n_sys, TorchComm(), rebalance=args.rebalance)
@@ -177,6 +179,10 @@ def main():
         if sharded:
             extra.update({"n_system": n_sys, "rebalance_every": args.rebalance,
                           "allgather_bytes_per_eval_per_gpu": run.exchange_bytes(), "backend": args.backend})
+    elif args.workload == "fmm_oct":
+        info = eng.oct_info()
+        pairs_per_eval = 0    # the octree path keeps no pair counter: no roofline entry for this workload
+        extra = {"L": info.L, "m2l_entries": int(info.m2l_entries), "p2p_chunks": int(info.p2p_chunks)}
     else:
         pairs_per_eval = n * n
         extra = {}
@@ -201,14 +207,15 @@ def main():
         "gpair_per_s": pairs_all * args.steps / elapsed / 1e9,
         "config": {"workload": ("FMM-3D kd-tree p=%d, N=%d per GPU (one system of %d), leapfrog, Gaussian ball, tree rebuilt every %d step(s)"
                                 % (args.order, n, n_sys, args.tree_steps)) if args.workload == "fmm_kd"
-                   else "direct O(N^2) 3D, N=%d per GPU, leapfrog" % n,
+                   else ("FMM-3D uniform octree, traceless multipoles p=%d, N=%d per GPU, leapfrog, Gaussian ball" % (args.order, n))
+                   if args.workload == "fmm_oct" else "direct O(N^2) 3D, N=%d per GPU, leapfrog" % n,
                    "n_per_gpu": n, "order": args.order, "dt": args.dt,
                    "parallelism": ("kd-domain sharding x%d, one all-gather of nodes + positions per evaluation" % world) if sharded
                    else ("single GPU" if world == 1 else "independent replicas x%d" % world), **extra},
     }
     if rank == 0:
         ms, launches = prof[dom]
-        if launches:
+        if launches and pairs_per_eval:
             avg_s = ms * 1e-3 / launches
             ach = pairs_per_eval * FLOP_PER_PAIR / avg_s / 1e12
             kname = "p2p_kernel" if dom == "p2p" else "direct_tiles"
@@ -221,7 +228,7 @@ def main():
                                "pairs_per_launch": pairs_per_eval, "avg_launch_ms": avg_s * 1e3, "flop_per_pair": FLOP_PER_PAIR}
         if args.profile_all:
             out["phase_ms_per_step"] = {k: v[0] / args.steps for k, v in prof.items() if v[1]}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload != "fmm_oct":
             out["cpu_baseline"] = cpu_baseline(args, n)
         print(json.dumps(out))
     if world > 1:

@@ -43,7 +43,12 @@ int nbco_ctx::fork_mark()
 {
 	if (!aux)
 	{
-		NBCO_HIP_M(this, hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+		// high priority: its kernels are small, latency-bound links of the far-field chain and must not queue up behind
+		// the thousands of workgroups of the near-field kernel running on the main stream
+		int prio_lo = 0, prio_hi = 0;
+		NBCO_HIP_M(this, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+		if (getenv("NBCO_AUX_PRIO") && atoi(getenv("NBCO_AUX_PRIO")) == 0) prio_hi = prio_lo;   // A/B switch (diagnostics)
+		NBCO_HIP_M(this, hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, prio_hi));
 		NBCO_HIP_M(this, hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
 		NBCO_HIP_M(this, hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
 	}
