@@ -894,16 +894,53 @@ __device__ inline int pair_children(int kd, int2 np, int2 ch[3])
 // One launch advances the pair frontier by TWO traversal steps: every thread classifies its pair and,
 // if it splits, classifies the (up to 3) children as well; only grandchildren go back to the frontier.
 // That halves the number of dependent launches of this latency-bound phase.  Output slots are reserved
-// with one packed block scan and three concurrent atomics per block.
+// with one packed block scan and three atomics per block.
+//
+// A returning atomic on ONE address costs ~27 ns on this part (measured), and every workgroup needs one per output
+// list before it can write: with a single counter per list the 1024 workgroups of a launch queue up for ~28 us.
+// The frontier and the two pair lists are therefore kept as kTravK independent regions (capacity cap / kTravK each,
+// workgroup b appends to region b mod kTravK): kTravK short queues instead of one long one.  Readers map a dense
+// index to (region, offset) with the regions' prefix sums.
+constexpr int kTravK = 16;
+constexpr int kTcFrontier = 0;                    // [it][kTravK] sizes of the frontier regions before iteration it (it < 36)
+constexpr int kTcP2P = 36 * kTravK;               // [kTravK] region sizes of the P2P pair list
+constexpr int kTcM2L = kTcP2P + kTravK;           // [kTravK]                    M2L pair list
+constexpr int kTcP2PPref = kTcM2L + kTravK;       // [kTravK + 1] exclusive prefix sums (traverse_finish_kernel)
+constexpr int kTcM2LPref = kTcP2PPref + kTravK + 1;
+constexpr int kTcInts = kTcM2LPref + kTravK + 1;
+
+// dense index -> slot of a region-structured list
+__device__ inline long long region_slot(const int *__restrict__ pref, long long capR, long long i)
+{
+	int r = 0;
+#pragma unroll
+	for (int q = 1; q < kTravK; ++q) r += (i >= pref[q]) ? 1 : 0;
+	return (long long)r * capR + (i - pref[r]);
+}
+
 __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab, const int2 *__restrict__ fin, int2 *__restrict__ fout,
-                                                          int2 *__restrict__ p2p, int2 *__restrict__ m2l, int *__restrict__ counters, int it,
-                                                          long long cap, float par, int m2l_first, unsigned *__restrict__ cnt_p2p,
-                                                          unsigned *__restrict__ cnt_m2l, const Dom dm)
+                                                          int2 *__restrict__ p2p, int2 *__restrict__ m2l, int *__restrict__ counters,
+                                                          int *__restrict__ tctr, int it, long long capR, float par, int m2l_first,
+                                                          unsigned *__restrict__ cnt_p2p, unsigned *__restrict__ cnt_m2l, const Dom dm)
 {
 	__shared__ uint64_t sh_wave[4];
 	__shared__ int sh_base[3];
-	const int nin = counters[4 + it];
+	__shared__ int in_pref[kTravK + 1];
+	if (threadIdx.x < 64)
+	{
+		// prefix sums of the input frontier's region sizes
+		const int lane = threadIdx.x;
+		// (a region that ran over its capacity holds capR valid pairs; the overflow flag is already up)
+		int v = lane < kTravK ? (int)min((long long)tctr[kTcFrontier + it * kTravK + lane], capR) : 0, incl = v;
+		for (int o = 1; o < kTravK; o <<= 1) { const int y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+		if (lane < kTravK) in_pref[lane] = incl - v;
+		if (lane == kTravK - 1) in_pref[kTravK] = incl;
+	}
+	__syncthreads();
+	const int nin = in_pref[kTravK];
 	const int lbeg = kd_beg(t.L);
+	const int rout = (blockIdx.x + 5 * it) & (kTravK - 1);   // rotate, so that a busy part of the frontier does not keep feeding one region
+	const long long obase = (long long)rout * capR;
 	for (long long base = (long long)blockIdx.x * kBlock; base < nin; base += (long long)gridDim.x * kBlock)
 	{
 		const long long i = base + threadIdx.x;
@@ -913,7 +950,7 @@ __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab
 		int nch = 0;
 		if (i < nin)
 		{
-			pr[0] = fin[i];
+			pr[0] = fin[region_slot(in_pref, capR, i)];
 			kd[0] = classify_pair(t, tab, pr[0], par, m2l_first, dm);
 			nch = pair_children(kd[0], pr[0], pr + 1);
 #pragma unroll
@@ -931,12 +968,12 @@ __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab
 		uint64_t tot;
 		const uint64_t off = block_exclusive_scan3(cnt, sh_wave, tot);
 		const int tf = (int)(tot & 0xFFFFF), tp = (int)((tot >> 20) & 0xFFFFF), tm = (int)(tot >> 40);
-		if (threadIdx.x == 0) sh_base[0] = tf ? atomicAdd(&counters[4 + it + 1], tf) : 0;
-		if (threadIdx.x == 64) sh_base[1] = tp ? atomicAdd(&counters[0], tp) : 0;
-		if (threadIdx.x == 128) sh_base[2] = tm ? atomicAdd(&counters[1], tm) : 0;
+		if (threadIdx.x == 0) sh_base[0] = tf ? atomicAdd(&tctr[kTcFrontier + (it + 1) * kTravK + rout], tf) : 0;
+		if (threadIdx.x == 64) sh_base[1] = tp ? atomicAdd(&tctr[kTcP2P + rout], tp) : 0;
+		if (threadIdx.x == 128) sh_base[2] = tm ? atomicAdd(&tctr[kTcM2L + rout], tm) : 0;
 		__syncthreads();
 		long long bf = sh_base[0], bp = sh_base[1], bm = sh_base[2];
-		const bool okf = bf + tf <= cap, okp = bp + tp <= cap, okm = bm + tm <= cap;
+		const bool okf = bf + tf <= capR, okp = bp + tp <= capR, okm = bm + tm <= capR;
 		if (threadIdx.x == 0 && !(okf && okp && okm)) counters[2] = 1;
 		bf += (long long)(off & 0xFFFFF); bp += (long long)((off >> 20) & 0xFFFFF); bm += (long long)(off >> 40);
 #pragma unroll
@@ -950,7 +987,7 @@ __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab
 			{
 				if (okp)
 				{
-					p2p[bp] = np;
+					p2p[obase + bp] = np;
 					if (dm.d == 0 || dom_touch(dm, np.x)) atomicAdd(&cnt_p2p[np.x - lbeg], 1u);
 					if (dm.d == 0 || dom_touch(dm, np.y)) atomicAdd(&cnt_p2p[np.y - lbeg], 1u);
 				}
@@ -960,7 +997,7 @@ __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab
 			{
 				if (okm)
 				{
-					m2l[bm] = np;
+					m2l[obase + bm] = np;
 					if (dm.d == 0 || dom_touch(dm, np.x)) atomicAdd(&cnt_m2l[np.x], 1u);
 					if (dm.d == 0 || dom_touch(dm, np.y)) atomicAdd(&cnt_m2l[np.y], 1u);
 				}
@@ -971,7 +1008,7 @@ __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab
 				int2 ch[3];
 				const int nc = pair_children(q, np, ch);
 				if (okf)
-					for (int e = 0; e < nc; ++e) fout[bf + e] = ch[e];
+					for (int e = 0; e < nc; ++e) fout[obase + bf + e] = ch[e];
 				bf += nc;
 			}
 		}
@@ -979,11 +1016,41 @@ __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab
 	}
 }
 
-__global__ void traverse_init_kernel(int2 *frontier, int *counters, int nctr)
+__global__ void traverse_init_kernel(int2 *frontier, int *counters, int nctr, int *tctr)
 {
 	for (int i = threadIdx.x; i < nctr; i += blockDim.x) counters[i] = 0;
+	for (int i = threadIdx.x; i < kTcInts; i += blockDim.x) tctr[i] = 0;
 	__syncthreads();
-	if (threadIdx.x == 0) { frontier[0] = make_int2(0, 0); counters[4] = 1; }
+	if (threadIdx.x == 0) { frontier[0] = make_int2(0, 0); tctr[kTcFrontier] = 1; }
+}
+
+// region prefix sums and totals of the two pair lists (counters[0] = P2P pairs, counters[1] = M2L pairs).  If a region ran
+// over its capacity (counters[2], reported to the caller as NBCO_ERR_CAPACITY once the host looks at the flags) the
+// lists are declared empty and the per-target counts cleared, so that everything already queued behind the traversal
+// runs on a consistent -- if useless -- state.
+__global__ __launch_bounds__(1024) void traverse_finish_kernel(int *counters, int *tctr, long long capR, unsigned *cnt_all, long long ncnt)
+{
+	const int lane = threadIdx.x;
+	const bool overflow = counters[2] != 0;
+	if (overflow)
+		for (long long i = threadIdx.x; i < ncnt; i += blockDim.x) cnt_all[i] = 0u;
+	if (lane >= 64) return;
+	for (int which = 0; which < 2; ++which)
+	{
+		const int src = which ? kTcM2L : kTcP2P, dst = which ? kTcM2LPref : kTcP2PPref;
+		int v = (lane < kTravK && !overflow) ? tctr[src + lane] : 0, incl = v;
+		for (int o = 1; o < kTravK; o <<= 1) { const int y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+		if (lane < kTravK) tctr[dst + lane] = incl - v;
+		if (lane == kTravK - 1) { tctr[dst + kTravK] = incl; counters[which] = incl; }
+	}
+}
+
+// dense copy of a region-structured pair list (nbco_kd_copy)
+__global__ __launch_bounds__(kBlock) void list_compact_kernel(const int2 *__restrict__ src, const int *__restrict__ pref, long long capR,
+                                                              int2 *__restrict__ dst)
+{
+	const long long n = pref[kTravK];
+	for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) dst[i] = src[region_slot(pref, capR, i)];
 }
 
 // ---- directed, sorted interaction lists ------------------------------------------------------------
@@ -1032,17 +1099,17 @@ __global__ __launch_bounds__(kBlock) void add_one_kernel(unsigned *__restrict__ 
 	for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) v[i] += 1u;
 }
 
-__global__ __launch_bounds__(kBlock) void list_fill_kernel(const int2 *__restrict__ pairs, const int *__restrict__ npairs_ptr, long long cap, int sub,
+__global__ __launch_bounds__(kBlock) void list_fill_kernel(const int2 *__restrict__ pairs, const int *__restrict__ pref, long long capR, int sub,
                                                            int self0, int nself, int shift, const int *__restrict__ start,
                                                            unsigned *__restrict__ fill, uint64_t *__restrict__ keys, const Dom dm)
 {
-	const long long npairs = min((long long)*npairs_ptr, cap);   // the pair count never leaves the device
+	const long long npairs = pref[kTravK];   // the pair count never leaves the device (regions are clamped to their capacity)
 	const long long total = npairs + nself;
 	for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock)
 	{
 		if (i < npairs)
 		{
-			const int2 p = pairs[i];
+			const int2 p = pairs[region_slot(pref, capR, i)];
 			const uint64_t a = (uint64_t)(p.x - sub), b = (uint64_t)(p.y - sub);
 			if (dm.d == 0 || dom_touch(dm, p.x)) keys[start[a] + atomicAdd(&fill[a], 1u)] = (a << shift) | b;
 			if (dm.d == 0 || dom_touch(dm, p.y)) keys[start[b] + atomicAdd(&fill[b], 1u)] = (b << shift) | a;
@@ -1417,7 +1484,7 @@ static int sort_keys_u64(nbco_ctx *c, uint64_t *kin, uint64_t *kout, long long n
 
 // directed, per-target sorted list of `pairs` (+ one self entry for each of the targets [self0, self0 + nself)) into
 // keys_out; start[0..T].  cnt[0..T) holds the per-target pair-entry counts accumulated by the traversal, fill[0..T) is zero.
-static int build_directed_list(nbco_ctx *c, const int2 *pairs, const int *npairs_dev, long long cap, long long npairs_hint, int sub, int self0, int nself,
+static int build_directed_list(nbco_ctx *c, const int2 *pairs, const int *pref_dev, long long capR, long long npairs_hint, int sub, int self0, int nself,
                                int ntargets, int shift, unsigned *cnt, unsigned *fill, int *start, uint64_t *keys_tmp, uint64_t *keys_out, const Dom dm,
                                DevBuf &scan_tmp, const int *leaf_index = nullptr, const int *leaf_mult = nullptr, int2 *desc = nullptr,
                                int *chunk_cnt = nullptr)
@@ -1429,7 +1496,7 @@ static int build_directed_list(nbco_ctx *c, const int2 *pairs, const int *npairs
 	NBCO_TRY(c->reserve(scan_tmp, bytes));
 	bytes = scan_tmp.bytes;
 	NBCO_HIP(rocprim::exclusive_scan(scan_tmp.ptr, bytes, (int *)cnt, start, 0, (size_t)(ntargets + 1), rocprim::plus<int>(), st));
-	hipLaunchKernelGGL(list_fill_kernel, dim3(grid1d(npairs_hint + nself)), dim3(kBlock), 0, st, pairs, npairs_dev, cap, sub, self0, nself, shift,
+	hipLaunchKernelGGL(list_fill_kernel, dim3(grid1d(npairs_hint + nself)), dim3(kBlock), 0, st, pairs, pref_dev, capR, sub, self0, nself, shift,
 	                   (const int *)start, fill, keys_tmp, dm);
 	if (desc)
 		hipLaunchKernelGGL(list_segsort_kernel<true>, dim3((ntargets + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, (const int *)start, ntargets,
@@ -1602,7 +1669,9 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 	hipStream_t st = c->stream;
 	if (dm.d > 0 && P > 8) return c->fail(NBCO_ERR_UNSUPPORTED, "kd-domain sharding needs the generated operators (fmm_order <= 8)");
 
-	const long long cap = (long long)c->o.list_factor * ntot + 4096;
+	// capacity of the frontier and of the two pair lists, split into kTravK regions
+	// (regions fill unevenly: each gets twice its share of list_factor * ntot pairs)
+	const long long capR = 2 * (((long long)c->o.list_factor * ntot + 4096 + kTravK - 1) / kTravK), cap = capR * kTravK;
 	NBCO_TRY(c->reserve(c->frontier_a, sizeof(int2) * (size_t)cap));
 	NBCO_TRY(c->reserve(c->frontier_b, sizeof(int2) * (size_t)cap));
 	NBCO_TRY(c->reserve(c->p2p_list, sizeof(int2) * (size_t)cap));
@@ -1630,14 +1699,18 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		NBCO_TRY(c->reserve(c->list_cnt, sizeof(unsigned) * 2 * (np_ + nm_)));
 		NBCO_HIP(hipMemsetAsync(c->list_cnt.ptr, 0, sizeof(unsigned) * 2 * (np_ + nm_), st));
 		unsigned *cnt_p2p = c->list_cnt.as<unsigned>(), *cnt_m2l = cnt_p2p + 2 * np_;
-		hipLaunchKernelGGL(traverse_init_kernel, dim3(1), dim3(128), 0, st, fa, ctr, 104);   // [110] is the selection-build flag
+		NBCO_TRY(c->reserve(c->trav_ctr, sizeof(int) * 1024));
+		static_assert(kTcInts <= 1024, "traversal counter block");
+		int *tctr = c->trav_ctr.as<int>();
+		hipLaunchKernelGGL(traverse_init_kernel, dim3(1), dim3(128), 0, st, fa, ctr, 104, tctr);   // [110] is the selection-build flag
 		const int iters = L + 2;   // every launch performs two traversal steps (2L + 1 are needed)
 		for (int it = 0; it < iters; ++it)
 		{
 			hipLaunchKernelGGL(traverse_kernel, dim3(1024), dim3(kBlock), 0, st, tv, tab, (const int2 *)fa, fb, c->p2p_list.as<int2>(),
-			                   c->m2l_list.as<int2>(), ctr, it, cap, c->o.tree_radius, c->o.m2l_first, cnt_p2p, cnt_m2l, dm);
+			                   c->m2l_list.as<int2>(), ctr, tctr, it, capR, c->o.tree_radius, c->o.m2l_first, cnt_p2p, cnt_m2l, dm);
 			std::swap(fa, fb);
 		}
+		hipLaunchKernelGGL(traverse_finish_kernel, dim3(1), dim3(1024), 0, st, ctr, tctr, capR, c->list_cnt.as<unsigned>(), (long long)(2 * (np_ + nm_)));
 		NBCO_HIP(hipGetLastError());
 		// counts and flags go to pinned host memory behind the traversal; the host looks at them only after it has
 		// enqueued the rest of the evaluation (every later kernel takes its counts from the device), so the GPU never
@@ -1647,7 +1720,7 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		NBCO_HIP(hipMemcpyAsync(c->h_flags + 3, ctr + 110, sizeof(int), hipMemcpyDeviceToHost, st));
 		NBCO_HIP(hipEventRecord(c->ev_flags, st));
 	}
-	const int *np2p_dev = c->counters.as<int>(), *nm2l_dev = np2p_dev + 1;
+	const int *p2p_pref = c->trav_ctr.as<int>() + kTcP2PPref, *m2l_pref = c->trav_ctr.as<int>() + kTcM2LPref;
 	const int shift = L + 1;
 	// capacities (the traversal never writes more than `cap` pairs) and launch-size hints from the previous evaluation
 	const long long dp2p_cap = c->o.coll ? 2 * cap + nself : 0, dm2l_cap = 2 * cap;
@@ -1674,7 +1747,7 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 			NBCO_TRY(c->reserve(c->p2p_chunk_cnt, sizeof(int) * (size_t)(nleaf + 2)));
 			NBCO_TRY(c->reserve(c->p2p_chunk_off, sizeof(int) * (size_t)(nleaf + 2)));
 			NBCO_TRY(c->reserve(c->p2p_chunks, sizeof(int4) * (size_t)max_chunks));
-			NBCO_TRY(build_directed_list(c, c->p2p_list.as<int2>(), np2p_dev, cap, np2p_hint, beg, self0, nself, nleaf, shift, cp, cp + ((size_t)nleaf + 2),
+			NBCO_TRY(build_directed_list(c, c->p2p_list.as<int2>(), p2p_pref, capR, np2p_hint, beg, self0, nself, nleaf, shift, cp, cp + ((size_t)nleaf + 2),
 			                             c->p2p_start.as<int>(), c->p2p_keys.as<uint64_t>(), c->p2p_keys_alt.as<uint64_t>(), dm, c->sort_tmp,
 			                             tv.index + beg, tv.mult + beg, c->p2p_desc.as<int2>(), c->p2p_chunk_cnt.as<int>()));
 			// chunked work units: (counts from the sort) -> exclusive scan -> descriptors
@@ -1698,7 +1771,7 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		{
 			StreamScope on_aux(c, c->aux);
 			unsigned *cm = c->list_cnt.as<unsigned>() + 2 * ((size_t)nleaf + 2);
-			NBCO_TRY(build_directed_list(c, c->m2l_list.as<int2>(), nm2l_dev, cap, nm2l_hint, 0, 0, 0, ntot, shift, cm, cm + ((size_t)ntot + 2),
+			NBCO_TRY(build_directed_list(c, c->m2l_list.as<int2>(), m2l_pref, capR, nm2l_hint, 0, 0, 0, ntot, shift, cm, cm + ((size_t)ntot + 2),
 			                             c->m2l_start.as<int>(), c->m2l_keys.as<uint64_t>(), c->m2l_keys_alt.as<uint64_t>(), dm, c->scan_tmp_aux));
 			{
 				PhaseScope ph(c, NBCO_PH_M2L);
@@ -2106,8 +2179,19 @@ int kd_copy_out(nbco_ctx *c, int which, void *dst, long long bytes)
 	case NBCO_KD_RBOUND: src = k.rbound; need = 12 * (size_t)k.ntot; break;
 	case NBCO_KD_MPOLE: src = k.mpole; need = 4 * (size_t)k.ntot * offM; break;
 	case NBCO_KD_LOCAL: src = k.local; need = 4 * (size_t)k.ntot * offL; break;
-	case NBCO_KD_P2P_LIST: src = c->p2p_list.ptr; need = 8 * (size_t)c->info.p2p_pairs; break;
-	case NBCO_KD_M2L_LIST: src = c->m2l_list.ptr; need = 8 * (size_t)c->info.m2l_pairs; break;
+	case NBCO_KD_P2P_LIST:
+	case NBCO_KD_M2L_LIST:
+	{
+		// the pair lists live in regions: make a dense copy in the (idle) frontier buffer
+		const bool p2p = which == NBCO_KD_P2P_LIST;
+		need = 8 * (size_t)(p2p ? c->info.p2p_pairs : c->info.m2l_pairs);
+		const long long capR = c->list_cap / kTravK;
+		hipLaunchKernelGGL(list_compact_kernel, dim3(1024), dim3(kBlock), 0, c->stream, (const int2 *)(p2p ? c->p2p_list.ptr : c->m2l_list.ptr),
+		                   (const int *)(c->trav_ctr.as<int>() + (p2p ? kTcP2PPref : kTcM2LPref)), capR, c->frontier_a.as<int2>());
+		NBCO_HIP(hipGetLastError());
+		src = c->frontier_a.ptr;
+		break;
+	}
 	case NBCO_KD_UNSORT: src = c->unsort.ptr; need = 4 * (size_t)k.n; break;
 	default: return c->fail(NBCO_ERR_ARG, "nbco_kd_copy: unknown array");
 	}

@@ -108,7 +108,7 @@ struct nbco_ctx
 	DevBuf p2p_chunk_cnt, p2p_chunk_off, p2p_chunks, p2p_desc;
 	const int *pc_mult = nullptr, *pc_total = nullptr;   // inputs of the on-demand directed pair count
 	int pc_shift = 0;
-	DevBuf list_cnt;
+	DevBuf list_cnt, trav_ctr;
 	DevBuf sel_hist, sel_nodes, sel_ties;   // selection build (k_kdselect.hip)
 	// multi-GPU kd-domain sharding: boxes / split axes of the global levels 0 .. d, the assembled global tree
 	DevBuf dist_top, dist_tree;
