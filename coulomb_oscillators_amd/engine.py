@@ -13,7 +13,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libnbco_hip.so")
+_LIB = os.environ.get("NBCO_LIB") or os.path.join(_HERE, "libnbco_hip.so")   # NBCO_LIB: A/B builds of the same ABI (diagnostics)
 
 EVAL_DIRECT, EVAL_DIRECT_KAHAN, EVAL_FMM_KDTREE, EVAL_FMM_TRACELESS = 0, 1, 2, 3
 INTEG_EULER, INTEG_PRE_EULER, INTEG_LEAPFROG, INTEG_FORESTRUTH, INTEG_PEFRL = 0, 1, 2, 3, 4
