@@ -21,9 +21,11 @@ namespace {
 
 using namespace kdc;
 
-constexpr int kBlock = 256;
-constexpr int kChunk = 2048;            // elements per block; nodes handled here hold > 4096 particles,
-                                        // so a chunk touches at most two nodes
+// Workgroups of BLOCK threads take chunks of 8 * BLOCK consecutive elements; a chunk must touch at most two nodes.
+// Atomics on one address retire at ~27 ns each on this part, and every workgroup of a node adds to the node's histogram
+// bins, completion counters and partition cursors: levels whose nodes hold >= 8192 particles use 1024-thread workgroups
+// (8192-element chunks), a quarter of the workgroups per node; the rest (nodes of 4097..8191) use 256 / 2048.
+constexpr int kBlockBig = 1024, kBlockSmall = 256;
 constexpr int kBins = 2048;
 constexpr int kTieCap = 64;
 
@@ -44,10 +46,12 @@ struct SelPivot { uint32_t prefix, r, neq, need; };
 
 __device__ inline uint32_t ld_agent_u32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// Locate the bin holding rank r in one 2048-bin histogram and descend into it.  Called by all kBlock threads.
-__device__ inline void descend(const uint32_t *__restrict__ h, int bits, SelPivot &pv, uint32_t *sh /* [kBlock/64 + 3] */)
+// Locate the bin holding rank r in one 2048-bin histogram and descend into it.  Called by all BLOCK threads.
+template <int BLOCK>
+__device__ inline void descend(const uint32_t *__restrict__ h, int bits, SelPivot &pv, uint32_t *sh /* [BLOCK/64 + 4] */)
 {
-	constexpr int PER = kBins / kBlock;
+	constexpr int R = BLOCK / 64;   // result slots follow the wave sums
+	constexpr int PER = kBins / BLOCK;
 	uint32_t v[PER], s = 0;
 #pragma unroll
 	for (int q = 0; q < PER; ++q) { v[q] = ld_agent_u32(&h[threadIdx.x * PER + q]); s += v[q]; }
@@ -63,13 +67,13 @@ __device__ inline void descend(const uint32_t *__restrict__ h, int bits, SelPivo
 #pragma unroll
 	for (int q = 0; q < PER; ++q)
 	{
-		if (pv.r >= cum && pv.r < cum + v[q]) { sh[4] = threadIdx.x * PER + q; sh[5] = cum; sh[6] = v[q]; }
+		if (pv.r >= cum && pv.r < cum + v[q]) { sh[R] = threadIdx.x * PER + q; sh[R + 1] = cum; sh[R + 2] = v[q]; }
 		cum += v[q];
 	}
 	__syncthreads();
-	pv.prefix = (pv.prefix << bits) | sh[4];
-	pv.r -= sh[5];
-	pv.neq = sh[6];
+	pv.prefix = (pv.prefix << bits) | sh[R];
+	pv.r -= sh[R + 1];
+	pv.neq = sh[R + 2];
 	pv.need = pv.r + 1;
 }
 
@@ -85,32 +89,34 @@ __device__ inline void key_window(const float *__restrict__ lbound, const float 
 	shl = span ? __clz(span) : 0;
 }
 
-// number of kChunk-sized blocks whose element range overlaps node j
+// number of CHUNK-sized blocks whose element range overlaps node j
+template <int CHUNK>
 __device__ inline uint32_t chunks_of_node(long long n, long long j, long long m)
 {
 	const long long s = range_start(n, j, m), e = range_start(n, j + 1, m);
-	return (uint32_t)((e - 1) / kChunk - s / kChunk + 1);
+	return (uint32_t)((e - 1) / CHUNK - s / CHUNK + 1);
 }
 
 // The block that completes node j's histogram of pass PASS descends into the bin holding the pivot rank and
 // publishes the new select state (the classic last-block-done pattern: nobody waits).
-template <int PASS>
+template <int PASS, int BLOCK>
 __device__ inline void finish_pass(const uint32_t *__restrict__ hist, SelNode *__restrict__ nodes, long long n, int l, long long j, uint32_t kmin,
                                    int shl, uint32_t *sh)
 {
+	constexpr int CHUNK = 8 * BLOCK, R = BLOCK / 64;
 	const long long m = 1LL << l;
 	// the histogram is only ever touched by device-scope atomics and agent-scope loads (both served by the L2), so
 	// completion of this block's atomics is all the ordering the counter needs -- no cache write-back / invalidate
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	__syncthreads();
-	if (threadIdx.x == 0) sh[7] = atomicAdd(&nodes[j].done[PASS], 1u);
+	if (threadIdx.x == 0) sh[R + 3] = atomicAdd(&nodes[j].done[PASS], 1u);
 	__syncthreads();
-	if (sh[7] != chunks_of_node(n, j, m) - 1) return;   // uniform over the block
+	if (sh[R + 3] != chunks_of_node<CHUNK>(n, j, m) - 1) return;   // uniform over the block
 	SelPivot pv;
 	if (PASS == 0) { pv.prefix = 0; pv.r = (uint32_t)(range_start(n, 2 * j + 1, 2 * m) - range_start(n, j, m) - 1); }
 	else { pv.prefix = ld_agent_u32(&nodes[j].prefix); pv.r = ld_agent_u32(&nodes[j].r); }
 	pv.neq = 0; pv.need = 0;
-	descend(hist + ((size_t)PASS * m + j) * kBins, PASS == 2 ? 10 : 11, pv, sh);
+	descend<BLOCK>(hist + ((size_t)PASS * m + j) * kBins, PASS == 2 ? 10 : 11, pv, sh);
 	if (threadIdx.x == 0)
 	{
 		nodes[j].prefix = pv.prefix; nodes[j].r = pv.r; nodes[j].neq = pv.neq; nodes[j].need = pv.need;
@@ -118,17 +124,18 @@ __device__ inline void finish_pass(const uint32_t *__restrict__ hist, SelNode *_
 	}
 }
 
-template <int PASS>
-__global__ __launch_bounds__(kBlock) void sel_hist_kernel(const float4 *__restrict__ pos, const int *__restrict__ sd_l, uint32_t *__restrict__ hist,
+template <int PASS, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void sel_hist_kernel(const float4 *__restrict__ pos, const int *__restrict__ sd_l, uint32_t *__restrict__ hist,
                                                           SelNode *__restrict__ nodes, const float *__restrict__ lbound,
                                                           const float *__restrict__ rbound, long long n, int l)
 {
+	constexpr int CHUNK = 8 * BLOCK;
 	__shared__ uint32_t h[2][kBins];
-	__shared__ uint32_t sh[8];
+	__shared__ uint32_t sh[BLOCK / 64 + 4];
 	const long long m = 1LL << l;
-	for (int t = threadIdx.x; t < 2 * kBins; t += kBlock) (&h[0][0])[t] = 0;
-	const long long i0 = (long long)blockIdx.x * kChunk;
-	const long long ilast = (i0 + kChunk < n ? i0 + kChunk : n) - 1;
+	for (int t = threadIdx.x; t < 2 * kBins; t += BLOCK) (&h[0][0])[t] = 0;
+	const long long i0 = (long long)blockIdx.x * CHUNK;
+	const long long ilast = (i0 + CHUNK < n ? i0 + CHUNK : n) - 1;
 	const long long j0 = (m * i0) / n, j1 = (m * ilast) / n;
 	uint32_t pfx[2] = {0, 0}, kmin[2] = {0, 0};
 	int shl[2] = {0, 0};
@@ -141,18 +148,18 @@ __global__ __launch_bounds__(kBlock) void sel_hist_kernel(const float4 *__restri
 	__syncthreads();
 	const long long split = j1 > j0 ? range_start(n, j1, m) : n;
 	const int sd[2] = {sd_l[j0], sd_l[j1]};
-	constexpr int PER = kChunk / kBlock;
+	constexpr int PER = CHUNK / BLOCK;
 	float4 p[PER];
 #pragma unroll
 	for (int e = 0; e < PER; ++e)
 	{
-		const long long i = i0 + e * kBlock + threadIdx.x;
+		const long long i = i0 + e * BLOCK + threadIdx.x;
 		if (i < n) p[e] = pos[i];
 	}
 #pragma unroll
 	for (int e = 0; e < PER; ++e)
 	{
-		const long long i = i0 + e * kBlock + threadIdx.x;
+		const long long i = i0 + e * BLOCK + threadIdx.x;
 		if (i < n)
 		{
 			const int jj = i >= split ? 1 : 0;
@@ -165,17 +172,18 @@ __global__ __launch_bounds__(kBlock) void sel_hist_kernel(const float4 *__restri
 		}
 	}
 	__syncthreads();
-	for (int t = threadIdx.x; t < 2 * kBins; t += kBlock)
+	for (int t = threadIdx.x; t < 2 * kBins; t += BLOCK)
 	{
 		const uint32_t v = (&h[0][0])[t];
 		const long long j = j0 + (t / kBins);
 		if (v && j <= j1) atomicAdd(&hist[((size_t)PASS * m + j) * kBins + (t % kBins)], v);
 	}
-	finish_pass<PASS>(hist, nodes, n, l, j0, kmin[0], shl[0], sh);
-	if (j1 > j0) finish_pass<PASS>(hist, nodes, n, l, j1, kmin[1], shl[1], sh);
+	finish_pass<PASS, BLOCK>(hist, nodes, n, l, j0, kmin[0], shl[0], sh);
+	if (j1 > j0) finish_pass<PASS, BLOCK>(hist, nodes, n, l, j1, kmin[1], shl[1], sh);
 }
 
-// exclusive scan over the block of four 16-bit counters packed in a uint64 (each block total <= kChunk < 2^16)
+// exclusive scan over the block of four 16-bit counters packed in a uint64 (each block total <= CHUNK < 2^16)
+template <int BLOCK>
 __device__ inline uint64_t block_scan4(uint64_t v, uint64_t *sh_wave, uint64_t &total)
 {
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -188,7 +196,7 @@ __device__ inline uint64_t block_scan4(uint64_t v, uint64_t *sh_wave, uint64_t &
 	if (lane == 63) sh_wave[w] = incl;
 	__syncthreads();
 	uint64_t base = 0, tot = 0;
-	for (int k = 0; k < kBlock / 64; ++k)
+	for (int k = 0; k < BLOCK / 64; ++k)
 	{
 		const uint64_t t = sh_wave[k];
 		if (k < w) base += t;
@@ -201,16 +209,19 @@ __device__ inline uint64_t block_scan4(uint64_t v, uint64_t *sh_wave, uint64_t &
 // Unordered partition of every node into [keys below the pivot | keys above the pivot]; elements equal to the
 // pivot go left when all of them belong there and to the tie list otherwise.  All loads of a thread's 8 elements
 // are issued up front, slots are reserved with one packed block scan and four concurrent global atomics.
-__global__ __launch_bounds__(kBlock) void sel_partition_kernel(const float4 *__restrict__ pos_in, const int *__restrict__ unsort_in,
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__restrict__ pos_in, const int *__restrict__ unsort_in,
                                                                float4 *__restrict__ pos_out, int *__restrict__ unsort_out,
                                                                const int *__restrict__ sd_l, SelNode *__restrict__ nodes,
                                                                uint32_t *__restrict__ tielist, long long n, int l)
 {
-	__shared__ uint64_t sh_wave[kBlock / 64];
+	constexpr int CHUNK = 8 * BLOCK;
+	static_assert(CHUNK < 65536, "packed 16-bit block counters");
+	__shared__ uint64_t sh_wave[BLOCK / 64];
 	__shared__ uint32_t base_s[4], mR[2];
 	const long long m = 1LL << l;
-	const long long i0 = (long long)blockIdx.x * kChunk;
-	const long long ilast = (i0 + kChunk < n ? i0 + kChunk : n) - 1;
+	const long long i0 = (long long)blockIdx.x * CHUNK;
+	const long long ilast = (i0 + CHUNK < n ? i0 + CHUNK : n) - 1;
 	const long long j0 = (m * i0) / n, j1 = (m * ilast) / n;
 	// first element of node j1 (only meaningful when the chunk straddles two nodes)
 	const long long split = j1 > j0 ? range_start(n, j1, m) : n;
@@ -223,13 +234,13 @@ __global__ __launch_bounds__(kBlock) void sel_partition_kernel(const float4 *__r
 	}
 	const int sd[2] = {sd_l[j0], sd_l[j1]};
 	if (threadIdx.x < 2) mR[threadIdx.x] = 0xFFFFFFFFu;
-	constexpr int PER = kChunk / kBlock;
+	constexpr int PER = CHUNK / BLOCK;
 	float4 p[PER];
 	int org[PER];
 #pragma unroll
 	for (int e = 0; e < PER; ++e)
 	{
-		const long long i = i0 + e * kBlock + threadIdx.x;
+		const long long i = i0 + e * BLOCK + threadIdx.x;
 		if (i < n) { p[e] = pos_in[i]; org[e] = unsort_in[i]; }
 	}
 	int cls[PER];   // 0 none / tie, 1 left, 2 right
@@ -238,7 +249,7 @@ __global__ __launch_bounds__(kBlock) void sel_partition_kernel(const float4 *__r
 #pragma unroll
 	for (int e = 0; e < PER; ++e)
 	{
-		const long long i = i0 + e * kBlock + threadIdx.x;
+		const long long i = i0 + e * BLOCK + threadIdx.x;
 		cls[e] = 0;
 		if (i < n)
 		{
@@ -254,7 +265,7 @@ __global__ __launch_bounds__(kBlock) void sel_partition_kernel(const float4 *__r
 		}
 	}
 	uint64_t tot;
-	const uint64_t off = block_scan4(cnt, sh_wave, tot);
+	const uint64_t off = block_scan4<BLOCK>(cnt, sh_wave, tot);
 	if (threadIdx.x < 4)
 	{
 		const int jj = threadIdx.x >> 1, right = threadIdx.x & 1;
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(kBlock) void sel_partition_kernel(const float4 *__r
 	for (int e = 0; e < PER; ++e)
 	{
 		if (!cls[e]) continue;
-		const long long i = i0 + e * kBlock + threadIdx.x;
+		const long long i = i0 + e * BLOCK + threadIdx.x;
 		const int q = (i >= split ? 2 : 0) + (cls[e] - 1);
 		const long long dst = q == 0 ? cur[0]++ : (q == 1 ? cur[1]++ : (q == 2 ? cur[2]++ : cur[3]++));
 		pos_out[dst] = p[e];
@@ -393,8 +404,9 @@ int kd_select_begin(nbco_ctx *c, int l0)
 
 // Split every node of level l (all of which hold more than 4096 particles) and write the boxes of level
 // l + 1.  `flag` (device int) is set when a node had more ties than the resolver handles.
-int kd_select_level(nbco_ctx *c, int l, long long n, const float4 *pos_in, const int *unsort_in, float4 *pos_out, int *unsort_out,
-                    float *lbound, float *rbound, int *splitdim, int *index, int *flag)
+template <int BLOCK>
+static void select_level_launch(nbco_ctx *c, int l, long long n, const float4 *pos_in, const int *unsort_in, float4 *pos_out, int *unsort_out,
+                                float *lbound, float *rbound, int *splitdim, int *index, int *flag)
 {
 	const int m = 1 << l;
 	// level l uses the slices [m - 1, 2m - 1) of the per-build arrays
@@ -403,13 +415,23 @@ int kd_select_level(nbco_ctx *c, int l, long long n, const float4 *pos_in, const
 	uint32_t *ties = c->sel_ties.as<uint32_t>() + (size_t)(m - 1) * kTieCap;
 	const int *sd_l = splitdim + (m - 1);
 	hipStream_t st = c->stream;
-	const int gchunks = (int)((n + kChunk - 1) / kChunk);
-	hipLaunchKernelGGL(sel_hist_kernel<0>, dim3(gchunks), dim3(kBlock), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l);
-	hipLaunchKernelGGL(sel_hist_kernel<1>, dim3(gchunks), dim3(kBlock), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l);
-	hipLaunchKernelGGL(sel_hist_kernel<2>, dim3(gchunks), dim3(kBlock), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l);
-	hipLaunchKernelGGL(sel_partition_kernel, dim3(gchunks), dim3(kBlock), 0, st, pos_in, unsort_in, pos_out, unsort_out, sd_l, nodes, ties, n, l);
+	constexpr int CHUNK = 8 * BLOCK;
+	const int gchunks = (int)((n + CHUNK - 1) / CHUNK);
+	hipLaunchKernelGGL((sel_hist_kernel<0, BLOCK>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l);
+	hipLaunchKernelGGL((sel_hist_kernel<1, BLOCK>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l);
+	hipLaunchKernelGGL((sel_hist_kernel<2, BLOCK>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l);
+	hipLaunchKernelGGL(sel_partition_kernel<BLOCK>, dim3(gchunks), dim3(BLOCK), 0, st, pos_in, unsort_in, pos_out, unsort_out, sd_l, nodes, ties, n, l);
 	hipLaunchKernelGGL(sel_ties_box_kernel, dim3(m), dim3(64), 0, st, pos_in, unsort_in, pos_out, unsort_out, lbound, rbound, splitdim, index, nodes,
 	                   (const uint32_t *)ties, flag, n, l);
+}
+
+int kd_select_level(nbco_ctx *c, int l, long long n, const float4 *pos_in, const int *unsort_in, float4 *pos_out, int *unsort_out,
+                    float *lbound, float *rbound, int *splitdim, int *index, int *flag)
+{
+	if ((n >> l) >= 8 * kBlockBig)
+		select_level_launch<kBlockBig>(c, l, n, pos_in, unsort_in, pos_out, unsort_out, lbound, rbound, splitdim, index, flag);
+	else
+		select_level_launch<kBlockSmall>(c, l, n, pos_in, unsort_in, pos_out, unsort_out, lbound, rbound, splitdim, index, flag);
 	NBCO_HIP(hipGetLastError());
 	return NBCO_OK;
 }
