@@ -137,6 +137,71 @@ __global__ void root_union_kernel(const float *__restrict__ box6, float *__restr
 	else if (i < 6) minmax6[i] = fmaxf(minmax6[i], box6[i]);
 }
 
+// ---- build prologue, one launch ------------------------------------------------------------------------------
+// Packs the caller's xyz triplets into float4, writes the identity permutation, clears the selection build's histograms
+// and node states, and reduces the bounding box: per-workgroup min / max go into six ordered-bit words with device
+// atomics, and the LAST workgroup to finish writes the root node (evalRootBox, fmm_cart3_kdtree.cuh:89-107) and
+// re-arms the accumulators for the next build.  Replaces eight small launches.  Atomics on one address retire at ~27 ns
+// each: the grid is kept to kPrepGrid large workgroups.
+// state: [0..2] min as ordered bits (armed 0xFFFFFFFF), [3..5] max (armed 0), [6] workgroups done (armed 0)
+constexpr int kPrepBlock = 1024, kPrepGrid = 128;
+__global__ __launch_bounds__(kPrepBlock) void kd_prep_kernel(const float *__restrict__ p3, long long n, float4 *__restrict__ pos,
+                                                             int *__restrict__ unsort, uint32_t *__restrict__ zero_a, long long words_a,
+                                                             uint32_t *__restrict__ zero_b, long long words_b, int *__restrict__ flag,
+                                                             unsigned *__restrict__ state, TreeView t, const float *__restrict__ root6)
+{
+	float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+	const long long stride = (long long)gridDim.x * kPrepBlock, tid = (long long)blockIdx.x * kPrepBlock + threadIdx.x;
+	for (long long i = tid; i < n; i += stride)
+	{
+		const float x = p3[3 * i], y = p3[3 * i + 1], z = p3[3 * i + 2];
+		pos[i] = make_float4(x, y, z, 0.f);
+		unsort[i] = (int)i;
+		mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);
+		mx[0] = fmaxf(mx[0], x); mx[1] = fmaxf(mx[1], y); mx[2] = fmaxf(mx[2], z);
+	}
+	for (long long i = tid; i < words_a; i += stride) zero_a[i] = 0u;
+	for (long long i = tid; i < words_b; i += stride) zero_b[i] = 0u;
+	if (tid == 0) *flag = 0;
+	__shared__ float sh[kPrepBlock / 64][6];
+	__shared__ unsigned last;
+	const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+	for (int c = 0; c < 3; ++c)
+		for (int o = 32; o > 0; o >>= 1) { mn[c] = fminf(mn[c], __shfl_xor(mn[c], o)); mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o)); }
+	if (lane == 0)
+#pragma unroll
+		for (int c = 0; c < 3; ++c) { sh[w][c] = mn[c]; sh[w][3 + c] = mx[c]; }
+	__syncthreads();
+	if (threadIdx.x < 6)
+	{
+		float v = sh[0][threadIdx.x];
+		for (int k = 1; k < kPrepBlock / 64; ++k) v = threadIdx.x < 3 ? fminf(v, sh[k][threadIdx.x]) : fmaxf(v, sh[k][threadIdx.x]);
+		if (threadIdx.x < 3) atomicMin(&state[threadIdx.x], ordered_bits(v));
+		else atomicMax(&state[threadIdx.x], ordered_bits(v));
+	}
+	// the accumulators are only touched by device atomics and agent-scope loads: completion of this workgroup's atomics is all
+	// the ordering the counter needs
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	if (threadIdx.x == 0) last = atomicAdd(&state[6], 1u) == gridDim.x - 1 ? 1u : 0u;
+	__syncthreads();
+	if (!last || threadIdx.x != 0) return;
+	float b[6];
+	for (int c = 0; c < 6; ++c)
+	{
+		b[c] = unordered_bits(__hip_atomic_load(&state[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+		__hip_atomic_store(&state[c], c < 3 ? 0xFFFFFFFFu : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+	__hip_atomic_store(&state[6], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	if (root6)   // a kd-domain keeps the union of its inherited box and the current bounds (see kd_build_upward)
+		for (int c = 0; c < 3; ++c) { b[c] = fminf(b[c], root6[c]); b[3 + c] = fmaxf(b[3 + c], root6[3 + c]); }
+	t.lbound[0] = b[0]; t.lbound[1] = b[1]; t.lbound[2] = b[2];
+	t.rbound[0] = b[3]; t.rbound[1] = b[4]; t.rbound[2] = b[5];
+	t.splitdim[0] = longest_axis(b[3] - b[0], b[4] - b[1], b[5] - b[2]);
+	t.index[0] = 0;
+}
+
 // composite keys of level l (fmm_cart3_kdtree.cuh:167-187): node j = floor(2^l i / n)
 __global__ __launch_bounds__(kBlock) void kd_keys_kernel(const float4 *__restrict__ pos, const int *__restrict__ splitdim_l, long long n,
                                                          int l, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
@@ -1531,10 +1596,10 @@ static int kd_carve(nbco_ctx *c, DevBuf &buf, KdTreeDev &k, int ntot, int offM, 
 // overflow, one global stable radix sort per level.  The root's box / split axis must be in place; on return
 // pos / unsort point at the buffers holding the result and the boxes of level l0 are written.
 static int kd_build_top(nbco_ctx *c, const TreeView &tv, float4 *&pos, float4 *&pos_alt, int *&unsort, int *&unsort_alt, long long n, int l0,
-                        bool use_select)
+                        bool use_select, bool select_ready = false)
 {
 	hipStream_t st = c->stream;
-	if (use_select && l0 > 0) NBCO_TRY(kd_select_begin(c, l0));
+	if (use_select && l0 > 0 && !select_ready) NBCO_TRY(kd_select_begin(c, l0));
 	for (int l = 0; l < l0; ++l)
 	{
 		if (use_select)
@@ -1597,22 +1662,25 @@ static int kd_build_upward(nbco_ctx *c, const float *p, long long n, int L, cons
 	rebuild = c->o.unsort || !c->tree_valid || (c->eval_counter % c->o.tree_steps) == 0;
 	{
 		PhaseScope ph(c, NBCO_PH_BUILD);
-		NBCO_TRY(launch_pack4(c, pos, p, n));
-		NBCO_HIP(hipMemsetAsync(c->counters.as<int>() + 110, 0, sizeof(int), st));
 		if (rebuild)
 		{
-			float *mm = c->small.as<float>() + 64;
-			NBCO_TRY(launch_minmax4(c, pos, n, mm));
-			// a kd-domain inherits its box from the global tree's top splits; between two partitions the particles
-			// may have left it, and the selection keys are normalised to the node box: keep the union
-			if (root6) hipLaunchKernelGGL(root_union_kernel, dim3(1), dim3(64), 0, st, root6, mm);
-			hipLaunchKernelGGL(kd_root_kernel, dim3(1), dim3(64), 0, st, tv, (const float *)mm);
-			hipLaunchKernelGGL(iota_kernel, dim3(grid1d(n)), dim3(kBlock), 0, st, unsort, n);
 			// levels whose nodes exceed the LDS slice
 			int l0 = 0;
 			while (l0 < L && (n + (1LL << l0) - 1) / (1LL << l0) > kSubS) ++l0;
 			const bool use_select = !c->force_sort_build;
-			NBCO_TRY(kd_build_top(c, tv, pos, pos_alt, unsort, unsort_alt, n, l0, use_select));
+			long long words_a = 0, words_b = 0;
+			if (use_select && l0 > 0) NBCO_TRY(kd_select_begin(c, l0, false, &words_a, &words_b));
+			if (!c->prep_state.ptr)
+			{
+				NBCO_TRY(c->reserve(c->prep_state, 64));
+				const unsigned arm[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
+				NBCO_HIP(hipMemcpyAsync(c->prep_state.ptr, arm, sizeof arm, hipMemcpyHostToDevice, st));
+				NBCO_HIP(hipStreamSynchronize(st));   // `arm` lives on this stack frame; happens once per context
+			}
+			// pack + identity permutation + bounding box + root node + cleared selection state: one launch
+			hipLaunchKernelGGL(kd_prep_kernel, dim3(kPrepGrid), dim3(kPrepBlock), 0, st, p, n, pos, unsort, c->sel_hist.as<uint32_t>(), words_a,
+			                   c->sel_nodes.as<uint32_t>(), words_b, c->counters.as<int>() + 110, c->prep_state.as<unsigned>(), tv, root6);
+			NBCO_TRY(kd_build_top(c, tv, pos, pos_alt, unsort, unsort_alt, n, l0, use_select, true));
 			// the rest of every level-l0 subtree inside one workgroup's LDS
 			hipLaunchKernelGGL(kd_subtree_kernel, dim3(kd_cnt(l0)), dim3(kSubT), 0, st, tv, (const float4 *)pos, (const int *)unsort, pos_alt, unsort_alt, n, l0,
 			                   use_select ? 1 : 0, c->counters.as<int>() + 110);
@@ -1622,6 +1690,12 @@ static int kd_build_upward(nbco_ctx *c, const float *p, long long n, int L, cons
 			// keep the "current" buffers in the primary slots
 			if (pos != c->pos4.as<float4>()) { std::swap(c->pos4, c->pos4_alt); std::swap(c->unsort, c->unsort_alt); }
 			pos = c->pos4.as<float4>();
+		}
+		else
+		{
+			// tree reused: the caller's positions are already in tree order
+			NBCO_TRY(launch_pack4(c, pos, p, n));
+			NBCO_HIP(hipMemsetAsync(c->counters.as<int>() + 110, 0, sizeof(int), st));
 		}
 		hipLaunchKernelGGL(kd_leaf_kernel, dim3(grid1d(nleaf)), dim3(kBlock), 0, st, tv, pos, n);
 		NBCO_HIP(hipGetLastError());

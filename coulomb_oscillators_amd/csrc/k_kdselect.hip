@@ -390,15 +390,22 @@ __global__ __launch_bounds__(64) void sel_ties_box_kernel(const float4 *__restri
 
 } // namespace
 
-// Zero the pass histograms and node counters of levels 0 .. l0-1 (one memset each per build).
-int kd_select_begin(nbco_ctx *c, int l0)
+// Storage of the pass histograms and node counters of levels 0 .. l0-1.  They have to be zero before the first level:
+// zero = true does it with two memsets, zero = false leaves it to the caller (the build prologue kernel clears the
+// two ranges returned in words_a / words_b while it packs the positions).
+int kd_select_begin(nbco_ctx *c, int l0, bool zero, long long *words_a, long long *words_b)
 {
 	const size_t nodes = ((size_t)1 << l0) - 1;
 	NBCO_TRY(c->reserve(c->sel_hist, sizeof(uint32_t) * 3 * nodes * kBins));
 	NBCO_TRY(c->reserve(c->sel_nodes, sizeof(SelNode) * nodes));
 	NBCO_TRY(c->reserve(c->sel_ties, sizeof(uint32_t) * nodes * kTieCap));
-	NBCO_HIP(hipMemsetAsync(c->sel_hist.ptr, 0, sizeof(uint32_t) * 3 * nodes * kBins, c->stream));
-	NBCO_HIP(hipMemsetAsync(c->sel_nodes.ptr, 0, sizeof(SelNode) * nodes, c->stream));
+	if (words_a) *words_a = (long long)(3 * nodes * kBins);
+	if (words_b) *words_b = (long long)(sizeof(SelNode) / sizeof(uint32_t) * nodes);
+	if (zero)
+	{
+		NBCO_HIP(hipMemsetAsync(c->sel_hist.ptr, 0, sizeof(uint32_t) * 3 * nodes * kBins, c->stream));
+		NBCO_HIP(hipMemsetAsync(c->sel_nodes.ptr, 0, sizeof(SelNode) * nodes, c->stream));
+	}
 	return NBCO_OK;
 }
 

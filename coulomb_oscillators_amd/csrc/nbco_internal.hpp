@@ -109,6 +109,7 @@ struct nbco_ctx
 	const int *pc_mult = nullptr, *pc_total = nullptr;   // inputs of the on-demand directed pair count
 	int pc_shift = 0;
 	DevBuf list_cnt, trav_ctr;
+	DevBuf prep_state;   // min / max accumulators + completion counter of the build prologue kernel
 	DevBuf sel_hist, sel_nodes, sel_ties;   // selection build (k_kdselect.hip)
 	// multi-GPU kd-domain sharding: boxes / split axes of the global levels 0 .. d, the assembled global tree
 	DevBuf dist_top, dist_tree;
@@ -202,7 +203,7 @@ int kd_dist_partition(nbco_ctx *c, const float *state_all, long long n_global, i
 int kd_dist_local(nbco_ctx *c, float *buf_local, long long n_local, void *nodes_send, void *pos_send);
 int kd_dist_finish(nbco_ctx *c, const void *nodes_all, const void *pos_all, float *buf_local, float *a_local, const float *param);
 // k_kdselect.hip
-int kd_select_begin(nbco_ctx *c, int l0);
+int kd_select_begin(nbco_ctx *c, int l0, bool zero = true, long long *words_a = nullptr, long long *words_b = nullptr);
 int kd_select_level(nbco_ctx *c, int l, long long n, const float4 *pos_in, const int *unsort_in, float4 *pos_out, int *unsort_out,
                     float *lbound, float *rbound, int *splitdim, int *index, int *flag);
 // k_farfield.hip
