@@ -37,6 +37,7 @@ struct SelNode
 	uint32_t neq;      // elements equal to the pivot key (after three passes)
 	uint32_t need;     // how many of them belong to the left child
 	uint32_t done[3];  // blocks that have finished their histogram contribution, per pass
+	uint32_t done_part; // blocks that have finished their part of the partition
 	uint32_t cntL, cntR, tiecnt;
 	uint32_t minR;     // smallest ordered key of the right child, stored inverted (~key) so that zero = "none yet"
 	uint32_t pivot;    // the pivot as an ordered key (valid after the third pass)
@@ -206,6 +207,89 @@ __device__ inline uint64_t block_scan4(uint64_t v, uint64_t *sh_wave, uint64_t &
 	return base + incl - v;
 }
 
+#pragma clang fp contract(off)
+// Run by ONE wave once every workgroup of node j has finished its part of the partition (last-block-done).  It first
+// orders the elements that tie with the pivot by the remaining keys of the stable-sort chain -- the next distinct
+// ancestor split axes, then the original index -- and hands the first `need` of them to the left child; then evalBox
+// for the two children (fmm_cart3_kdtree.cuh:109-137): the sorted order's boundary elements are the pivot (largest
+// key of the left child) and the smallest key of the right child.
+__device__ inline void ties_and_boxes(const float4 *__restrict__ pos_in, const int *__restrict__ unsort_in, float4 *__restrict__ pos_out,
+                                      int *__restrict__ unsort_out, float *__restrict__ lbound, float *__restrict__ rbound,
+                                      int *__restrict__ splitdim, int *__restrict__ index, SelNode *__restrict__ nodes,
+                                      const uint32_t *__restrict__ tielist, int *__restrict__ flag, long long n, int l, int j, int lane)
+{
+	const int m = 1 << l;
+	const SelPivot pv{nodes[j].pivot, nodes[j].r, nodes[j].neq, nodes[j].need};   // written by the previous launch
+	const int node = m - 1 + j, a1 = splitdim[node];
+	const uint32_t nt = ld_agent_u32(&nodes[j].tiecnt);
+	bool tie_right = false;
+	if (nt > kTieCap) { if (lane == 0) *flag = 1; }
+	else if (nt > 0)
+	{
+		int a2 = -1, a3 = -1;
+		for (int anc = node; anc > 0;)
+		{
+			anc = (anc - 1) >> 1;
+			const int a = splitdim[anc];
+			if (a == a1 || a == a2) continue;
+			if (a2 < 0) a2 = a;
+			else { a3 = a; break; }
+		}
+		uint32_t idx = 0, k2 = 0, k3 = 0, org = 0;
+		if ((uint32_t)lane < nt)
+		{
+			idx = ld_agent_u32(&tielist[(size_t)j * kTieCap + lane]);
+			const float4 p = pos_in[idx];
+			k2 = a2 >= 0 ? ordered_bits(axis_of(p, a2)) : 0;
+			k3 = a3 >= 0 ? ordered_bits(axis_of(p, a3)) : 0;
+			org = (uint32_t)unsort_in[idx];
+		}
+		uint32_t rank = 0;
+		for (uint32_t q = 0; q < nt; ++q)
+		{
+			const uint32_t q2 = __shfl(k2, q), q3 = __shfl(k3, q), qo = __shfl(org, q);
+			const bool before = q2 < k2 || (q2 == k2 && (q3 < k3 || (q3 == k3 && qo < org)));
+			rank += before ? 1u : 0u;
+		}
+		bool right = false;
+		if ((uint32_t)lane < nt)
+		{
+			long long dst;
+			if (rank < pv.need) dst = range_start(n, j, m) + atomicAdd(&nodes[j].cntL, 1u);
+			else
+			{
+				dst = range_start(n, 2 * j + 1, 2LL * m) + atomicAdd(&nodes[j].cntR, 1u);
+				right = true;   // a pivot-valued element went right: it is the right child's smallest key
+			}
+			pos_out[dst] = pos_in[idx];
+			unsort_out[dst] = unsort_in[idx];
+		}
+		tie_right = __ballot(right) != 0;
+	}
+	if (lane < 2)
+	{
+		const int c = 2 * j + lane, child = 2 * m - 1 + c;
+		float lb[3] = {lbound[3 * node], lbound[3 * node + 1], lbound[3 * node + 2]};
+		float rb[3] = {rbound[3 * node], rbound[3 * node + 1], rbound[3 * node + 2]};
+		if (c & 1)
+		{
+			const uint32_t mr = tie_right ? pv.prefix : ~ld_agent_u32(&nodes[j].minR);
+			const float v = unordered_bits(mr);
+			if (a1 == 0) lb[0] = v; else if (a1 == 1) lb[1] = v; else lb[2] = v;
+		}
+		else
+		{
+			const float v = unordered_bits(pv.prefix);
+			if (a1 == 0) rb[0] = v; else if (a1 == 1) rb[1] = v; else rb[2] = v;
+		}
+		lbound[3 * child] = lb[0]; lbound[3 * child + 1] = lb[1]; lbound[3 * child + 2] = lb[2];
+		rbound[3 * child] = rb[0]; rbound[3 * child + 1] = rb[1]; rbound[3 * child + 2] = rb[2];
+		splitdim[child] = longest_axis(rb[0] - lb[0], rb[1] - lb[1], rb[2] - lb[2]);
+		index[child] = (int)range_start(n, c, 2LL * m);
+	}
+}
+#pragma clang fp contract(on)
+
 // Unordered partition of every node into [keys below the pivot | keys above the pivot]; elements equal to the
 // pivot go left when all of them belong there and to the tie list otherwise.  All loads of a thread's 8 elements
 // are issued up front, slots are reserved with one packed block scan and four concurrent global atomics.
@@ -213,7 +297,9 @@ template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__restrict__ pos_in, const int *__restrict__ unsort_in,
                                                                float4 *__restrict__ pos_out, int *__restrict__ unsort_out,
                                                                const int *__restrict__ sd_l, SelNode *__restrict__ nodes,
-                                                               uint32_t *__restrict__ tielist, long long n, int l)
+                                                               uint32_t *__restrict__ tielist, long long n, int l, float *__restrict__ lbound,
+                                                               float *__restrict__ rbound, int *__restrict__ splitdim, int *__restrict__ index,
+                                                               int *__restrict__ flag)
 {
 	constexpr int CHUNK = 8 * BLOCK;
 	static_assert(CHUNK < 65536, "packed 16-bit block counters");
@@ -260,7 +346,8 @@ __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__re
 			else
 			{
 				const uint32_t t = atomicAdd(&nodes[j0 + jj].tiecnt, 1u);
-				if (t < kTieCap) tielist[(size_t)(j0 + jj) * kTieCap + t] = (uint32_t)i;
+				// read back inside this launch by the workgroup that completes the node: store past the (non-coherent) L2
+				if (t < kTieCap) __hip_atomic_store(&tielist[(size_t)(j0 + jj) * kTieCap + t], (uint32_t)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
 		}
 	}
@@ -301,92 +388,20 @@ __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__re
 		pos_out[dst] = p[e];
 		unsort_out[dst] = org[e];
 	}
+	// The workgroup that completes a node resolves its pivot ties and writes the children's boxes (last-block-done: the
+	// cursors, tie list and minimum are only touched by device atomics and read back with agent-scope loads).
+	__shared__ uint32_t fin[2];
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	if (threadIdx.x < 2) fin[threadIdx.x] = (j0 + threadIdx.x <= j1) ? atomicAdd(&nodes[j0 + threadIdx.x].done_part, 1u) : 0xFFFFFFFFu;
+	__syncthreads();
+	if (threadIdx.x < 64)
+		for (int jj = 0; jj < 2; ++jj)
+			if (j0 + jj <= j1 && fin[jj] == chunks_of_node<CHUNK>(n, j0 + jj, m) - 1)
+				ties_and_boxes(pos_in, unsort_in, pos_out, unsort_out, lbound, rbound, splitdim, index, nodes, tielist, flag, n, l, (int)(j0 + jj),
+				               (int)threadIdx.x);
 }
 
-#pragma clang fp contract(off)
-// One block per node of level l.  Wave 0 first orders the elements that tie with the pivot by the remaining
-// keys of the stable-sort chain -- the next distinct ancestor split axes, then the original index -- and
-// hands the first `need` of them to the left child; then evalBox for the two children
-// (fmm_cart3_kdtree.cuh:109-137): the sorted order's boundary elements are the pivot (largest key of the
-// left child) and the smallest key of the right child.
-__global__ __launch_bounds__(64) void sel_ties_box_kernel(const float4 *__restrict__ pos_in, const int *__restrict__ unsort_in,
-                                                              float4 *__restrict__ pos_out, int *__restrict__ unsort_out,
-                                                              float *__restrict__ lbound, float *__restrict__ rbound, int *__restrict__ splitdim,
-                                                              int *__restrict__ index, SelNode *__restrict__ nodes,
-                                                              const uint32_t *__restrict__ tielist, int *__restrict__ flag, long long n, int l)
-{
-	__shared__ uint32_t tie_min;
-	const int m = 1 << l, j = blockIdx.x, lane = threadIdx.x;
-	const SelPivot pv{nodes[j].pivot, nodes[j].r, nodes[j].neq, nodes[j].need};
-	const int node = m - 1 + j, a1 = splitdim[node];
-	const uint32_t nt = nodes[j].tiecnt;
-	if (threadIdx.x == 0) tie_min = 0;
-	__syncthreads();
-	if (nt > kTieCap) { if (threadIdx.x == 0) *flag = 1; }
-	else if (nt > 0)
-	{
-		int a2 = -1, a3 = -1;
-		for (int anc = node; anc > 0;)
-		{
-			anc = (anc - 1) >> 1;
-			const int a = splitdim[anc];
-			if (a == a1 || a == a2) continue;
-			if (a2 < 0) a2 = a;
-			else { a3 = a; break; }
-		}
-		uint32_t idx = 0, k2 = 0, k3 = 0, org = 0;
-		if ((uint32_t)lane < nt)
-		{
-			idx = tielist[(size_t)j * kTieCap + lane];
-			const float4 p = pos_in[idx];
-			k2 = a2 >= 0 ? ordered_bits(axis_of(p, a2)) : 0;
-			k3 = a3 >= 0 ? ordered_bits(axis_of(p, a3)) : 0;
-			org = (uint32_t)unsort_in[idx];
-		}
-		uint32_t rank = 0;
-		for (uint32_t q = 0; q < nt; ++q)
-		{
-			const uint32_t q2 = __shfl(k2, q), q3 = __shfl(k3, q), qo = __shfl(org, q);
-			const bool before = q2 < k2 || (q2 == k2 && (q3 < k3 || (q3 == k3 && qo < org)));
-			rank += before ? 1u : 0u;
-		}
-		if ((uint32_t)lane < nt)
-		{
-			long long dst;
-			if (rank < pv.need) dst = range_start(n, j, m) + atomicAdd(&nodes[j].cntL, 1u);
-			else
-			{
-				dst = range_start(n, 2 * j + 1, 2LL * m) + atomicAdd(&nodes[j].cntR, 1u);
-				tie_min = 1;   // a pivot-valued element went right: it is the right child's smallest key
-			}
-			pos_out[dst] = pos_in[idx];
-			unsort_out[dst] = unsort_in[idx];
-		}
-	}
-	__syncthreads();
-	if (threadIdx.x < 2)
-	{
-		const int c = 2 * j + threadIdx.x, child = 2 * m - 1 + c;
-		float lb[3] = {lbound[3 * node], lbound[3 * node + 1], lbound[3 * node + 2]};
-		float rb[3] = {rbound[3 * node], rbound[3 * node + 1], rbound[3 * node + 2]};
-		if (c & 1)
-		{
-			const uint32_t mr = tie_min ? pv.prefix : ~nodes[j].minR;
-			const float v = unordered_bits(mr);
-			if (a1 == 0) lb[0] = v; else if (a1 == 1) lb[1] = v; else lb[2] = v;
-		}
-		else
-		{
-			const float v = unordered_bits(pv.prefix);
-			if (a1 == 0) rb[0] = v; else if (a1 == 1) rb[1] = v; else rb[2] = v;
-		}
-		lbound[3 * child] = lb[0]; lbound[3 * child + 1] = lb[1]; lbound[3 * child + 2] = lb[2];
-		rbound[3 * child] = rb[0]; rbound[3 * child + 1] = rb[1]; rbound[3 * child + 2] = rb[2];
-		splitdim[child] = longest_axis(rb[0] - lb[0], rb[1] - lb[1], rb[2] - lb[2]);
-		index[child] = (int)range_start(n, c, 2LL * m);
-	}
-}
-#pragma clang fp contract(on)
 
 } // namespace
 
@@ -427,9 +442,8 @@ static void select_level_launch(nbco_ctx *c, int l, long long n, const float4 *p
 	hipLaunchKernelGGL((sel_hist_kernel<0, BLOCK>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l);
 	hipLaunchKernelGGL((sel_hist_kernel<1, BLOCK>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l);
 	hipLaunchKernelGGL((sel_hist_kernel<2, BLOCK>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l);
-	hipLaunchKernelGGL(sel_partition_kernel<BLOCK>, dim3(gchunks), dim3(BLOCK), 0, st, pos_in, unsort_in, pos_out, unsort_out, sd_l, nodes, ties, n, l);
-	hipLaunchKernelGGL(sel_ties_box_kernel, dim3(m), dim3(64), 0, st, pos_in, unsort_in, pos_out, unsort_out, lbound, rbound, splitdim, index, nodes,
-	                   (const uint32_t *)ties, flag, n, l);
+	hipLaunchKernelGGL(sel_partition_kernel<BLOCK>, dim3(gchunks), dim3(BLOCK), 0, st, pos_in, unsort_in, pos_out, unsort_out, sd_l, nodes, ties, n, l,
+	                   lbound, rbound, splitdim, index, flag);
 }
 
 int kd_select_level(nbco_ctx *c, int l, long long n, const float4 *pos_in, const int *unsort_in, float4 *pos_out, int *unsort_out,
