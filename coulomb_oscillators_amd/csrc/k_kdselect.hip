@@ -303,7 +303,6 @@ __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__re
 {
 	constexpr int CHUNK = 8 * BLOCK;
 	static_assert(CHUNK < 65536, "packed 16-bit block counters");
-	__shared__ uint64_t sh_wave[BLOCK / 64];
 	__shared__ uint32_t base_s[4], mR[2];
 	const long long m = 1LL << l;
 	const long long i0 = (long long)blockIdx.x * CHUNK;
@@ -329,20 +328,29 @@ __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__re
 		const long long i = i0 + e * BLOCK + threadIdx.x;
 		if (i < n) { p[e] = pos_in[i]; org[e] = unsort_in[i]; }
 	}
-	int cls[PER];   // 0 none / tie, 1 left, 2 right
-	uint64_t cnt = 0;
+	// Destination slots.  The four output streams of the chunk (left / right of its one or two nodes) are filled in
+	// element order: consecutive lanes with the same destination stream write consecutive slots, so the stores coalesce
+	// (per-thread cursors made every lane of a store instruction hit a different sector: twice the HBM write traffic).
+	// Per round e (one element per thread) and wave: four ballots give the lane's rank inside its stream and the wave's
+	// counts; an exclusive scan over the (round, wave) grid turns the counts into offsets.
+	constexpr int W = BLOCK / 64;
+	__shared__ uint64_t pw[PER * W + 1];   // four 16-bit counters per (round, wave); [PER * W] = block totals
+	const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const uint64_t below = (1ull << lane) - 1ull;
+	int cat[PER];          // -1 tie / nothing, else 2 * (second node ?) + (right ?)
+	uint32_t lp[PER];      // rank among the wave's elements of the same stream in this round
 	uint32_t tmin[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
 #pragma unroll
 	for (int e = 0; e < PER; ++e)
 	{
 		const long long i = i0 + e * BLOCK + threadIdx.x;
-		cls[e] = 0;
+		cat[e] = -1;
 		if (i < n)
 		{
 			const int jj = i >= split ? 1 : 0;
 			const uint32_t key = ordered_bits(axis_of(p[e], sd[jj]));
-			if (key < piv[jj] || (key == piv[jj] && all_left[jj])) { cls[e] = 1; cnt += 1ull << (32 * jj); }
-			else if (key > piv[jj]) { cls[e] = 2; cnt += 1ull << (32 * jj + 16); tmin[jj] = key < tmin[jj] ? key : tmin[jj]; }
+			if (key < piv[jj] || (key == piv[jj] && all_left[jj])) cat[e] = 2 * jj;
+			else if (key > piv[jj]) { cat[e] = 2 * jj + 1; tmin[jj] = key < tmin[jj] ? key : tmin[jj]; }
 			else
 			{
 				const uint32_t t = atomicAdd(&nodes[j0 + jj].tiecnt, 1u);
@@ -350,9 +358,33 @@ __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__re
 				if (t < kTieCap) __hip_atomic_store(&tielist[(size_t)(j0 + jj) * kTieCap + t], (uint32_t)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
 		}
+		uint64_t packed = 0;
+		lp[e] = 0;
+#pragma unroll
+		for (int q = 0; q < 4; ++q)
+		{
+			const uint64_t bq = __ballot(cat[e] == q);
+			packed |= (uint64_t)__popcll(bq) << (16 * q);
+			if (cat[e] == q) lp[e] = (uint32_t)__popcll(bq & below);
+		}
+		if (lane == 0) pw[e * W + wv] = packed;
 	}
-	uint64_t tot;
-	const uint64_t off = block_scan4<BLOCK>(cnt, sh_wave, tot);
+	__syncthreads();
+	if (threadIdx.x < 64)
+	{
+		// exclusive scan of the PER * W packed counters (two consecutive entries per lane)
+		constexpr int NE = PER * W;
+		const int k0 = 2 * lane, k1 = 2 * lane + 1;
+		const uint64_t v0 = k0 < NE ? pw[k0] : 0, v1 = k1 < NE ? pw[k1] : 0;
+		uint64_t incl = v0 + v1;
+		for (int o = 1; o < 64; o <<= 1) { const uint64_t y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+		const uint64_t excl = incl - (v0 + v1);
+		if (k0 < NE) pw[k0] = excl;
+		if (k1 < NE) pw[k1] = excl + v0;
+		if (lane == 63) pw[NE] = incl;
+	}
+	__syncthreads();
+	const uint64_t tot = pw[PER * W];
 	if (threadIdx.x < 4)
 	{
 		const int jj = threadIdx.x >> 1, right = threadIdx.x & 1;
@@ -364,27 +396,25 @@ __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__re
 	{
 		uint32_t v = tmin[q];
 		for (int o = 32; o > 0; o >>= 1) { const uint32_t y = __shfl_xor(v, o); v = y < v ? y : v; }
-		if ((threadIdx.x & 63) == 0 && v != 0xFFFFFFFFu) atomicMin(&mR[q], v);
+		if (lane == 0 && v != 0xFFFFFFFFu) atomicMin(&mR[q], v);
 	}
 	__syncthreads();
 	if (threadIdx.x < 2 && mR[threadIdx.x] != 0xFFFFFFFFu) atomicMax(&nodes[j0 + threadIdx.x].minR, ~mR[threadIdx.x]);
-	// destination cursors of this thread: [left0, right0, left1, right1]
-	long long cur[4];
+	// first slot of each stream: [left0, right0, left1, right1]
+	long long first[4];
 #pragma unroll
 	for (int q = 0; q < 4; ++q)
 	{
-		const int jj = q >> 1;
-		const long long j = j0 + jj;
-		const long long region = (q & 1) ? range_start(n, 2 * j + 1, 2 * m) : range_start(n, j, m);
-		cur[q] = region + base_s[q] + (long long)((off >> (16 * q)) & 0xFFFF);
+		const long long j = j0 + (q >> 1);
+		first[q] = ((q & 1) ? range_start(n, 2 * j + 1, 2 * m) : range_start(n, j, m)) + base_s[q];
 	}
 #pragma unroll
 	for (int e = 0; e < PER; ++e)
 	{
-		if (!cls[e]) continue;
-		const long long i = i0 + e * BLOCK + threadIdx.x;
-		const int q = (i >= split ? 2 : 0) + (cls[e] - 1);
-		const long long dst = q == 0 ? cur[0]++ : (q == 1 ? cur[1]++ : (q == 2 ? cur[2]++ : cur[3]++));
+		if (cat[e] < 0) continue;
+		const int q = cat[e];
+		const long long dst = (q == 0 ? first[0] : (q == 1 ? first[1] : (q == 2 ? first[2] : first[3])))
+		                      + (long long)((pw[e * W + wv] >> (16 * q)) & 0xFFFF) + lp[e];
 		pos_out[dst] = p[e];
 		unsort_out[dst] = org[e];
 	}
