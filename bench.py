@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--particles", dest="n", type=int, default=1048576, help="particles per GPU (not --n: torchrun would read that as an abbreviation of its own flags)")
     ap.add_argument("--order", type=int, default=6)
     ap.add_argument("--tree-steps", type=int, default=1)
-    ap.add_argument("--rebalance", type=int, default=8,
+    ap.add_argument("--rebalance", type=int, default=16,
                     help="multi-GPU: force evaluations between two re-partitions of the kd-domains (top log2(G) splits)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL (one rank per GPU); gloo = rehearsal with several ranks sharing one card")
