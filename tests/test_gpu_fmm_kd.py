@@ -241,3 +241,27 @@ def test_large_tree_bit_exact_selection_build(engine, oracle32, n, p, quant):
     for name in ("p2p", "m2l"):
         np.testing.assert_array_equal(canon_pairs(engine.kd_array(name)), canon_pairs(want[name]), err_msg=name)
     assert force_err(a, a_ref) < 1e-5
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 33, 100, 513, 4097, 8191, 8193, 12289])
+def test_edge_sizes(oracle32, n):
+    """sizes around every switch of the build (one-node trees, the 4096-particle LDS slice, the 8192-particle
+    workgroup switch of the selection levels), fresh evaluation and tree reuse"""
+    import torch
+    from coulomb_oscillators_amd import Engine, EVAL_FMM_KDTREE
+    o = oracle32
+    for p in (2, 6):
+        buf = o.init_reference(n)
+        if n == 1:    # the reference's centred / rms-normalised init is 0/0 for a single particle
+            buf[:] = 0
+            buf[0, 0] = (0.1, -0.2, 0.3)
+        par = o.params(n)
+        _, a_ref = o.fmm_kd(buf[:2], par, p=p, threads=4, unsort=True)
+        _, a = run_gpu(Engine(), buf, par, n, fmm_order=p, unsort=1)
+        assert force_err(a, a_ref) < 1e-5
+        e = Engine(fmm_order=p, unsort=0, tree_steps=3)
+        d = dev(buf)
+        for _ in range(4):
+            e.compute_force(EVAL_FMM_KDTREE, d, n, dev(par))
+        torch.cuda.synchronize()
+        assert torch.isfinite(d).all()
