@@ -41,12 +41,29 @@ class TorchComm:
             self.dist.all_gather_into_tensor(out, inp, group=self.group)
 
 
+    def all_reduce(self, t, op="sum"):
+        """in-place reduction of a small tensor of scalars (energies, bounds)"""
+        if self.world == 1:
+            return t
+        ops = {"sum": self.dist.ReduceOp.SUM, "min": self.dist.ReduceOp.MIN, "max": self.dist.ReduceOp.MAX}
+        if self.dist.get_backend(self.group) == "gloo" and t.is_cuda:
+            host = t.cpu()
+            self.dist.all_reduce(host, op=ops[op], group=self.group)
+            t.copy_(host)
+        else:
+            self.dist.all_reduce(t, op=ops[op], group=self.group)
+        return t
+
+
 class SingleComm:
     """world of one: the exchange degenerates to a copy (used by bench.py --gpus 1 style checks)."""
     world, rank = 1, 0
 
     def all_gather(self, out, inp):
         out.copy_(inp)
+
+    def all_reduce(self, t, op="sum"):
+        return t
 
 
 class DomainRun:
@@ -122,6 +139,22 @@ class DomainRun:
         self.local()
         self.exchange()
         self.finish(param, elastic)
+
+    # ---- reductions over all domains: a handful of scalars through an all-reduce -----------------
+    def minmax(self):
+        """component-wise bounds of all positions, (2, 3) tensor [min; max] (reductions.cuh:67-80)"""
+        mm = self.eng.minmax(self.pos, self.n_local).clone()
+        self.comm.all_reduce(mm[0], "min")
+        self.comm.all_reduce(mm[1], "max")
+        return mm
+
+    def energy(self, param):
+        """(kinetic, elastic) energy of the whole system.  The Coulomb part of nbco_energy is an O(N^2) diagnostic over
+        ONE buffer; for a sharded run gather the positions and evaluate it on one GPU."""
+        kin, ela, _ = self.eng.energy(self.buf, self.n_local, param)
+        t = torch.tensor([kin, ela], dtype=torch.float64, device=self.device)
+        self.comm.all_reduce(t, "sum")
+        return float(t[0]), float(t[1])
 
     # ---- kick-drift-kick leapfrog on the local state (integrator.cuh:68-80) --------------------------
     def leapfrog(self, param, dt, elastic=True, first=False):

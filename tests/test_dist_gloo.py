@@ -86,6 +86,16 @@ class NumpyDomainEngine:
         scale = float(param[0]) if param is not None else 1.0
         a_local.numpy()[:] = (acc * scale).astype(np.float32).reshape(-1)
 
+    def minmax(self, p, n):
+        q = p.numpy()[:3 * n].reshape(n, 3)
+        return torch.from_numpy(np.stack([q.min(0), q.max(0)]))
+
+    def energy(self, buf, n, param):
+        b = buf.numpy().astype(np.float64)
+        x, v = b[:3 * n].reshape(n, 3), b[3 * n:6 * n].reshape(n, 3)
+        k = param.numpy()[3:6].astype(np.float64)
+        return [0.5 * (v * v).sum(), 0.5 * (k * x * x).sum(), 0.0]
+
     def step(self, b, a, ds, n):
         b.numpy()[:3 * n] += np.float32(ds) * a.numpy()[:3 * n]
 
@@ -123,6 +133,9 @@ def _worker(rank, world, port, n, steps, dt, rebalance, outdir):
         run.partition(torch.from_numpy(pos[rank * nl:(rank + 1) * nl]).reshape(-1), torch.from_numpy(vel[rank * nl:(rank + 1) * nl]).reshape(-1))
         res = _drive(run, torch.from_numpy(par), steps, dt)
         np.save(os.path.join(outdir, "rank%d.npy" % rank), res)
+        mm = run.minmax().numpy()
+        kin, ela = run.energy(torch.from_numpy(par))
+        np.save(os.path.join(outdir, "scal%d.npy" % rank), np.concatenate([mm.ravel(), [kin, ela]]))
         with open(os.path.join(outdir, "calls%d.txt" % rank), "w") as f:
             f.write(" ".join(eng.calls))
         dist.barrier()
@@ -151,6 +164,13 @@ def test_domain_run_over_gloo_matches_single_process(world):
         mp.spawn(_worker, args=(world, _free_port(), n, steps, dt, rebalance, d), nprocs=world, join=True)
         got = np.concatenate([np.load(os.path.join(d, "rank%d.npy" % r)) for r in range(world)])
         calls = [open(os.path.join(d, "calls%d.txt" % r)).read().split() for r in range(world)]
+        scal = [np.load(os.path.join(d, "scal%d.npy" % r)) for r in range(world)]
+    # reductions over the domains: every rank holds the same global bounds and energies
+    for sc in scal:
+        np.testing.assert_array_equal(sc, scal[0])
+    np.testing.assert_allclose(scal[0][:3], ref[:, 0:3].min(0), rtol=1e-5)
+    np.testing.assert_allclose(scal[0][3:6], ref[:, 0:3].max(0), rtol=1e-5)
+    np.testing.assert_allclose(scal[0][6], 0.5 * (ref[:, 3:6].astype(np.float64) ** 2).sum(), rtol=1e-4)
     # same particles, same trajectories (the summation order differs: float64 inside, so ~1 ulp of float32)
     ka, kb = np.argsort(got[:, 0]), np.argsort(ref[:, 0])
     np.testing.assert_allclose(got[ka], ref[kb], rtol=2e-5, atol=2e-6)
