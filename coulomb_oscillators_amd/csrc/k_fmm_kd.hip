@@ -1639,7 +1639,8 @@ static int kd_reserve_particles(nbco_ctx *c, long long n)
 // root6 (device, {lbound, rbound}) overrides the root box: the box of a kd-domain is inherited from the
 // global tree's top splits.  On return c->pos4 / c->unsort hold the tree-ordered positions and the map
 // back to the caller's order.
-static int kd_build_upward(nbco_ctx *c, const float *p, long long n, int L, const float *root6, bool &rebuild)
+// stage: 0 = build + upward, 1 = build only, 2 = upward only (of the tree built by the previous stage-1 call)
+static int kd_build_upward(nbco_ctx *c, const float *p, long long n, int L, const float *root6, bool &rebuild, int stage = 0)
 {
 	const int P = c->o.fmm_order;
 	DevTables tb;
@@ -1647,19 +1648,21 @@ static int kd_build_upward(nbco_ctx *c, const float *p, long long n, int L, cons
 	const int ntot = (1 << (L + 1)) - 1, nleaf = 1 << L;
 	const int mlt_max = (int)((n - 1) / nleaf + 1);
 	hipStream_t st = c->stream;
-	NBCO_TRY(c->join_aux());   // e.g. the multipole chain of an evaluation that is being redone
+	if (stage != 2)
 	{
+		NBCO_TRY(c->join_aux());   // e.g. the multipole chain of an evaluation that is being redone
 		KdTreeDev &k = c->kd;
 		NBCO_TRY(kd_carve(c, c->treebuf, k, ntot, tb.offM, tb.offL));
 		const bool topo_change = k.L != L || k.ntot != ntot || k.order != P || k.n != n;
 		if (topo_change) c->tree_valid = false;
 		k.L = L; k.ntot = ntot; k.order = P; k.mlt_max = mlt_max; k.n = n;
+		NBCO_TRY(kd_reserve_particles(c, n));
+		rebuild = c->o.unsort || !c->tree_valid || (c->eval_counter % c->o.tree_steps) == 0;
 	}
-	NBCO_TRY(kd_reserve_particles(c, n));
 	TreeView tv = view_of(c->kd);
 	float4 *pos = c->pos4.as<float4>(), *pos_alt = c->pos4_alt.as<float4>();
 	int *unsort = c->unsort.as<int>(), *unsort_alt = c->unsort_alt.as<int>();
-	rebuild = c->o.unsort || !c->tree_valid || (c->eval_counter % c->o.tree_steps) == 0;
+	if (stage != 2)
 	{
 		PhaseScope ph(c, NBCO_PH_BUILD);
 		if (rebuild)
@@ -1700,6 +1703,7 @@ static int kd_build_upward(nbco_ctx *c, const float *p, long long n, int L, cons
 		hipLaunchKernelGGL(kd_leaf_kernel, dim3(grid1d(nleaf)), dim3(kBlock), 0, st, tv, pos, n);
 		NBCO_HIP(hipGetLastError());
 	}
+	if (stage == 1) return NBCO_OK;
 	if (P <= 8)
 	{
 		// centres of all nodes first (2 launches): that is all the traversal needs, so the multipole chain
@@ -2133,6 +2137,9 @@ int kd_dist_partition(nbco_ctx *c, const float *state_all, long long n_global, i
 	return NBCO_OK;
 }
 
+// stage 1 (pos_send != null): subtree build, tree-ordered positions into pos_send; stage 2 (nodes_send != null): upward
+// pass, node block into nodes_send.  Both pointers: the whole local stage.  The split lets the caller start the all-gather
+// of the positions while the multipoles are still being computed.
 int kd_dist_local(nbco_ctx *c, float *buf_local, long long n_local, void *nodes_send, void *pos_send)
 {
 	if (!c->dist.partitioned || n_local != c->dist.n_local)
@@ -2143,33 +2150,43 @@ int kd_dist_local(nbco_ctx *c, float *buf_local, long long n_local, void *nodes_
 	if (lay.L != c->dist.L) return c->fail(NBCO_ERR_ARG, "nbco_dist_local: options changed since nbco_dist_partition");
 	const int d = lay.d, ntop = (1 << (d + 1)) - 1;
 	hipStream_t st = c->stream;
-	TopView top = top_view(c, ntop);
-	float *root6 = c->small.as<float>() + 80;
-	hipLaunchKernelGGL(dist_root6_kernel, dim3(1), dim3(64), 0, st, (const float *)top.lbound, (const float *)top.rbound, (1 << d) - 1 + lay.rank, root6);
-	bool rebuild = false;
-	NBCO_TRY(kd_build_upward(c, buf_local, n_local, lay.L_local, root6, rebuild));
-	if (rebuild && !c->force_sort_build)
+	bool rebuild = c->dist.rebuilt;
+	if (pos_send)
 	{
-		// A tie overflow of the selection build has to be caught BEFORE the exchange (the other domains are
-		// about to consume these nodes); the retry with the sorting build is purely local.
-		int flag = 0;
-		NBCO_HIP(hipMemcpyAsync(&flag, c->counters.as<int>() + 110, sizeof(int), hipMemcpyDeviceToHost, st));
-		NBCO_HIP(hipStreamSynchronize(st));
-		if (flag)
+		TopView top = top_view(c, ntop);
+		float *root6 = c->small.as<float>() + 80;
+		hipLaunchKernelGGL(dist_root6_kernel, dim3(1), dim3(64), 0, st, (const float *)top.lbound, (const float *)top.rbound, (1 << d) - 1 + lay.rank, root6);
+		NBCO_TRY(kd_build_upward(c, buf_local, n_local, lay.L_local, root6, rebuild, 1));
+		if (rebuild && !c->force_sort_build)
 		{
-			c->force_sort_build = true;
-			c->tree_valid = false;
-			NBCO_TRY(kd_build_upward(c, buf_local, n_local, lay.L_local, root6, rebuild));
+			// A tie overflow of the selection build has to be caught BEFORE the exchange (the other domains are
+			// about to consume these positions and nodes); the retry with the sorting build is purely local.
+			int flag = 0;
+			NBCO_HIP(hipMemcpyAsync(&flag, c->counters.as<int>() + 110, sizeof(int), hipMemcpyDeviceToHost, st));
+			NBCO_HIP(hipStreamSynchronize(st));
+			if (flag)
+			{
+				c->force_sort_build = true;
+				c->tree_valid = false;
+				NBCO_TRY(kd_build_upward(c, buf_local, n_local, lay.L_local, root6, rebuild, 1));
+			}
 		}
+		c->dist.rebuilt = rebuild;
+		NBCO_HIP(hipMemcpyAsync(pos_send, c->pos4.ptr, sizeof(float4) * (size_t)n_local, hipMemcpyDeviceToDevice, st));
+		c->dist.build_done = true;
 	}
-	c->dist.rebuilt = rebuild;
-	NBCO_TRY(c->join_aux());   // the multipoles are about to leave the GPU
-	const int offM = sym_off(lay.order);
-	NBCO_HIP(hipMemcpyAsync(nodes_send, c->kd.csz, sizeof(float4) * (size_t)lay.ntot_local, hipMemcpyDeviceToDevice, st));
-	NBCO_HIP(hipMemcpyAsync((char *)nodes_send + sizeof(float4) * (size_t)lay.ntot_local, c->kd.mpole, sizeof(float) * (size_t)lay.ntot_local * offM,
-	                        hipMemcpyDeviceToDevice, st));
-	NBCO_HIP(hipMemcpyAsync(pos_send, c->pos4.ptr, sizeof(float4) * (size_t)n_local, hipMemcpyDeviceToDevice, st));
-	c->dist.local_done = true;
+	if (nodes_send)
+	{
+		if (!c->dist.build_done) return c->fail(NBCO_ERR_ARG, "nbco_dist_local_upward: the build stage has not run");
+		c->dist.build_done = false;
+		NBCO_TRY(kd_build_upward(c, buf_local, n_local, lay.L_local, nullptr, rebuild, 2));
+		NBCO_TRY(c->join_aux());   // the multipoles are about to leave the GPU
+		const int offM = sym_off(lay.order);
+		NBCO_HIP(hipMemcpyAsync(nodes_send, c->kd.csz, sizeof(float4) * (size_t)lay.ntot_local, hipMemcpyDeviceToDevice, st));
+		NBCO_HIP(hipMemcpyAsync((char *)nodes_send + sizeof(float4) * (size_t)lay.ntot_local, c->kd.mpole, sizeof(float) * (size_t)lay.ntot_local * offM,
+		                        hipMemcpyDeviceToDevice, st));
+		c->dist.local_done = true;
+	}
 	return NBCO_OK;
 }
 

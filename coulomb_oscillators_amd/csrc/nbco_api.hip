@@ -305,6 +305,18 @@ int nbco_dist_local(nbco_ctx *c, float *buf_local, long long n_local, void *node
 	NBCO_TRY(kd_dist_local(c, buf_local, n_local, nodes_send, pos_send));
 	return maybe_sync(c);
 }
+int nbco_dist_local_build(nbco_ctx *c, float *buf_local, long long n_local, void *pos_send)
+{
+	if (!c || !buf_local || !pos_send) return c ? c->fail(NBCO_ERR_ARG, "nbco_dist_local_build: null pointer") : NBCO_ERR_ARG;
+	NBCO_TRY(kd_dist_local(c, buf_local, n_local, nullptr, pos_send));
+	return maybe_sync(c);
+}
+int nbco_dist_local_upward(nbco_ctx *c, float *buf_local, long long n_local, void *nodes_send)
+{
+	if (!c || !buf_local || !nodes_send) return c ? c->fail(NBCO_ERR_ARG, "nbco_dist_local_upward: null pointer") : NBCO_ERR_ARG;
+	NBCO_TRY(kd_dist_local(c, buf_local, n_local, nodes_send, nullptr));
+	return maybe_sync(c);
+}
 int nbco_dist_finish(nbco_ctx *c, const void *nodes_all, const void *pos_all, float *buf_local, float *a_local, const float *param)
 {
 	if (!c || !nodes_all || !pos_all || !buf_local || !a_local) return c ? c->fail(NBCO_ERR_ARG, "nbco_dist_finish: null pointer") : NBCO_ERR_ARG;

@@ -120,7 +120,7 @@ struct nbco_ctx
 	{
 		int world = 0, rank = 0, d = 0, L = 0;
 		long long n_global = 0, n_local = 0;
-		bool partitioned = false, local_done = false, rebuilt = false;
+		bool partitioned = false, build_done = false, local_done = false, rebuilt = false;
 	} dist;
 	bool force_sort_build = false;          // set after a tie overflow: use the sorting build from then on
 	long long list_cap = 0;

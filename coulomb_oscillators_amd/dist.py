@@ -19,6 +19,11 @@ one-directionally on the owner of the target.
 import torch
 
 
+class _Done:
+    def wait(self):
+        return True
+
+
 class TorchComm:
     """all-gather over a torch.distributed process group (one rank per GPU)."""
 
@@ -41,6 +46,13 @@ class TorchComm:
             self.dist.all_gather_into_tensor(out, inp, group=self.group)
 
 
+    def all_gather_start(self, out, inp):
+        """all_gather that returns at once; .wait() on the result orders the CURRENT stream behind the collective"""
+        if self.world == 1 or (self.dist.get_backend(self.group) == "gloo" and inp.is_cuda):
+            self.all_gather(out, inp)
+            return _Done()
+        return self.dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True)
+
     def all_reduce(self, t, op="sum"):
         """in-place reduction of a small tensor of scalars (energies, bounds)"""
         if self.world == 1:
@@ -61,6 +73,10 @@ class SingleComm:
 
     def all_gather(self, out, inp):
         out.copy_(inp)
+
+    def all_gather_start(self, out, inp):
+        out.copy_(inp)
+        return _Done()
 
     def all_reduce(self, t, op="sum"):
         return t
@@ -136,8 +152,17 @@ class DomainRun:
     def force(self, param=None, elastic=True):
         if self.rebalance > 0 and self.evals >= self.rebalance:
             self.partition()
-        self.local()
-        self.exchange()
+        if hasattr(self.eng, "dist_local_build") and hasattr(self.comm, "all_gather_start"):
+            # the positions travel while the multipoles are still being computed
+            self.eng.dist_local_build(self.buf, self.n_local, self.pos_send)
+            h_pos = self.comm.all_gather_start(self.pos_all, self.pos_send)
+            self.eng.dist_local_upward(self.buf, self.n_local, self.nodes_send)
+            h_nodes = self.comm.all_gather_start(self.nodes_all, self.nodes_send)
+            h_pos.wait()
+            h_nodes.wait()
+        else:
+            self.local()
+            self.exchange()
         self.finish(param, elastic)
 
     # ---- reductions over all domains: a handful of scalars through an all-reduce -----------------

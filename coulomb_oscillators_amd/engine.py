@@ -111,6 +111,8 @@ def _load():
         "nbco_dist_layout_query": [P, LL, I, I, C.POINTER(DistLayout)],
         "nbco_dist_partition": [P, P, LL, I, I, P],
         "nbco_dist_local": [P, P, LL, P, P],
+        "nbco_dist_local_build": [P, P, LL, P],
+        "nbco_dist_local_upward": [P, P, LL, P],
         "nbco_dist_finish": [P, P, P, P, P, P],
         "nbco_profile_enable": [P, I],
         "nbco_profile_reset": [P],
@@ -260,6 +262,12 @@ class Engine:
 
     def dist_local(self, buf_local, n_local, nodes_send, pos_send):
         self._chk(self.lib.nbco_dist_local(self.ctx, _ptr(buf_local), n_local, _ptr(nodes_send), _ptr(pos_send)))
+
+    def dist_local_build(self, buf_local, n_local, pos_send):
+        self._chk(self.lib.nbco_dist_local_build(self.ctx, _ptr(buf_local), n_local, _ptr(pos_send)))
+
+    def dist_local_upward(self, buf_local, n_local, nodes_send):
+        self._chk(self.lib.nbco_dist_local_upward(self.ctx, _ptr(buf_local), n_local, _ptr(nodes_send)))
 
     def dist_finish(self, nodes_all, pos_all, buf_local, a_local, param=None):
         self._chk(self.lib.nbco_dist_finish(self.ctx, _ptr(nodes_all), _ptr(pos_all), _ptr(buf_local), _ptr(a_local), _ptr(param)))

@@ -189,6 +189,10 @@ typedef struct nbco_dist_layout {
 int nbco_dist_layout_query(nbco_ctx *c, long long n_global, int world, int rank, nbco_dist_layout *out);
 int nbco_dist_partition(nbco_ctx *c, const float *state_all, long long n_global, int world, int rank, float *state_local);
 int nbco_dist_local(nbco_ctx *c, float *buf_local, long long n_local, void *nodes_send, void *pos_send);
+/* nbco_dist_local in two halves, so that the all-gather of the positions can run beside the upward pass:
+ * _build fills pos_send (subtree build), _upward fills nodes_send (multipoles). */
+int nbco_dist_local_build(nbco_ctx *c, float *buf_local, long long n_local, void *pos_send);
+int nbco_dist_local_upward(nbco_ctx *c, float *buf_local, long long n_local, void *nodes_send);
 int nbco_dist_finish(nbco_ctx *c, const void *nodes_all, const void *pos_all, float *buf_local, float *a_local,
                      const float *param);
 
