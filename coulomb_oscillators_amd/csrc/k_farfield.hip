@@ -1,4 +1,4 @@
-// k_farfield.hip -- register-resident P2M / M2M / L2L / L2P for the kd-tree FMM, orders 1..8.
+// k_farfield.hip -- register-resident P2M / M2M / L2L / L2P for the kd-tree FMM, orders 1..10 (the highest orders spill part of their tensors to scratch).
 // Reference drivers: fmm_multipoleLeaves3_kdtree (fmm_cart3_kdtree.cuh:231-250), fmm_buildTree3_kdtree2
 // (:328-368), fmm_pushl3_kdtree (:1134-1194), fmm_pushLeaves3_kdtree (:1227-1275).  One THREAD per leaf /
 // node / particle runs a generated straight-line body (fmm_ops_gen.inc, see gen_ops.py): all tensor
@@ -432,7 +432,8 @@ static int run_l2p(nbco_ctx *c, const float4 *pos, const float *center, const fl
 	{                                                                                  \
 	case 1: return CALL(1); case 2: return CALL(2); case 3: return CALL(3); case 4: return CALL(4); \
 	case 5: return CALL(5); case 6: return CALL(6); case 7: return CALL(7); case 8: return CALL(8); \
-	default: return c->fail(NBCO_ERR_UNSUPPORTED, "generated far-field operators exist for orders 1..8"); \
+	case 9: return CALL(9); case 10: return CALL(10);                                                \
+	default: return c->fail(NBCO_ERR_UNSUPPORTED, "generated far-field operators exist for orders 1..10"); \
 	}
 
 // centres + multiplicities of all internal nodes from the leaves' (2 launches)

@@ -39,31 +39,6 @@ namespace {
 using fmmtab::sym_off;
 using fmmtab::tl_off;
 
-struct DevTables
-{
-	int P, offM, offL, nfull;
-	const uint32_t *sym_xyz, *mono_rec;
-	const float *p2m_coef;
-	const int *m2m_start;
-	const uint32_t *m2m_idx;
-	const float *m2m_coef;
-	const int *tl2full, *tl_order;
-	const int *gp_start;
-	const uint32_t *gp_exp;
-	const float *gp_coef;
-	const int *rf_start;
-	const uint32_t *rf_dst, *rf_a, *rf_b;
-	const int *m2l_start;
-	const uint32_t *m2l_idx;
-	const float *m2l_coef;
-	const int *m_order;
-	const int *l2l_start;
-	const uint32_t *l2l_idx;
-	const float *l2l_coef;
-	const float *l2p_coef;
-	const uint32_t *l2p_idx;
-};
-
 struct TreeView
 {
 	float *center, *lbound, *rbound;
@@ -97,12 +72,6 @@ __host__ __device__ inline bool dom_touch(const Dom dm, int node)
 	return l >= dm.d ? (pos >> (l - dm.d)) == dm.g : (dm.g >> (dm.d - l)) == pos;
 }
 
-__device__ inline float powi(float b, int e)
-{
-	float r = 1.f;
-	for (int i = 0; i < e; ++i) r *= b;
-	return r;
-}
 
 // ---- tree geometry: every function below must round exactly like the oracle ---------------------
 #pragma clang fp contract(off)
@@ -826,80 +795,6 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 
 #pragma clang fp contract(fast)
 
-// ---- P2M / M2M -------------------------------------------------------------------------------------
-
-// one wave per leaf, one lane per multipole component (fmm_cart3_kdtree.cuh:231-250)
-__global__ __launch_bounds__(64) void p2m_kernel(TreeView t, DevTables tb, const float4 *__restrict__ pos)
-{
-	const int leaf = kd_beg(t.L) + blockIdx.x, lane = threadIdx.x;
-	const int mlt = t.mult[leaf], ind = t.index[leaf];
-	const float cx = t.center[3 * leaf], cy = t.center[3 * leaf + 1], cz = t.center[3 * leaf + 2];
-	for (int comp = lane; comp < tb.offM; comp += 64)
-	{
-		uint32_t e = tb.sym_xyz[comp];
-		int q = e & 0xFF, x = (e >> 8) & 0xFF, y = (e >> 16) & 0xFF, z = (e >> 24) & 0xFF;
-		float coef = tb.p2m_coef[comp], acc = 0.f;
-		if (q >= 2)
-			for (int j = 0; j < mlt; ++j)
-			{
-				float4 p = pos[ind + j];
-				acc = fmaf(coef, powi(p.x - cx, x) * powi(p.y - cy, y) * powi(p.z - cz, z), acc);
-			}
-		if (comp == 0) acc = (float)mlt;
-		t.mpole[(size_t)leaf * tb.offM + comp] = acc;
-	}
-}
-
-// one wave per parent at level l (fmm_cart3_kdtree.cuh:328-368)
-__global__ __launch_bounds__(64) void m2m_kernel(TreeView t, DevTables tb, int l)
-{
-	__shared__ float D[224], Mc[224];
-	const int k = kd_beg(l) + blockIdx.x, lane = threadIdx.x;
-	float c[3];
-	int mlt;
-	parent_centre(t, k, c, mlt);
-	float acc[4] = {0.f, 0.f, 0.f, 0.f};
-	for (int ch = 0; ch < 2; ++ch)
-	{
-		const int child = 2 * k + 1 + ch;
-		const float dx = c[0] - t.center[3 * child], dy = c[1] - t.center[3 * child + 1], dz = c[2] - t.center[3 * child + 2];
-		for (int i = lane; i < tb.offM; i += 64)
-		{
-			uint32_t e = tb.sym_xyz[i];
-			D[i] = powi(dx, (e >> 8) & 0xFF) * powi(dy, (e >> 16) & 0xFF) * powi(dz, (e >> 24) & 0xFF);
-			Mc[i] = t.mpole[(size_t)child * tb.offM + i];
-		}
-		__syncthreads();
-#pragma unroll
-		for (int s = 0; s < 4; ++s)
-		{
-			int comp = lane + 64 * s;
-			if (comp < tb.offM)
-			{
-				float a = 0.f;
-				for (int e = tb.m2m_start[comp]; e < tb.m2m_start[comp + 1]; ++e)
-				{
-					uint32_t ix = tb.m2m_idx[e];
-					a = fmaf(tb.m2m_coef[e] * D[ix & 0xFFFF], Mc[ix >> 16], a);
-				}
-				acc[s] += a;
-			}
-		}
-		__syncthreads();
-	}
-#pragma unroll
-	for (int s = 0; s < 4; ++s)
-	{
-		int comp = lane + 64 * s;
-		if (comp < tb.offM) t.mpole[(size_t)k * tb.offM + comp] = comp == 0 ? (float)mlt : acc[s];
-	}
-	if (lane == 0)
-	{
-		t.center[3 * k] = c[0]; t.center[3 * k + 1] = c[1]; t.center[3 * k + 2] = c[2];
-		t.mult[k] = mlt;
-	}
-}
-
 // ---- dual tree traversal -----------------------------------------------------------------------------
 // counters: [0] p2p count, [1] m2l count, [2] overflow flag, [4 + it] frontier size of iteration it
 
@@ -1281,172 +1176,6 @@ __global__ __launch_bounds__(kBlock) void p2p_chunk_fill_kernel(const int *__res
 	}
 }
 
-// ---- M2L ---------------------------------------------------------------------------------------------
-// One wave per target node; for every source of its sorted list: dimensionless gradient tensors
-// G^_m(u) (lanes over the 2m+1 independent components, then the traceless refinement passes), source
-// multipoles pre-scaled by r^-k, contraction by term table, post-scale r^-(n+1).
-// (fmm_cart3_kdtree.cuh:613-671 host branch; fmm_cart_base3.cuh:1181-1208, :698-729, :611-623, :378-426)
-__global__ __launch_bounds__(64) void m2l_kernel(TreeView t, DevTables tb, const uint64_t *__restrict__ keys, const int *__restrict__ start,
-                                                 int shift, float eps2)
-{
-	__shared__ float Ms[224], F[288], pw[3][12];
-	const int tgt = blockIdx.x, lane = threadIdx.x;
-	const int s_beg = start[tgt], s_end = start[tgt + 1];
-	const uint64_t mask = (1ull << shift) - 1;
-	const float4 ct = t.csz[tgt];
-	float acc[2] = {0.f, 0.f};
-	for (int s = s_beg; s < s_end; ++s)
-	{
-		const int src = (int)(keys[s] & mask);
-		const float4 cs = t.csz[src];
-		float dx = ct.x - cs.x, dy = ct.y - cs.y, dz = ct.z - cs.z;
-		const float r = sqrtf(dx * dx + dy * dy + dz * dz + eps2);
-		const float rinv = 1.f / r;
-		dx *= rinv; dy *= rinv; dz *= rinv;
-		__syncthreads();   // previous source's Ms / F fully consumed
-		for (int i = lane; i < tb.offM; i += 64) Ms[i] = t.mpole[(size_t)src * tb.offM + i] * powi(rinv, tb.m_order[i]);
-		if (lane < 3 * 12)
-		{
-			int a = lane / 12, e = lane % 12;
-			if (e <= tb.P) pw[a][e] = powi(a == 0 ? dx : (a == 1 ? dy : dz), e);
-		}
-		__syncthreads();
-		for (int e = 1 + lane; e < tb.offL; e += 64)
-		{
-			float v = 0.f;
-			for (int k = tb.gp_start[e]; k < tb.gp_start[e + 1]; ++k)
-			{
-				uint32_t x = tb.gp_exp[k];
-				v = fmaf(tb.gp_coef[k], pw[0][x & 0xFF] * pw[1][(x >> 8) & 0xFF] * pw[2][(x >> 16) & 0xFF], v);
-			}
-			F[tb.tl2full[e]] = v;
-		}
-		__syncthreads();
-		for (int z = 2; z <= tb.P; ++z)
-		{
-			for (int e = tb.rf_start[z] + lane; e < tb.rf_start[z + 1]; e += 64) F[tb.rf_dst[e]] = -(F[tb.rf_a[e]] + F[tb.rf_b[e]]);
-			__syncthreads();
-		}
-#pragma unroll
-		for (int q = 0; q < 2; ++q)
-		{
-			int o = lane + 64 * q;
-			if (o >= 1 && o < tb.offL)
-			{
-				float a = 0.f;
-				for (int e = tb.m2l_start[o]; e < tb.m2l_start[o + 1]; ++e)
-				{
-					uint32_t ix = tb.m2l_idx[e];
-					a = fmaf(tb.m2l_coef[e] * Ms[ix & 0xFFFF], F[ix >> 16], a);
-				}
-				acc[q] = fmaf(a, powi(rinv, tb.tl_order[o] + 1), acc[q]);
-			}
-		}
-	}
-#pragma unroll
-	for (int q = 0; q < 2; ++q)
-	{
-		int o = lane + 64 * q;
-		if (o < tb.offL) t.local[(size_t)tgt * tb.offL + o] = acc[q];
-	}
-}
-
-// ---- L2L ---------------------------------------------------------------------------------------------
-// one wave per child node at level l+1 (fmm_cart3_kdtree.cuh:1171-1194; operator fmm_cart_base3.cuh:1348-1363)
-__global__ __launch_bounds__(64) void l2l_kernel(TreeView t, DevTables tb, int lchild)
-{
-	__shared__ float F[288], D[224];
-	const int c = kd_beg(lchild) + blockIdx.x, p = (c - 1) >> 1, lane = threadIdx.x;
-	const float dx = t.center[3 * c] - t.center[3 * p], dy = t.center[3 * c + 1] - t.center[3 * p + 1], dz = t.center[3 * c + 2] - t.center[3 * p + 2];
-	for (int e = 1 + lane; e < tb.offL; e += 64) F[tb.tl2full[e]] = t.local[(size_t)p * tb.offL + e];
-	for (int i = lane; i < tb.offM; i += 64)
-	{
-		uint32_t e = tb.sym_xyz[i];
-		D[i] = powi(dx, (e >> 8) & 0xFF) * powi(dy, (e >> 16) & 0xFF) * powi(dz, (e >> 24) & 0xFF);
-	}
-	__syncthreads();
-	for (int z = 2; z <= tb.P; ++z)
-	{
-		for (int e = tb.rf_start[z] + lane; e < tb.rf_start[z + 1]; e += 64) F[tb.rf_dst[e]] = -(F[tb.rf_a[e]] + F[tb.rf_b[e]]);
-		__syncthreads();
-	}
-	for (int o = 1 + lane; o < tb.offL; o += 64)
-	{
-		float a = 0.f;
-		for (int e = tb.l2l_start[o]; e < tb.l2l_start[o + 1]; ++e)
-		{
-			uint32_t ix = tb.l2l_idx[e];
-			a = fmaf(tb.l2l_coef[e] * F[ix & 0xFFFF], D[ix >> 16], a);
-		}
-		t.local[(size_t)c * tb.offL + o] += a;
-	}
-}
-
-// ---- L2P + finish ------------------------------------------------------------------------------------
-// one wave per leaf, one lane per particle (fmm_cart3_kdtree.cuh:1255-1275; operator
-// fmm_cart_base3.cuh:1511-1529); adds the near-field sum, applies rescale (appel.cuh:506-512) and writes
-// either in tree order or scattered back to the caller's order (fmm_cart3_kdtree.cuh:1746-1754)
-__global__ __launch_bounds__(64) void l2p_kernel(TreeView t, DevTables tb, const float4 *__restrict__ pos, const float4 *__restrict__ near,
-                                                 const int *__restrict__ chunk_off, int mlt_max, const int *__restrict__ unsort,
-                                                 int scatter, const float *__restrict__ param, float *__restrict__ a_out, int have_near)
-{
-	extern __shared__ float lds[];
-	float *F = lds;                       // nfull
-	float *mono = lds + 288;              // [offM][64]
-	const int leaf = kd_beg(t.L) + blockIdx.x, lane = threadIdx.x;
-	const int mlt = t.mult[leaf], ind = t.index[leaf];
-	const float cx = t.center[3 * leaf], cy = t.center[3 * leaf + 1], cz = t.center[3 * leaf + 2];
-	const float scale = param ? param[0] : 1.f;
-	for (int e = 1 + lane; e < tb.offL; e += 64) F[tb.tl2full[e]] = t.local[(size_t)leaf * tb.offL + e];
-	__syncthreads();
-	for (int z = 2; z <= tb.P; ++z)
-	{
-		for (int e = tb.rf_start[z] + lane; e < tb.rf_start[z + 1]; e += 64) F[tb.rf_dst[e]] = -(F[tb.rf_a[e]] + F[tb.rf_b[e]]);
-		__syncthreads();
-	}
-	for (int jb = 0; jb < mlt; jb += 64)
-	{
-		const int j = jb + lane;
-		if (j < mlt)
-		{
-			const float4 p = pos[ind + j];
-			const float d[3] = {p.x - cx, p.y - cy, p.z - cz};
-			float fx = 0.f, fy = 0.f, fz = 0.f;
-			mono[lane] = 1.f;
-			for (int k = 0; k < tb.offM; ++k)
-			{
-				float m;
-				if (k == 0) m = 1.f;
-				else
-				{
-					uint32_t rec = tb.mono_rec[k];
-					int ax = (rec >> 16) & 3;
-					m = mono[(rec & 0xFFFF) * 64 + lane] * (ax == 0 ? d[0] : (ax == 1 ? d[1] : d[2]));
-					mono[k * 64 + lane] = m;
-				}
-				const float cm = tb.l2p_coef[k] * m;
-				const uint32_t ix = tb.l2p_idx[k];
-				fx = fmaf(-cm, F[ix & 0x3FF], fx);
-				fy = fmaf(-cm, F[(ix >> 10) & 0x3FF], fy);
-				fz = fmaf(-cm, F[(ix >> 20) & 0x3FF], fz);
-			}
-			if (have_near)
-			{
-				// near field: the leaf's P2P chunks in list order
-				float nx = 0.f, ny = 0.f, nz = 0.f;
-				for (int ck = chunk_off[blockIdx.x]; ck < chunk_off[blockIdx.x + 1]; ++ck)
-				{
-					const float4 nr = near[(size_t)ck * mlt_max + j];
-					nx += nr.x; ny += nr.y; nz += nr.z;
-				}
-				fx += nx; fy += ny; fz += nz;
-			}
-			const long long o = scatter ? (long long)unsort[ind + j] : (long long)(ind + j);
-			a_out[3 * o] = fx * scale; a_out[3 * o + 1] = fy * scale; a_out[3 * o + 2] = fz * scale;
-		}
-	}
-}
-
 // sorted positions back to xyz triplets; velocities gathered into tree order
 __global__ __launch_bounds__(kBlock) void unpack4_kernel(const float4 *__restrict__ src, float *__restrict__ dst, long long n)
 {
@@ -1465,6 +1194,9 @@ static int grid1d(long long n, int cap = 2048)
 	return (int)b;
 }
 
+
+// ---- host side ----------------------------------------------------------------------------------------
+
 // kd levels, fmm_cart3_kdtree.cuh:1502-1515 (GPU driver honours tree_L; the CPU driver's formula is the same otherwise)
 static int kd_levels(long long n, int p, float dens_inhom, int tree_L)
 {
@@ -1478,45 +1210,6 @@ static int kd_levels(long long n, int p, float dens_inhom, int tree_L)
 	L = std::max(2, std::min(30, L));
 	while ((1LL << L) > n) --L;
 	return L;
-}
-
-static int ensure_tables(nbco_ctx *c, DevTables &dt)
-{
-	const int P = c->o.fmm_order;
-	static thread_local fmmtab::Packed packed;
-	static thread_local int packed_order = 0;
-	if (c->tables_order != P)
-	{
-		fmmtab::Tables t = fmmtab::build(P);
-		packed = fmmtab::pack(t);
-		packed_order = P;
-		size_t bi = packed.ints.size() * 4, bf = packed.floats.size() * 4;
-		NBCO_TRY(c->reserve(c->tables, bi + bf + 64));
-		NBCO_HIP(hipMemcpyAsync(c->tables.ptr, packed.ints.data(), bi, hipMemcpyHostToDevice, c->stream));
-		NBCO_HIP(hipMemcpyAsync((char *)c->tables.ptr + bi, packed.floats.data(), bf, hipMemcpyHostToDevice, c->stream));
-		NBCO_HIP(hipStreamSynchronize(c->stream));
-		c->tables_order = P;
-		c->h_tab_off = {packed.o_sym_xyz, packed.o_mono_rec, packed.o_m2m_start, packed.o_m2m_idx, packed.o_tl2full, packed.o_tl_order,
-		                packed.o_gp_start, packed.o_gp_exp, packed.o_rf_start, packed.o_rf_dst, packed.o_rf_a, packed.o_rf_b,
-		                packed.o_m2l_start, packed.o_m2l_idx, packed.o_m_order, packed.o_l2l_start, packed.o_l2l_idx, packed.o_l2p_idx,
-		                (int)packed.ints.size(), packed.f_p2m_coef, packed.f_m2m_coef, packed.f_gp_coef, packed.f_m2l_coef,
-		                packed.f_l2l_coef, packed.f_l2p_coef};
-	}
-	(void)packed_order;
-	const int32_t *I = c->tables.as<int32_t>();
-	const std::vector<int> &o = c->h_tab_off;
-	const float *Fp = (const float *)(I + o[18]);
-	dt.P = P; dt.offM = sym_off(P); dt.offL = tl_off(P + 1); dt.nfull = sym_off(P + 1);
-	dt.sym_xyz = (const uint32_t *)(I + o[0]); dt.mono_rec = (const uint32_t *)(I + o[1]);
-	dt.m2m_start = I + o[2]; dt.m2m_idx = (const uint32_t *)(I + o[3]);
-	dt.tl2full = I + o[4]; dt.tl_order = I + o[5];
-	dt.gp_start = I + o[6]; dt.gp_exp = (const uint32_t *)(I + o[7]);
-	dt.rf_start = I + o[8]; dt.rf_dst = (const uint32_t *)(I + o[9]); dt.rf_a = (const uint32_t *)(I + o[10]); dt.rf_b = (const uint32_t *)(I + o[11]);
-	dt.m2l_start = I + o[12]; dt.m2l_idx = (const uint32_t *)(I + o[13]); dt.m_order = I + o[14];
-	dt.l2l_start = I + o[15]; dt.l2l_idx = (const uint32_t *)(I + o[16]); dt.l2p_idx = (const uint32_t *)(I + o[17]);
-	dt.p2m_coef = Fp + o[19]; dt.m2m_coef = Fp + o[20]; dt.gp_coef = Fp + o[21]; dt.m2l_coef = Fp + o[22];
-	dt.l2l_coef = Fp + o[23]; dt.l2p_coef = Fp + o[24];
-	return NBCO_OK;
 }
 
 static TreeView view_of(const KdTreeDev &k)
@@ -1643,8 +1336,6 @@ static int kd_reserve_particles(nbco_ctx *c, long long n)
 static int kd_build_upward(nbco_ctx *c, const float *p, long long n, int L, const float *root6, bool &rebuild, int stage = 0)
 {
 	const int P = c->o.fmm_order;
-	DevTables tb;
-	NBCO_TRY(ensure_tables(c, tb));
 	const int ntot = (1 << (L + 1)) - 1, nleaf = 1 << L;
 	const int mlt_max = (int)((n - 1) / nleaf + 1);
 	hipStream_t st = c->stream;
@@ -1652,7 +1343,7 @@ static int kd_build_upward(nbco_ctx *c, const float *p, long long n, int L, cons
 	{
 		NBCO_TRY(c->join_aux());   // e.g. the multipole chain of an evaluation that is being redone
 		KdTreeDev &k = c->kd;
-		NBCO_TRY(kd_carve(c, c->treebuf, k, ntot, tb.offM, tb.offL));
+		NBCO_TRY(kd_carve(c, c->treebuf, k, ntot, sym_off(P), tl_off(P + 1)));
 		const bool topo_change = k.L != L || k.ntot != ntot || k.order != P || k.n != n;
 		if (topo_change) c->tree_valid = false;
 		k.L = L; k.ntot = ntot; k.order = P; k.mlt_max = mlt_max; k.n = n;
@@ -1704,7 +1395,6 @@ static int kd_build_upward(nbco_ctx *c, const float *p, long long n, int L, cons
 		NBCO_HIP(hipGetLastError());
 	}
 	if (stage == 1) return NBCO_OK;
-	if (P <= 8)
 	{
 		// centres of all nodes first (2 launches): that is all the traversal needs, so the multipole chain
 		// (P2M + M2M, generated register-resident bodies of k_farfield.hip) runs beside it on the second stream
@@ -1714,13 +1404,6 @@ static int kd_build_upward(nbco_ctx *c, const float *p, long long n, int L, cons
 		StreamScope on_aux(c, c->aux);
 		PhaseScope ph(c, NBCO_PH_P2M_M2M);
 		NBCO_TRY(launch_upward_gen(c, P, pos, tv.center, tv.mpole, tv.mult, tv.index, L, 0));
-	}
-	else
-	{
-		PhaseScope ph(c, NBCO_PH_P2M_M2M);
-		hipLaunchKernelGGL(p2m_kernel, dim3(nleaf), dim3(64), 0, st, tv, tb, pos);
-		for (int l = L - 1; l >= 0; --l) hipLaunchKernelGGL(m2m_kernel, dim3(kd_cnt(l)), dim3(64), 0, st, tv, tb, l);
-		hipLaunchKernelGGL(kd_csz_kernel, dim3(grid1d(ntot)), dim3(kBlock), 0, st, tv);
 	}
 	NBCO_HIP(hipGetLastError());
 	return NBCO_OK;
@@ -1739,13 +1422,10 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
                        const int *unsort, float *a, const float *param, KdCounts &out)
 {
 	const int P = c->o.fmm_order;
-	DevTables tb;
-	NBCO_TRY(ensure_tables(c, tb));
 	const int L = tv.L, ntot = tv.ntot, nleaf = 1 << L, beg = kd_beg(L);
-	const int offL = tb.offL, offM = tb.offM;
+	const int offL = tl_off(P + 1);
 	const int self0 = dm.g << (L - dm.d), nself = 1 << (L - dm.d);   // the domain's own leaves
 	hipStream_t st = c->stream;
-	if (dm.d > 0 && P > 8) return c->fail(NBCO_ERR_UNSUPPORTED, "kd-domain sharding needs the generated operators (fmm_order <= 8)");
 
 	// capacity of the frontier and of the two pair lists, split into kTravK regions
 	// (regions fill unevenly: each gets twice its share of list_factor * ntot pairs)
@@ -1853,23 +1533,13 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 			                             c->m2l_start.as<int>(), c->m2l_keys.as<uint64_t>(), c->m2l_keys_alt.as<uint64_t>(), dm, c->scan_tmp_aux));
 			{
 				PhaseScope ph(c, NBCO_PH_M2L);
-				if (P <= 8)
-				{
-					// register-resident generated bodies, one interaction per lane (k_m2l.hip)
-					NBCO_HIP(hipMemsetAsync(tv.local, 0, sizeof(float) * (size_t)ntot * offL, c->stream));
-					NBCO_TRY(launch_m2l_lanes(c, P, tv.csz, tv.mpole, tv.local, c->m2l_keys_alt.as<uint64_t>(), c->m2l_start.as<int>(), shift, ntot));
-				}
-				else
-					hipLaunchKernelGGL(m2l_kernel, dim3(ntot), dim3(64), 0, c->stream, tv, tb, (const uint64_t *)c->m2l_keys_alt.as<uint64_t>(),
-					                   (const int *)c->m2l_start.as<int>(), shift, c->o.eps2);
-				NBCO_HIP(hipGetLastError());
+				// register-resident generated bodies, one interaction per lane (k_m2l.hip)
+				NBCO_HIP(hipMemsetAsync(tv.local, 0, sizeof(float) * (size_t)ntot * offL, c->stream));
+				NBCO_TRY(launch_m2l_lanes(c, P, tv.csz, tv.mpole, tv.local, c->m2l_keys_alt.as<uint64_t>(), c->m2l_start.as<int>(), shift, ntot));
 			}
 			{
 				PhaseScope ph(c, NBCO_PH_L2L);
-				if (P <= 8) NBCO_TRY(launch_downward_gen(c, P, tv.center, tv.local, L, dm.d, dm.g));
-				else
-					for (int lc = 2; lc <= L; ++lc) hipLaunchKernelGGL(l2l_kernel, dim3(kd_cnt(lc)), dim3(64), 0, c->stream, tv, tb, lc);
-				NBCO_HIP(hipGetLastError());
+				NBCO_TRY(launch_downward_gen(c, P, tv.center, tv.local, L, dm.d, dm.g));
 			}
 		}
 		NBCO_HIP(hipGetLastError());
@@ -1894,14 +1564,8 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 	NBCO_TRY(c->join_aux());   // far field (multipoles, M2L list, M2L, L2L) complete
 	{
 		PhaseScope ph(c, NBCO_PH_L2P);
-		size_t lds = (288 + (size_t)std::max(offM, 1) * 64) * sizeof(float);
-		if (P <= 8)
-			NBCO_TRY(launch_l2p_gen(c, P, pos, tv.center, tv.local, near, c->p2p_chunk_off.as<int>(), tv.index, mlt_max, unsort, c->o.unsort ? 1 : 0,
-			                        param, a, c->o.coll ? 1 : 0, n, L, own0, own_n));
-		else
-			hipLaunchKernelGGL(l2p_kernel, dim3(nleaf), dim3(64), lds, st, tv, tb, (const float4 *)pos, (const float4 *)near,
-			                   (const int *)c->p2p_chunk_off.as<int>(), mlt_max, (const int *)unsort, c->o.unsort ? 1 : 0, param, a, c->o.coll ? 1 : 0);
-		NBCO_HIP(hipGetLastError());
+		NBCO_TRY(launch_l2p_gen(c, P, pos, tv.center, tv.local, near, c->p2p_chunk_off.as<int>(), tv.index, mlt_max, unsort, c->o.unsort ? 1 : 0,
+		                        param, a, c->o.coll ? 1 : 0, n, L, own0, own_n));
 	}
 	// ---- now look at what the traversal reported (long finished: the GPU is busy with the work queued above) ----------
 	NBCO_HIP(hipEventSynchronize(c->ev_flags));
@@ -2082,7 +1746,6 @@ int kd_dist_layout(nbco_ctx *c, long long n_global, int world, int rank, nbco_di
 	if (n_global <= 0 || n_global % world != 0) return c->fail(NBCO_ERR_ARG, "nbco_dist: n must be a positive multiple of the number of domains");
 	if (n_global > 0x7fffffffLL / 4) return c->fail(NBCO_ERR_UNSUPPORTED, "nbco_dist: n too large for 32-bit tree indices");
 	const int P = c->o.fmm_order;
-	if (P > 8) return c->fail(NBCO_ERR_UNSUPPORTED, "kd-domain sharding needs the generated operators (fmm_order <= 8)");
 	const int L = kd_levels(n_global, P, c->o.dens_inhom, c->o.tree_L);
 	if (L - d < 2) return c->fail(NBCO_ERR_ARG, "nbco_dist: too few particles per domain (the local tree needs >= 2 levels)");
 	if (d > 0 && n_global / world < 4096) return c->fail(NBCO_ERR_ARG, "nbco_dist: at least 4096 particles per domain are required");

@@ -603,7 +603,9 @@ int fmm_oct_traceless_eval(nbco_ctx *c, float *p, float *a, long long n, const f
 	case 6: return oct_eval<6>(c, p, a, n, param);
 	case 7: return oct_eval<7>(c, p, a, n, param);
 	case 8: return oct_eval<8>(c, p, a, n, param);
-	default: return c->fail(NBCO_ERR_UNSUPPORTED, "nbco_fmm_traceless: generated operators exist for orders 1..8");
+	case 9: return oct_eval<9>(c, p, a, n, param);
+	case 10: return oct_eval<10>(c, p, a, n, param);
+	default: return c->fail(NBCO_ERR_UNSUPPORTED, "nbco_fmm_traceless: generated operators exist for orders 1..10");
 	}
 }
 

@@ -124,6 +124,8 @@ int launch_m2l_lanes(nbco_ctx *c, int P, const float4 *csz, const float *mpole, 
 	case 6: launch<6>(c, csz, mpole, local, keys, start, shift, ntot); break;
 	case 7: launch<7>(c, csz, mpole, local, keys, start, shift, ntot); break;
 	case 8: launch<8>(c, csz, mpole, local, keys, start, shift, ntot); break;
+	case 9: launch<9>(c, csz, mpole, local, keys, start, shift, ntot); break;
+	case 10: launch<10>(c, csz, mpole, local, keys, start, shift, ntot); break;
 	default: return c->fail(NBCO_ERR_UNSUPPORTED, "launch_m2l_lanes: order not generated");
 	}
 	NBCO_HIP(hipGetLastError());

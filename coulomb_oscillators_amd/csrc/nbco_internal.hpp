@@ -124,10 +124,6 @@ struct nbco_ctx
 	} dist;
 	bool force_sort_build = false;          // set after a tie overflow: use the sorting build from then on
 	long long list_cap = 0;
-	// operator tables
-	DevBuf tables;
-	int tables_order = 0;
-	std::vector<int> h_tab_off;   // offsets of the sub-tables inside `tables`
 	// bookkeeping of the last evaluation
 	nbco_kd_info info{};
 	long long eval_counter = 0;

@@ -175,7 +175,7 @@ int nbco_oct_copy(nbco_ctx *c, int which, void *host_dst, long long host_bytes);
  *                            like nbco_fmm_kdtree with opts.unsort = 0
  * The accelerations equal those of a single-GPU nbco_fmm_kdtree over the n_global particles bit for bit
  * (rank r's particles are positions [r n_local, (r+1) n_local) of the single-GPU tree order).
- * Requirements: world a power of two, n_global % world == 0, n_local >= 4096, fmm_order <= 8, opts.unsort = 0. */
+ * Requirements: world a power of two, n_global % world == 0, n_local >= 4096, opts.unsort = 0. */
 typedef struct nbco_dist_layout {
 	int world, rank;
 	int d;                 /* log2(world): global level of the domain roots */

@@ -44,7 +44,7 @@ def loopback(n, G, pos, vel, **opts):
 
 
 @pytest.mark.parametrize("n,G,p,kind", [(32768, 2, 6, "reference"), (32768, 4, 4, "reference"), (32768, 8, 6, "clumps"),
-                                        (40000, 8, 5, "uniform"), (24576, 2, 3, "clumps"), (1 << 20, 4, 6, "reference")])
+                                        (40000, 8, 5, "uniform"), (24576, 2, 3, "clumps"), (1 << 20, 4, 6, "reference"), (32768, 4, 10, "uniform")])
 def test_sharded_equals_single_gpu(oracle32, n, G, p, kind):
     import torch
     pos, vel = make_state(oracle32, n, kind)
@@ -145,8 +145,7 @@ def test_layout_and_argument_errors(engine):
         with pytest.raises(EngineError):
             engine.dist_layout(**bad)
     engine.set(fmm_order=10)
-    with pytest.raises(EngineError):
-        engine.dist_layout(1 << 20, 2, 0)
+    assert engine.dist_layout(1 << 20, 2, 0).order == 10
 
 
 def test_sharded_stale_domains_stay_correct(oracle32):

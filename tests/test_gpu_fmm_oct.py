@@ -39,7 +39,7 @@ def run_gpu(engine, buf, par, n, **opts):
 
 
 @pytest.mark.parametrize("n,p,kind", [(4096, 6, "cube"), (4096, 6, "gauss"), (30001, 6, "blob"), (5000, 8, "cube"),
-                                      (20000, 4, "blob"), (700, 3, "cube"), (65536, 7, "blob")])
+                                      (20000, 4, "blob"), (700, 3, "cube"), (65536, 7, "blob"), (8000, 10, "blob")])
 def test_cells_bit_exact_and_forces(engine, oracle32, oracle64, n, p, kind):
     o = oracle32
     buf = state(o, n, kind)
@@ -144,14 +144,19 @@ def test_options_and_edges(engine, oracle32):
     engine.set(eps2=1e-18)
 
 
-def test_unsupported_order_fails_loudly(engine):
-    import torch
+def test_orders_nine_and_ten(engine, oracle32):
+    """BASELINE config 5 runs the traceless evaluator at p = 10; orders above 10 are rejected by the options check"""
     from coulomb_oscillators_amd import EngineError
-    engine.set(fmm_order=10)
-    d = torch.zeros(2 * 3 * 100, device="cuda")
-    a = torch.zeros(3 * 100, device="cuda")
+    o = oracle32
+    n = 4096
+    buf = state(o, n, "cube")
+    par = o.params(n)
+    for p in (9, 10):
+        _, want = o.fmm_oct_traceless(buf[:2], par, p=p, threads=8)
+        _, got = run_gpu(engine, buf, par, n, fmm_order=p)
+        assert force_err(got, want) < 1e-5
     with pytest.raises(EngineError):
-        engine.fmm_cart3_traceless(d, a, 100, None)
+        engine.set(fmm_order=11)
 
 
 def test_integrate_with_octree_evaluator(engine, oracle32):
