@@ -290,7 +290,7 @@ struct AdmTab   // M = (max(mult1,mult2)/N)^(1/(3p+6)) evaluated on the host wit
 };
 
 // kd_admissible (fmm_cart3_kdtree.cuh:401-414)
-__device__ inline bool kd_admissible(const float4 c1, const float4 c2, int n1, int n2, const int *__restrict__ mult, const AdmTab &tab,
+__device__ inline bool kd_admissible(const float4 c1, const float4 c2, int n1, int n2, const int *__restrict__ mult, const AdmTab *tabp,
                                      float par)
 {
 	float dx = c2.x - c1.x, dy = c2.y - c1.y, dz = c2.z - c1.z;
@@ -298,7 +298,7 @@ __device__ inline bool kd_admissible(const float4 c1, const float4 c2, int n1, i
 	int m1 = mult[n1], m2 = mult[n2];
 	int nb = m1 >= m2 ? n1 : n2, mb = m1 >= m2 ? m1 : m2;
 	int lev = 31 - __clz(nb + 1);
-	float M = (mb == tab.lo[lev]) ? tab.Mlo[lev] : tab.Mhi[lev];
+	float M = (mb == tabp->lo[lev]) ? tabp->Mlo[lev] : tabp->Mhi[lev];
 	float parM = par * M;
 	float sz = fmaxf(c1.w, c2.w);
 	return parM * parM * sz < dist2;
@@ -824,7 +824,7 @@ __device__ inline uint64_t block_exclusive_scan3(uint64_t v, uint64_t *sh_wave, 
 
 // classification of one node pair (fmm_cart3_kdtree.cuh:586-609 CPU order, :504-542 GPU order):
 // 0 nothing, 1 P2P, 2 M2L, 3 self pair -> 3 children, 4 split the second node, 5 split the first node
-__device__ inline int classify_pair(const TreeView &t, const AdmTab &tab, int2 np, float par, int m2l_first, const Dom dm)
+__device__ inline int classify_pair(const TreeView &t, const AdmTab *tab, int2 np, float par, int m2l_first, const Dom dm)
 {
 	const int ntot = t.ntot;
 	if (dm.d > 0 && !dom_touch(dm, np.x) && !dom_touch(dm, np.y)) return 0;   // nothing below this pair reaches the domain
@@ -837,18 +837,26 @@ __device__ inline int classify_pair(const TreeView &t, const AdmTab &tab, int2 n
 	return (leaf1 || (!leaf2 && c1.w <= c2.w)) ? 4 : 5;
 }
 
-__device__ inline int pair_children(int kd, int2 np, int2 ch[3])
+// children of a split pair, by value (an int2[] written through a pointer ends up in scratch memory, i.e. in extra
+// round trips on the traversal's dependency chain)
+struct PairKids
 {
-	if (kd == 3)
-	{
-		ch[0] = make_int2(2 * np.x + 1, 2 * np.x + 1);
-		ch[1] = make_int2(2 * np.x + 1, 2 * np.x + 2);
-		ch[2] = make_int2(2 * np.x + 2, 2 * np.x + 2);
-		return 3;
-	}
-	if (kd == 4) { ch[0] = make_int2(np.x, 2 * np.y + 1); ch[1] = make_int2(np.x, 2 * np.y + 2); return 2; }
-	if (kd == 5) { ch[0] = make_int2(2 * np.x + 1, np.y); ch[1] = make_int2(2 * np.x + 2, np.y); return 2; }
-	return 0;
+	int2 a, b, c;
+	int n;
+};
+__device__ inline PairKids pair_children(int kd, int2 np)
+{
+	// branch-free selects on scalars (kd: 3 self pair -> 3 children, 4 split the second node, 5 split the first)
+	const int x1 = 2 * np.x + 1, x2 = 2 * np.x + 2, y1 = 2 * np.y + 1, y2 = 2 * np.y + 2;
+	PairKids k;
+	k.a.x = kd == 4 ? np.x : x1;
+	k.a.y = kd == 5 ? np.y : (kd == 4 ? y1 : x1);
+	k.b.x = kd == 4 ? np.x : (kd == 5 ? x2 : x1);
+	k.b.y = kd == 5 ? np.y : (kd == 4 ? y2 : x2);
+	k.c.x = x2;
+	k.c.y = x2;
+	k.n = kd == 3 ? 3 : (kd >= 4 ? 2 : 0);
+	return k;
 }
 
 // One launch advances the pair frontier by TWO traversal steps: every thread classifies its pair and,
@@ -878,7 +886,7 @@ __device__ inline long long region_slot(const int *__restrict__ pref, long long 
 	return (long long)r * capR + (i - pref[r]);
 }
 
-__global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab, const int2 *__restrict__ fin, int2 *__restrict__ fout,
+__global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab_arg, const int2 *__restrict__ fin, int2 *__restrict__ fout,
                                                           int2 *__restrict__ p2p, int2 *__restrict__ m2l, int *__restrict__ counters,
                                                           int *__restrict__ tctr, int it, long long capR, float par, int m2l_first,
                                                           unsigned *__restrict__ cnt_p2p, unsigned *__restrict__ cnt_m2l, const Dom dm)
@@ -886,6 +894,8 @@ __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab
 	__shared__ uint64_t sh_wave[4];
 	__shared__ int sh_base[3];
 	__shared__ int in_pref[kTravK + 1];
+	__shared__ AdmTab tab;   // LDS copy: a lane-indexed read of the kernel argument would be one more global round trip per test
+	for (int q = threadIdx.x; q < (int)(sizeof(AdmTab) / sizeof(int)); q += kBlock) reinterpret_cast<int *>(&tab)[q] = reinterpret_cast<const int *>(&tab_arg)[q];
 	if (threadIdx.x < 64)
 	{
 		// prefix sums of the input frontier's region sizes
@@ -904,27 +914,25 @@ __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab
 	for (long long base = (long long)blockIdx.x * kBlock; base < nin; base += (long long)gridDim.x * kBlock)
 	{
 		const long long i = base + threadIdx.x;
-		// up to 4 classified pairs per thread: the input pair and its children
-		int2 pr[4];
-		int kd[4] = {0, 0, 0, 0};
-		int nch = 0;
+		// up to 4 classified pairs per thread: the input pair and its children (named scalars: nothing goes to scratch)
+		int2 p0 = make_int2(0, 0);
+		int k0 = 0, k1 = 0, k2 = 0, k3 = 0;
+		PairKids ch;
+		ch.a = ch.b = ch.c = make_int2(0, 0);
+		ch.n = 0;
 		if (i < nin)
 		{
-			pr[0] = fin[region_slot(in_pref, capR, i)];
-			kd[0] = classify_pair(t, tab, pr[0], par, m2l_first, dm);
-			nch = pair_children(kd[0], pr[0], pr + 1);
-#pragma unroll
-			for (int k = 1; k < 4; ++k)
-				if (k <= nch) kd[k] = classify_pair(t, tab, pr[k], par, m2l_first, dm);
+			p0 = fin[region_slot(in_pref, capR, i)];
+			k0 = classify_pair(t, &tab, p0, par, m2l_first, dm);
+			ch = pair_children(k0, p0);
+			if (ch.n > 0) k1 = classify_pair(t, &tab, ch.a, par, m2l_first, dm);
+			if (ch.n > 1) k2 = classify_pair(t, &tab, ch.b, par, m2l_first, dm);
+			if (ch.n > 2) k3 = classify_pair(t, &tab, ch.c, par, m2l_first, dm);
 		}
-		uint64_t cnt = 0;
-#pragma unroll
-		for (int k = 0; k < 4; ++k)
-		{
-			if (k == 0 && nch > 0) continue;   // a split input pair itself emits nothing
-			const int q = kd[k];
-			cnt += (uint64_t)(q == 3 ? 3 : (q >= 4 ? 2 : 0)) | ((uint64_t)(q == 1) << 20) | ((uint64_t)(q == 2) << 40);
-		}
+		const int nch = ch.n;
+		auto weight = [](int q) { return (uint64_t)(q == 3 ? 3 : (q >= 4 ? 2 : 0)) | ((uint64_t)(q == 1) << 20) | ((uint64_t)(q == 2) << 40); };
+		// a split input pair itself emits nothing
+		const uint64_t cnt = nch > 0 ? weight(k1) + weight(k2) + weight(k3) : weight(k0);
 		uint64_t tot;
 		const uint64_t off = block_exclusive_scan3(cnt, sh_wave, tot);
 		const int tf = (int)(tot & 0xFFFFF), tp = (int)((tot >> 20) & 0xFFFFF), tm = (int)(tot >> 40);
@@ -936,41 +944,38 @@ __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab
 		const bool okf = bf + tf <= capR, okp = bp + tp <= capR, okm = bm + tm <= capR;
 		if (threadIdx.x == 0 && !(okf && okp && okm)) counters[2] = 1;
 		bf += (long long)(off & 0xFFFFF); bp += (long long)((off >> 20) & 0xFFFFF); bm += (long long)(off >> 40);
-#pragma unroll
-		for (int k = 0; k < 4; ++k)
-		{
-			if (k == 0 && nch > 0) continue;
-			const int q = kd[k];
-			const int2 np = pr[k];
+		auto emit = [&](int q, int2 np) {
 			// the per-target entry counts of the directed lists are accumulated here, under the traversal's latency
-			if (q == 1)
+			if (q == 1 && okp)
 			{
-				if (okp)
-				{
-					p2p[obase + bp] = np;
-					if (dm.d == 0 || dom_touch(dm, np.x)) atomicAdd(&cnt_p2p[np.x - lbeg], 1u);
-					if (dm.d == 0 || dom_touch(dm, np.y)) atomicAdd(&cnt_p2p[np.y - lbeg], 1u);
-				}
-				++bp;
+				p2p[obase + bp] = np;
+				if (dm.d == 0 || dom_touch(dm, np.x)) atomicAdd(&cnt_p2p[np.x - lbeg], 1u);
+				if (dm.d == 0 || dom_touch(dm, np.y)) atomicAdd(&cnt_p2p[np.y - lbeg], 1u);
 			}
-			else if (q == 2)
+			if (q == 2 && okm)
 			{
-				if (okm)
-				{
-					m2l[obase + bm] = np;
-					if (dm.d == 0 || dom_touch(dm, np.x)) atomicAdd(&cnt_m2l[np.x], 1u);
-					if (dm.d == 0 || dom_touch(dm, np.y)) atomicAdd(&cnt_m2l[np.y], 1u);
-				}
-				++bm;
+				m2l[obase + bm] = np;
+				if (dm.d == 0 || dom_touch(dm, np.x)) atomicAdd(&cnt_m2l[np.x], 1u);
+				if (dm.d == 0 || dom_touch(dm, np.y)) atomicAdd(&cnt_m2l[np.y], 1u);
 			}
-			else if (q >= 3)
+			const PairKids g = pair_children(q, np);
+			if (q >= 3 && okf)
 			{
-				int2 ch[3];
-				const int nc = pair_children(q, np, ch);
-				if (okf)
-					for (int e = 0; e < nc; ++e) fout[obase + bf + e] = ch[e];
-				bf += nc;
+				fout[obase + bf] = g.a;
+				fout[obase + bf + 1] = g.b;
+				if (g.n > 2) fout[obase + bf + 2] = g.c;
 			}
+			// cursors advance by selects (an if / else chain over them is turned into a scratch array by the compiler)
+			bp += q == 1 ? 1 : 0;
+			bm += q == 2 ? 1 : 0;
+			bf += g.n;
+		};
+		if (nch == 0) emit(k0, p0);
+		else
+		{
+			emit(k1, ch.a);
+			emit(k2, ch.b);
+			if (nch > 2) emit(k3, ch.c);
 		}
 		__syncthreads();
 	}
