@@ -1171,13 +1171,16 @@ __global__ __launch_bounds__(kBlock) void pair_count_kernel(const int *__restric
 // evaluates one chunk and stores the partial sums of its 32 targets, and the L2P kernel adds a leaf's
 // chunks in list order (fixed order: still bit-reproducible, still no atomics).  Source descriptors and chunk
 // counts come out of the per-target sort (list_segsort_kernel<true>).
+// chunk record: {first particle of the target leaf, first entry, end entry, particles of the target leaf}
 __global__ __launch_bounds__(kBlock) void p2p_chunk_fill_kernel(const int *__restrict__ start, const int *__restrict__ off, int nleaf,
+                                                                const int *__restrict__ leaf_index, const int *__restrict__ leaf_mult,
                                                                 int4 *__restrict__ chunk)
 {
 	for (int i = blockIdx.x * kBlock + threadIdx.x; i < nleaf; i += gridDim.x * kBlock)
 	{
 		const int b = start[i], e = start[i + 1], o = off[i], n = off[i + 1] - o;
-		for (int k = 0; k < n; ++k) chunk[o + k] = make_int4(i, min(b + k * kP2PChunk, e), min(b + (k + 1) * kP2PChunk, e), 0);
+		const int ind = leaf_index[i], mlt = leaf_mult[i];
+		for (int k = 0; k < n; ++k) chunk[o + k] = make_int4(ind, min(b + k * kP2PChunk, e), min(b + (k + 1) * kP2PChunk, e), mlt);
 	}
 }
 
@@ -1524,7 +1527,8 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 				                                 (size_t)(nleaf + 1), rocprim::plus<int>(), st));
 			}
 			hipLaunchKernelGGL(p2p_chunk_fill_kernel, dim3(grid1d(nleaf)), dim3(kBlock), 0, st, (const int *)c->p2p_start.as<int>(),
-			                   (const int *)c->p2p_chunk_off.as<int>(), nleaf, c->p2p_chunks.as<int4>());
+			                   (const int *)c->p2p_chunk_off.as<int>(), nleaf, (const int *)(tv.index + beg), (const int *)(tv.mult + beg),
+			                   c->p2p_chunks.as<int4>());
 			// remembered for nbco_kd_get_info (the directed pair count is evaluated on demand)
 			c->pc_mult = tv.mult + beg; c->pc_shift = shift; c->pc_total = c->p2p_start.as<int>() + nleaf;
 		}
@@ -1558,11 +1562,10 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		const int2 *pd = c->p2p_desc.as<int2>();
 		const int4 *pc = c->p2p_chunks.as<int4>();
 		const int *pt = c->p2p_chunk_off.as<int>() + nleaf;   // total number of chunks
-		const int *ti = tv.index + beg, *tm = tv.mult + beg;   // target group = leaf
-		if (mlt_max <= 8) launch_p2p<8>(c, ti, tm, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near);
-		else if (mlt_max <= 16) launch_p2p<16>(c, ti, tm, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near);
-		else if (mlt_max <= 32) launch_p2p<32>(c, ti, tm, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near);
-		else launch_p2p<64>(c, ti, tm, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near);
+		if (mlt_max <= 8) launch_p2p<8>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near);
+		else if (mlt_max <= 16) launch_p2p<16>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near);
+		else if (mlt_max <= 32) launch_p2p<32>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near);
+		else launch_p2p<64>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near);
 		NBCO_HIP(hipGetLastError());
 	}
 	// ---- L2P + rescale + (un)sort -------------------------------------------------------------------------

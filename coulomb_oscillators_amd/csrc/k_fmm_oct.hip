@@ -354,7 +354,8 @@ __global__ __launch_bounds__(kBlock) void oct_p2p_fill_kernel(OctView t, int rad
 // per target group: its chunks = slices of its cell's descriptor range
 __global__ __launch_bounds__(kBlock) void oct_p2p_chunk_kernel(const int *__restrict__ ngroups_total, const int *__restrict__ grp_cell,
                                                                const int *__restrict__ group_off, const int *__restrict__ desc_off,
-                                                               const int *__restrict__ chunk_off, int4 *__restrict__ chunk)
+                                                               const int *__restrict__ chunk_off, const int *__restrict__ grp_index,
+                                                               const int *__restrict__ grp_mult, int4 *__restrict__ chunk)
 {
 	const int ng = *ngroups_total;
 	for (int g = blockIdx.x * kBlock + threadIdx.x; g < ng; g += gridDim.x * kBlock)
@@ -362,7 +363,8 @@ __global__ __launch_bounds__(kBlock) void oct_p2p_chunk_kernel(const int *__rest
 		const int c = grp_cell[g], d0 = desc_off[c], d1 = desc_off[c + 1];
 		const int per = (d1 - d0 + kOctChunk - 1) / kOctChunk;
 		const int o = chunk_off[c] + (g - group_off[c]) * per;
-		for (int q = 0; q < per; ++q) chunk[o + q] = make_int4(g, d0 + q * kOctChunk, min(d0 + (q + 1) * kOctChunk, d1), 0);
+		const int ind = grp_index[g], mlt = grp_mult[g];   // chunk record: {first target particle, first desc, end desc, targets}
+		for (int q = 0; q < per; ++q) chunk[o + q] = make_int4(ind, d0 + q * kOctChunk, min(d0 + (q + 1) * kOctChunk, d1), mlt);
 	}
 }
 
@@ -532,7 +534,8 @@ static int oct_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 			hipLaunchKernelGGL(oct_p2p_fill_kernel, dim3(grid1d(m)), dim3(kBlock), 0, st, t, radius, tpl, (const int *)group_off, (const int *)desc_off,
 			                   grp_index, grp_mult, grp_cell, c->p2p_keys.as<int2>());
 			hipLaunchKernelGGL(oct_p2p_chunk_kernel, dim3(grid1d(std::max<long long>(ngr, 1))), dim3(kBlock), 0, st, (const int *)(group_off + m),
-			                   (const int *)grp_cell, (const int *)group_off, (const int *)desc_off, (const int *)chunk_off, c->p2p_chunks.as<int4>());
+			                   (const int *)grp_cell, (const int *)group_off, (const int *)desc_off, (const int *)chunk_off, (const int *)grp_index,
+			                   (const int *)grp_mult, c->p2p_chunks.as<int4>());
 		}
 		NBCO_HIP(hipGetLastError());
 	}
@@ -543,14 +546,13 @@ static int oct_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 	if (have_near)
 	{
 		PhaseScope ph(c, NBCO_PH_P2P);
-		const int *gi = c->oct_groups.as<int>(), *gm = gi + (ngr + 1);
 		const int2 *pd = c->p2p_keys.as<int2>();
 		const int4 *pc = c->p2p_chunks.as<int4>();
 		const int *pt = chunk_off + m;
-		if (tpl == 8) launch_p2p<8>(c, gi, gm, pos, pd, pc, pt, nck, kSrcPiece, tpl, near);
-		else if (tpl == 16) launch_p2p<16>(c, gi, gm, pos, pd, pc, pt, nck, kSrcPiece, tpl, near);
-		else if (tpl == 32) launch_p2p<32>(c, gi, gm, pos, pd, pc, pt, nck, kSrcPiece, tpl, near);
-		else launch_p2p<64>(c, gi, gm, pos, pd, pc, pt, nck, kSrcPiece, tpl, near);
+		if (tpl == 8) launch_p2p<8>(c, pos, pd, pc, pt, nck, kSrcPiece, tpl, near);
+		else if (tpl == 16) launch_p2p<16>(c, pos, pd, pc, pt, nck, kSrcPiece, tpl, near);
+		else if (tpl == 32) launch_p2p<32>(c, pos, pd, pc, pt, nck, kSrcPiece, tpl, near);
+		else launch_p2p<64>(c, pos, pd, pc, pt, nck, kSrcPiece, tpl, near);
 		NBCO_HIP(hipGetLastError());
 	}
 	// ---- M2L, L2L ------------------------------------------------------------------------------------------
