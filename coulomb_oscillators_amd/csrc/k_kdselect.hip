@@ -32,15 +32,13 @@ constexpr int kTieCap = 64;
 // per-node state of one level (zeroed for all levels by one memset per build)
 struct SelNode
 {
-	uint32_t prefix;   // selected digits so far (after three passes: the pivot key)
-	uint32_t r;        // 0-based rank of the pivot inside the current candidate set
-	uint32_t neq;      // elements equal to the pivot key (after three passes)
-	uint32_t need;     // how many of them belong to the left child
-	uint32_t done[3];  // blocks that have finished their histogram contribution, per pass
+	// select state after pass 0 ([0]) and after pass 1 ([1]): digits chosen so far and the 0-based rank of the pivot inside
+	// the remaining candidates.  Written during the launch that resolves the pass, read by the launch after it (two slots: a
+	// launch never overwrites what its own workgroups are reading)
+	uint32_t prefix[2], r[2];
 	uint32_t done_part; // blocks that have finished their part of the partition
 	uint32_t cntL, cntR, tiecnt;
 	uint32_t minR;     // smallest ordered key of the right child, stored inverted (~key) so that zero = "none yet"
-	uint32_t pivot;    // the pivot as an ordered key (valid after the third pass)
 };
 
 struct SelPivot { uint32_t prefix, r, neq, need; };
@@ -100,29 +98,27 @@ __device__ inline uint32_t chunks_of_node(long long n, long long j, long long m)
 
 // The block that completes node j's histogram of pass PASS descends into the bin holding the pivot rank and
 // publishes the new select state (the classic last-block-done pattern: nobody waits).
+// Select state of node j after the passes before PASS, computed by EVERY workgroup that touches the node at the start
+// of the launch of pass PASS (PASS = 3: the partition): the result of the passes before the previous one is read from
+// nodes[j] (written during the previous launch), the previous pass's histogram is descended here.  Compared with letting
+// the last workgroup of each pass do it, this takes the atomics drain, the completion counter and the serial descent off
+// the tail of every launch (three dependent round trips) and puts one descent beside the element loads of the next one.
+// The workgroup that holds the node's first element records the state for the launches after it.
 template <int PASS, int BLOCK>
-__device__ inline void finish_pass(const uint32_t *__restrict__ hist, SelNode *__restrict__ nodes, long long n, int l, long long j, uint32_t kmin,
-                                   int shl, uint32_t *sh)
+__device__ inline SelPivot resolve_before(const uint32_t *__restrict__ hist, SelNode *__restrict__ nodes, long long n, int l, long long j,
+                                          long long i0, uint32_t *sh)
 {
-	constexpr int CHUNK = 8 * BLOCK, R = BLOCK / 64;
+	constexpr int CHUNK = 8 * BLOCK;
 	const long long m = 1LL << l;
-	// the histogram is only ever touched by device-scope atomics and agent-scope loads (both served by the L2), so
-	// completion of this block's atomics is all the ordering the counter needs -- no cache write-back / invalidate
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	__syncthreads();
-	if (threadIdx.x == 0) sh[R + 3] = atomicAdd(&nodes[j].done[PASS], 1u);
-	__syncthreads();
-	if (sh[R + 3] != chunks_of_node<CHUNK>(n, j, m) - 1) return;   // uniform over the block
 	SelPivot pv;
-	if (PASS == 0) { pv.prefix = 0; pv.r = (uint32_t)(range_start(n, 2 * j + 1, 2 * m) - range_start(n, j, m) - 1); }
-	else { pv.prefix = ld_agent_u32(&nodes[j].prefix); pv.r = ld_agent_u32(&nodes[j].r); }
-	pv.neq = 0; pv.need = 0;
-	descend<BLOCK>(hist + ((size_t)PASS * m + j) * kBins, PASS == 2 ? 10 : 11, pv, sh);
-	if (threadIdx.x == 0)
-	{
-		nodes[j].prefix = pv.prefix; nodes[j].r = pv.r; nodes[j].neq = pv.neq; nodes[j].need = pv.need;
-		if (PASS == 2) nodes[j].pivot = (pv.prefix >> shl) + kmin;   // back to the un-normalised ordered key
-	}
+	pv.prefix = 0; pv.neq = 0; pv.need = 0;
+	pv.r = (uint32_t)(range_start(n, 2 * j + 1, 2 * m) - range_start(n, j, m) - 1);
+	if (PASS == 0) return pv;
+	if (PASS >= 2) { pv.prefix = nodes[j].prefix[PASS - 2]; pv.r = nodes[j].r[PASS - 2]; }
+	descend<BLOCK>(hist + ((size_t)(PASS - 1) * m + j) * kBins, PASS == 3 ? 10 : 11, pv, sh);
+	const long long first = range_start(n, j, m);
+	if (PASS <= 2 && threadIdx.x == 0 && first >= i0 && first < i0 + CHUNK) { nodes[j].prefix[PASS - 1] = pv.prefix; nodes[j].r[PASS - 1] = pv.r; }
+	return pv;
 }
 
 template <int PASS, int BLOCK>
@@ -134,21 +130,8 @@ __global__ __launch_bounds__(BLOCK) void sel_hist_kernel(const float4 *__restric
 	__shared__ uint32_t h[2][kBins];
 	__shared__ uint32_t sh[BLOCK / 64 + 4];
 	const long long m = 1LL << l;
-	for (int t = threadIdx.x; t < 2 * kBins; t += BLOCK) (&h[0][0])[t] = 0;
 	const long long i0 = (long long)blockIdx.x * CHUNK;
-	const long long ilast = (i0 + CHUNK < n ? i0 + CHUNK : n) - 1;
-	const long long j0 = (m * i0) / n, j1 = (m * ilast) / n;
-	uint32_t pfx[2] = {0, 0}, kmin[2] = {0, 0};
-	int shl[2] = {0, 0};
-	for (int jj = 0; jj < 2; ++jj)
-		if (j0 + jj <= j1)
-		{
-			if (PASS > 0) pfx[jj] = nodes[j0 + jj].prefix;
-			key_window(lbound, rbound, sd_l, l, j0 + jj, kmin[jj], shl[jj]);
-		}
-	__syncthreads();
-	const long long split = j1 > j0 ? range_start(n, j1, m) : n;
-	const int sd[2] = {sd_l[j0], sd_l[j1]};
+	// element loads first: they are independent of the node state resolved below
 	constexpr int PER = CHUNK / BLOCK;
 	float4 p[PER];
 #pragma unroll
@@ -157,6 +140,20 @@ __global__ __launch_bounds__(BLOCK) void sel_hist_kernel(const float4 *__restric
 		const long long i = i0 + e * BLOCK + threadIdx.x;
 		if (i < n) p[e] = pos[i];
 	}
+	for (int t = threadIdx.x; t < 2 * kBins; t += BLOCK) (&h[0][0])[t] = 0;
+	const long long ilast = (i0 + CHUNK < n ? i0 + CHUNK : n) - 1;
+	const long long j0 = (m * i0) / n, j1 = (m * ilast) / n;
+	uint32_t pfx[2] = {0, 0}, kmin[2] = {0, 0};
+	int shl[2] = {0, 0};
+	for (int jj = 0; jj < 2; ++jj)
+		if (j0 + jj <= j1)
+		{
+			pfx[jj] = resolve_before<PASS, BLOCK>(hist, nodes, n, l, j0 + jj, i0, sh).prefix;   // uniform over the block
+			key_window(lbound, rbound, sd_l, l, j0 + jj, kmin[jj], shl[jj]);
+		}
+	__syncthreads();
+	const long long split = j1 > j0 ? range_start(n, j1, m) : n;
+	const int sd[2] = {sd_l[j0], sd_l[j1]};
 #pragma unroll
 	for (int e = 0; e < PER; ++e)
 	{
@@ -179,8 +176,6 @@ __global__ __launch_bounds__(BLOCK) void sel_hist_kernel(const float4 *__restric
 		const long long j = j0 + (t / kBins);
 		if (v && j <= j1) atomicAdd(&hist[((size_t)PASS * m + j) * kBins + (t % kBins)], v);
 	}
-	finish_pass<PASS, BLOCK>(hist, nodes, n, l, j0, kmin[0], shl[0], sh);
-	if (j1 > j0) finish_pass<PASS, BLOCK>(hist, nodes, n, l, j1, kmin[1], shl[1], sh);
 }
 
 // exclusive scan over the block of four 16-bit counters packed in a uint64 (each block total <= CHUNK < 2^16)
@@ -216,10 +211,10 @@ __device__ inline uint64_t block_scan4(uint64_t v, uint64_t *sh_wave, uint64_t &
 __device__ inline void ties_and_boxes(const float4 *__restrict__ pos_in, const int *__restrict__ unsort_in, float4 *__restrict__ pos_out,
                                       int *__restrict__ unsort_out, float *__restrict__ lbound, float *__restrict__ rbound,
                                       int *__restrict__ splitdim, int *__restrict__ index, SelNode *__restrict__ nodes,
-                                      const uint32_t *__restrict__ tielist, int *__restrict__ flag, long long n, int l, int j, int lane)
+                                      const uint32_t *__restrict__ tielist, int *__restrict__ flag, long long n, int l, int j, int lane,
+                                      const SelPivot pv /* prefix = the pivot as an ordered key */)
 {
 	const int m = 1 << l;
-	const SelPivot pv{nodes[j].pivot, nodes[j].r, nodes[j].neq, nodes[j].need};   // written by the previous launch
 	const int node = m - 1 + j, a1 = splitdim[node];
 	const uint32_t nt = ld_agent_u32(&nodes[j].tiecnt);
 	bool tie_right = false;
@@ -299,26 +294,14 @@ __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__re
                                                                const int *__restrict__ sd_l, SelNode *__restrict__ nodes,
                                                                uint32_t *__restrict__ tielist, long long n, int l, float *__restrict__ lbound,
                                                                float *__restrict__ rbound, int *__restrict__ splitdim, int *__restrict__ index,
-                                                               int *__restrict__ flag)
+                                                               int *__restrict__ flag, const uint32_t *__restrict__ hist)
 {
 	constexpr int CHUNK = 8 * BLOCK;
 	static_assert(CHUNK < 65536, "packed 16-bit block counters");
 	__shared__ uint32_t base_s[4], mR[2];
 	const long long m = 1LL << l;
 	const long long i0 = (long long)blockIdx.x * CHUNK;
-	const long long ilast = (i0 + CHUNK < n ? i0 + CHUNK : n) - 1;
-	const long long j0 = (m * i0) / n, j1 = (m * ilast) / n;
-	// first element of node j1 (only meaningful when the chunk straddles two nodes)
-	const long long split = j1 > j0 ? range_start(n, j1, m) : n;
-	uint32_t piv[2], all_left[2];
-	for (int jj = 0; jj < 2; ++jj)
-	{
-		const SelNode &nd = nodes[j0 + jj <= j1 ? j0 + jj : j0];
-		piv[jj] = nd.pivot;
-		all_left[jj] = nd.need == nd.neq;
-	}
-	const int sd[2] = {sd_l[j0], sd_l[j1]};
-	if (threadIdx.x < 2) mR[threadIdx.x] = 0xFFFFFFFFu;
+	// element loads first: they are independent of the node state resolved below
 	constexpr int PER = CHUNK / BLOCK;
 	float4 p[PER];
 	int org[PER];
@@ -328,6 +311,31 @@ __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__re
 		const long long i = i0 + e * BLOCK + threadIdx.x;
 		if (i < n) { p[e] = pos_in[i]; org[e] = unsort_in[i]; }
 	}
+	const long long ilast = (i0 + CHUNK < n ? i0 + CHUNK : n) - 1;
+	const long long j0 = (m * i0) / n, j1 = (m * ilast) / n;
+	// first element of node j1 (only meaningful when the chunk straddles two nodes)
+	const long long split = j1 > j0 ? range_start(n, j1, m) : n;
+	// the third pass's histogram is descended here (see resolve_before): pivot back to the un-normalised ordered key
+	__shared__ uint32_t sh[BLOCK / 64 + 4];
+	uint32_t piv[2] = {0, 0}, all_left[2] = {0, 0};
+	SelPivot pvs[2];
+	for (int jj = 0; jj < 2; ++jj)
+	{
+		pvs[jj] = SelPivot{0, 0, 0, 0};
+		if (j0 + jj <= j1)
+		{
+			uint32_t kmin;
+			int shl;
+			key_window(lbound, rbound, sd_l, l, j0 + jj, kmin, shl);
+			pvs[jj] = resolve_before<3, BLOCK>(hist, nodes, n, l, j0 + jj, i0, sh);
+			pvs[jj].prefix = (pvs[jj].prefix >> shl) + kmin;
+			piv[jj] = pvs[jj].prefix;
+			all_left[jj] = pvs[jj].need == pvs[jj].neq;
+		}
+	}
+	if (j1 == j0) { piv[1] = piv[0]; all_left[1] = all_left[0]; }
+	const int sd[2] = {sd_l[j0], sd_l[j1]};
+	if (threadIdx.x < 2) mR[threadIdx.x] = 0xFFFFFFFFu;
 	// Destination slots.  The four output streams of the chunk (left / right of its one or two nodes) are filled in
 	// element order: consecutive lanes with the same destination stream write consecutive slots, so the stores coalesce
 	// (per-thread cursors made every lane of a store instruction hit a different sector: twice the HBM write traffic).
@@ -429,7 +437,7 @@ __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__re
 		for (int jj = 0; jj < 2; ++jj)
 			if (j0 + jj <= j1 && fin[jj] == chunks_of_node<CHUNK>(n, j0 + jj, m) - 1)
 				ties_and_boxes(pos_in, unsort_in, pos_out, unsort_out, lbound, rbound, splitdim, index, nodes, tielist, flag, n, l, (int)(j0 + jj),
-				               (int)threadIdx.x);
+				               (int)threadIdx.x, pvs[jj]);
 }
 
 
@@ -473,7 +481,7 @@ static void select_level_launch(nbco_ctx *c, int l, long long n, const float4 *p
 	hipLaunchKernelGGL((sel_hist_kernel<1, BLOCK>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l);
 	hipLaunchKernelGGL((sel_hist_kernel<2, BLOCK>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l);
 	hipLaunchKernelGGL(sel_partition_kernel<BLOCK>, dim3(gchunks), dim3(BLOCK), 0, st, pos_in, unsort_in, pos_out, unsort_out, sd_l, nodes, ties, n, l,
-	                   lbound, rbound, splitdim, index, flag);
+	                   lbound, rbound, splitdim, index, flag, (const uint32_t *)hist);
 }
 
 int kd_select_level(nbco_ctx *c, int l, long long n, const float4 *pos_in, const int *unsort_in, float4 *pos_out, int *unsort_out,
