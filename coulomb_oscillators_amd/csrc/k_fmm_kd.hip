@@ -993,12 +993,16 @@ __global__ void traverse_init_kernel(int2 *frontier, int *counters, int nctr, in
 // over its capacity (counters[2], reported to the caller as NBCO_ERR_CAPACITY once the host looks at the flags) the
 // lists are declared empty and the per-target counts cleared, so that everything already queued behind the traversal
 // runs on a consistent -- if useless -- state.
-__global__ __launch_bounds__(1024) void traverse_finish_kernel(int *counters, int *tctr, long long capR, unsigned *cnt_all, long long ncnt)
+__global__ __launch_bounds__(1024) void traverse_finish_kernel(int *counters, int *tctr, long long capR, unsigned *cnt_all, long long ncnt,
+                                                               unsigned *cnt_self, int nself)
 {
 	const int lane = threadIdx.x;
 	const bool overflow = counters[2] != 0;
 	if (overflow)
 		for (long long i = threadIdx.x; i < ncnt; i += blockDim.x) cnt_all[i] = 0u;
+	__syncthreads();
+	// one (leaf, leaf) self entry per own leaf of the P2P list (fmm_cart3_kdtree.cuh:1059-1071)
+	for (int i = threadIdx.x; i < nself; i += blockDim.x) cnt_self[i] += 1u;
 	if (lane >= 64) return;
 	for (int which = 0; which < 2; ++which)
 	{
@@ -1059,10 +1063,6 @@ __global__ __launch_bounds__(kBlock) void list_starts_kernel(const uint64_t *__r
 // count -> exclusive scan -> scatter (slot order inside a target is whatever the atomics give) ->
 // per-target sort of the (short) source ranges.  The last step makes the lists, and with them every
 // floating-point sum downstream, identical from run to run.
-__global__ __launch_bounds__(kBlock) void add_one_kernel(unsigned *__restrict__ v, int n)
-{
-	for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) v[i] += 1u;
-}
 
 __global__ __launch_bounds__(kBlock) void list_fill_kernel(const int2 *__restrict__ pairs, const int *__restrict__ pref, long long capR, int sub,
                                                            int self0, int nself, int shift, const int *__restrict__ start,
@@ -1184,7 +1184,22 @@ __global__ __launch_bounds__(kBlock) void p2p_chunk_fill_kernel(const int *__res
 	}
 }
 
-// sorted positions back to xyz triplets; velocities gathered into tree order
+// tree order for the caller's state in one pass: positions unpacked to xyz triplets, velocities gathered into a scratch
+// copy (the gather cannot run in place)
+__global__ __launch_bounds__(kBlock) void reorder_state_kernel(const float4 *__restrict__ pos, const int *__restrict__ unsort,
+                                                               const float *__restrict__ v_in, float *__restrict__ p_out, float *__restrict__ v_tmp,
+                                                               long long n)
+{
+	for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock)
+	{
+		const float4 q = pos[i];
+		p_out[3 * i] = q.x; p_out[3 * i + 1] = q.y; p_out[3 * i + 2] = q.z;
+		const long long s = unsort[i];
+		v_tmp[3 * i] = v_in[3 * s]; v_tmp[3 * i + 1] = v_in[3 * s + 1]; v_tmp[3 * i + 2] = v_in[3 * s + 2];
+	}
+}
+
+// sorted positions back to xyz triplets
 __global__ __launch_bounds__(kBlock) void unpack4_kernel(const float4 *__restrict__ src, float *__restrict__ dst, long long n)
 {
 	for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock)
@@ -1250,18 +1265,50 @@ static int sort_keys_u64(nbco_ctx *c, uint64_t *kin, uint64_t *kout, long long n
 
 // directed, per-target sorted list of `pairs` (+ one self entry for each of the targets [self0, self0 + nself)) into
 // keys_out; start[0..T].  cnt[0..T) holds the per-target pair-entry counts accumulated by the traversal, fill[0..T) is zero.
+// exclusive scan of up to kScanSmall ints in ONE launch of one workgroup (rocPRIM's device scan is two launches: on the
+// critical path of the list construction every launch is ~5 us)
+constexpr int kScanSmall = 1 << 17;
+__global__ __launch_bounds__(1024) void scan_small_kernel(const int *__restrict__ in, int *__restrict__ out, int count)
+{
+	__shared__ int wsum[16];
+	const int t = threadIdx.x, per = (count + 1023) / 1024, i0 = t * per, i1 = min(i0 + per, count);
+	int s = 0;
+	for (int i = i0; i < i1; ++i) s += in[i];
+	int incl = s;
+	const int lane = t & 63, w = t >> 6;
+	for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+	if (lane == 63) wsum[w] = incl;
+	__syncthreads();
+	int base = 0;
+	for (int q = 0; q < w; ++q) base += wsum[q];
+	int run = base + incl - s;
+	for (int i = i0; i < i1; ++i) { const int v = in[i]; out[i] = run; run += v; }
+}
+
+static int exclusive_scan_ints(nbco_ctx *c, int *in, int *out, size_t count, DevBuf &tmp)
+{
+	hipStream_t st = c->stream;
+	if (count <= (size_t)kScanSmall)
+	{
+		hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, (const int *)in, out, (int)count);
+		NBCO_HIP(hipGetLastError());
+		return NBCO_OK;
+	}
+	size_t bytes = 0;
+	NBCO_HIP(rocprim::exclusive_scan(nullptr, bytes, in, out, 0, count, rocprim::plus<int>(), st));
+	NBCO_TRY(c->reserve(tmp, bytes));
+	bytes = tmp.bytes;
+	NBCO_HIP(rocprim::exclusive_scan(tmp.ptr, bytes, in, out, 0, count, rocprim::plus<int>(), st));
+	return NBCO_OK;
+}
+
 static int build_directed_list(nbco_ctx *c, const int2 *pairs, const int *pref_dev, long long capR, long long npairs_hint, int sub, int self0, int nself,
                                int ntargets, int shift, unsigned *cnt, unsigned *fill, int *start, uint64_t *keys_tmp, uint64_t *keys_out, const Dom dm,
                                DevBuf &scan_tmp, const int *leaf_index = nullptr, const int *leaf_mult = nullptr, int2 *desc = nullptr,
                                int *chunk_cnt = nullptr)
 {
-	hipStream_t st = c->stream;
-	if (nself > 0) hipLaunchKernelGGL(add_one_kernel, dim3(grid1d(nself)), dim3(kBlock), 0, st, cnt + self0, nself);
-	size_t bytes = 0;
-	NBCO_HIP(rocprim::exclusive_scan(nullptr, bytes, (int *)cnt, start, 0, (size_t)(ntargets + 1), rocprim::plus<int>(), st));
-	NBCO_TRY(c->reserve(scan_tmp, bytes));
-	bytes = scan_tmp.bytes;
-	NBCO_HIP(rocprim::exclusive_scan(scan_tmp.ptr, bytes, (int *)cnt, start, 0, (size_t)(ntargets + 1), rocprim::plus<int>(), st));
+	hipStream_t st = c->stream;   // (the self entries were added to cnt by traverse_finish_kernel)
+	NBCO_TRY(exclusive_scan_ints(c, (int *)cnt, start, (size_t)(ntargets + 1), scan_tmp));
 	hipLaunchKernelGGL(list_fill_kernel, dim3(grid1d(npairs_hint + nself)), dim3(kBlock), 0, st, pairs, pref_dev, capR, sub, self0, nself, shift,
 	                   (const int *)start, fill, keys_tmp, dm);
 	if (desc)
@@ -1476,7 +1523,8 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 			                   c->m2l_list.as<int2>(), ctr, tctr, it, capR, c->o.tree_radius, c->o.m2l_first, cnt_p2p, cnt_m2l, dm);
 			std::swap(fa, fb);
 		}
-		hipLaunchKernelGGL(traverse_finish_kernel, dim3(1), dim3(1024), 0, st, ctr, tctr, capR, c->list_cnt.as<unsigned>(), (long long)(2 * (np_ + nm_)));
+		hipLaunchKernelGGL(traverse_finish_kernel, dim3(1), dim3(1024), 0, st, ctr, tctr, capR, c->list_cnt.as<unsigned>(), (long long)(2 * (np_ + nm_)),
+		                   cnt_p2p + self0, c->o.coll ? nself : 0);
 		NBCO_HIP(hipGetLastError());
 		// counts and flags go to pinned host memory behind the traversal; the host looks at them only after it has
 		// enqueued the rest of the evaluation (every later kernel takes its counts from the device), so the GPU never
@@ -1517,15 +1565,7 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 			                             c->p2p_start.as<int>(), c->p2p_keys.as<uint64_t>(), c->p2p_keys_alt.as<uint64_t>(), dm, c->sort_tmp,
 			                             tv.index + beg, tv.mult + beg, c->p2p_desc.as<int2>(), c->p2p_chunk_cnt.as<int>()));
 			// chunked work units: (counts from the sort) -> exclusive scan -> descriptors
-			{
-				size_t bytes = 0;
-				NBCO_HIP(rocprim::exclusive_scan(nullptr, bytes, c->p2p_chunk_cnt.as<int>(), c->p2p_chunk_off.as<int>(), 0, (size_t)(nleaf + 1),
-				                                 rocprim::plus<int>(), st));
-				NBCO_TRY(c->reserve(c->sort_tmp, bytes));
-				bytes = c->sort_tmp.bytes;
-				NBCO_HIP(rocprim::exclusive_scan(c->sort_tmp.ptr, bytes, c->p2p_chunk_cnt.as<int>(), c->p2p_chunk_off.as<int>(), 0,
-				                                 (size_t)(nleaf + 1), rocprim::plus<int>(), st));
-			}
+			NBCO_TRY(exclusive_scan_ints(c, c->p2p_chunk_cnt.as<int>(), c->p2p_chunk_off.as<int>(), (size_t)(nleaf + 1), c->sort_tmp));
 			hipLaunchKernelGGL(p2p_chunk_fill_kernel, dim3(grid1d(nleaf)), dim3(kBlock), 0, st, (const int *)c->p2p_start.as<int>(),
 			                   (const int *)c->p2p_chunk_off.as<int>(), nleaf, (const int *)(tv.index + beg), (const int *)(tv.mult + beg),
 			                   c->p2p_chunks.as<int4>());
@@ -1597,9 +1637,9 @@ static int kd_finish_order(nbco_ctx *c, float *p, long long n)
 {
 	PhaseScope ph(c, NBCO_PH_FINISH);
 	hipStream_t st = c->stream;
-	hipLaunchKernelGGL(unpack4_kernel, dim3(grid1d(n)), dim3(kBlock), 0, st, (const float4 *)c->pos4.as<float4>(), p, n);
 	NBCO_TRY(c->reserve(c->tmp3, sizeof(float) * 3 * (size_t)n));
-	NBCO_TRY(launch_gather3(c, c->tmp3.as<float>(), p + 3 * n, c->unsort.as<int>(), n, false));
+	hipLaunchKernelGGL(reorder_state_kernel, dim3(grid1d(n)), dim3(kBlock), 0, st, (const float4 *)c->pos4.as<float4>(), (const int *)c->unsort.as<int>(),
+	                   (const float *)(p + 3 * n), p, c->tmp3.as<float>(), n);
 	NBCO_HIP(hipMemcpyAsync(p + 3 * n, c->tmp3.ptr, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToDevice, st));
 	NBCO_HIP(hipGetLastError());
 	return NBCO_OK;

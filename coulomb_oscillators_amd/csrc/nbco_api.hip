@@ -388,8 +388,12 @@ int nbco_integrate(nbco_ctx *c, int scheme, int kind, float *buf, long long n, c
 			PhaseScope ph(c, NBCO_PH_AXPY);
 			NBCO_TRY(launch_kick_drift(c, x, v, a, (float)ds, (float)dt, n3));
 		}
-		NBCO_TRY(F());
-		NBCO_TRY(K(ds));
+		// F K(ds): the elastic term and the kick share one pass over x, v, a
+		NBCO_TRY(eval_kind(c, kind, x, a, n, param));
+		{
+			PhaseScope ph(c, NBCO_PH_AXPY);
+			NBCO_TRY(launch_finish_kick(c, x, v, a, param, (float)ds, n, elastic != 0));
+		}
 		break;
 	}
 	case NBCO_INTEG_FORESTRUTH:
