@@ -1265,35 +1265,10 @@ static int sort_keys_u64(nbco_ctx *c, uint64_t *kin, uint64_t *kout, long long n
 
 // directed, per-target sorted list of `pairs` (+ one self entry for each of the targets [self0, self0 + nself)) into
 // keys_out; start[0..T].  cnt[0..T) holds the per-target pair-entry counts accumulated by the traversal, fill[0..T) is zero.
-// exclusive scan of up to kScanSmall ints in ONE launch of one workgroup (rocPRIM's device scan is two launches: on the
-// critical path of the list construction every launch is ~5 us)
-constexpr int kScanSmall = 1 << 17;
-__global__ __launch_bounds__(1024) void scan_small_kernel(const int *__restrict__ in, int *__restrict__ out, int count)
-{
-	__shared__ int wsum[16];
-	const int t = threadIdx.x, per = (count + 1023) / 1024, i0 = t * per, i1 = min(i0 + per, count);
-	int s = 0;
-	for (int i = i0; i < i1; ++i) s += in[i];
-	int incl = s;
-	const int lane = t & 63, w = t >> 6;
-	for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o); if (lane >= o) incl += y; }
-	if (lane == 63) wsum[w] = incl;
-	__syncthreads();
-	int base = 0;
-	for (int q = 0; q < w; ++q) base += wsum[q];
-	int run = base + incl - s;
-	for (int i = i0; i < i1; ++i) { const int v = in[i]; out[i] = run; run += v; }
-}
-
 static int exclusive_scan_ints(nbco_ctx *c, int *in, int *out, size_t count, DevBuf &tmp)
 {
+	// (a one-workgroup scan in a single launch was tried for these 32K..64K-element arrays: 3x slower than rocPRIM's two launches)
 	hipStream_t st = c->stream;
-	if (count <= (size_t)kScanSmall)
-	{
-		hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, (const int *)in, out, (int)count);
-		NBCO_HIP(hipGetLastError());
-		return NBCO_OK;
-	}
 	size_t bytes = 0;
 	NBCO_HIP(rocprim::exclusive_scan(nullptr, bytes, in, out, 0, count, rocprim::plus<int>(), st));
 	NBCO_TRY(c->reserve(tmp, bytes));
