@@ -265,3 +265,27 @@ def test_edge_sizes(oracle32, n):
             e.compute_force(EVAL_FMM_KDTREE, d, n, dev(par))
         torch.cuda.synchronize()
         assert torch.isfinite(d).all()
+
+
+def test_list_capacity_overflow_is_reported_and_recoverable(oracle32):
+    """a traversal that runs out of list capacity must come back as NBCO_ERR_CAPACITY (everything queued behind it runs on
+    a consistent empty state), leave the caller's positions / velocities untouched, and the context must keep working"""
+    import torch
+    from coulomb_oscillators_amd import Engine, EngineError
+    o = oracle32
+    n, p = 65536, 6
+    buf = o.init_reference(n)
+    par = o.params(n)
+    e = Engine(fmm_order=p, unsort=0, list_factor=1)
+    d = dev(buf[:2])
+    before = d.clone()
+    a = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+    with pytest.raises(EngineError, match="list capacity"):
+        e.fmm_cart3_kdtree(d, a, n, dev(par))
+    torch.cuda.synchronize()
+    assert torch.equal(d, before)
+    e.set(list_factor=48)
+    _, want = o.fmm_kd(buf[:2], par, p=p, threads=4, unsort=False)
+    e.fmm_cart3_kdtree(d, a, n, dev(par))
+    torch.cuda.synchronize()
+    assert force_err(a.cpu().numpy(), want) < 1e-5
