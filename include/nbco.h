@@ -71,7 +71,10 @@ typedef struct nbco_opts {
 	                       (reference GPU traversal <true>, :520-534) */
 	int   sync;         /* != 0: evaluators return after the stream has drained */
 	int   list_factor;  /* capacity of the P2P / M2L lists and of the traversal frontier, in units
-	                       of the node count (reference: 1000, fmm_cart3_kdtree.cuh:1584-1586) */
+	                       of the node count (reference: 1000, fmm_cart3_kdtree.cuh:1584-1586).  The
+	                       lists are kept in 16 regions of list_factor * nodes / 8 pairs each; a region
+	                       that runs full makes the evaluation return NBCO_ERR_CAPACITY with the
+	                       caller's arrays untouched (default 48: ~10x the lists of the BASELINE runs) */
 	void *stream;       /* hipStream_t; NULL = the null stream */
 } nbco_opts;
 
