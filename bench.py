@@ -44,6 +44,8 @@ def parse():
                     help="nccl = RCCL (one rank per GPU); gloo = rehearsal with several ranks sharing one card")
     ap.add_argument("--workload", default="fmm_kd", choices=["fmm_kd", "fmm_oct", "direct"],
                     help="fmm_kd: kd-tree FMM (the nbco3 path, default); fmm_oct: uniform octree with traceless multipoles; direct: O(N^2)")
+    ap.add_argument("--far-fp64", action="store_true", help="fmm_oct only: multipole / local expansions and all far-field operators in double")
+    ap.add_argument("--dens-inhom", type=float, default=1.0, help="the reference's -i option (deeper trees for clustered inputs)")
     ap.add_argument("--dt", type=float, default=5e-4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=6)
@@ -131,7 +133,9 @@ def main():
     prm = torch.from_numpy(par).cuda()
 
     kind = {"fmm_kd": EVAL_FMM_KDTREE, "fmm_oct": EVAL_FMM_TRACELESS, "direct": EVAL_DIRECT}[args.workload]
-    eng = Engine(fmm_order=args.order, unsort=0, tree_steps=args.tree_steps, sync=0)
+    if args.far_fp64 and args.workload != "fmm_oct":
+        raise SystemExit("--far-fp64 needs --workload fmm_oct")
+    eng = Engine(fmm_order=args.order, unsort=0, tree_steps=args.tree_steps, sync=0, far_fp64=int(args.far_fp64), dens_inhom=args.dens_inhom)
     dom = "direct" if args.workload == "direct" else "p2p"
     run = None
     if sharded:
@@ -182,7 +186,8 @@ def main():
     elif args.workload == "fmm_oct":
         info = eng.oct_info()
         pairs_per_eval = 0    # the octree path keeps no pair counter: no roofline entry for this workload
-        extra = {"L": info.L, "m2l_entries": int(info.m2l_entries), "p2p_chunks": int(info.p2p_chunks)}
+        extra = {"L": info.L, "m2l_entries": int(info.m2l_entries), "p2p_chunks": int(info.p2p_chunks),
+                 "far_field": "fp64" if info.real_bytes == 8 else "fp32"}
     else:
         pairs_per_eval = n * n
         extra = {}

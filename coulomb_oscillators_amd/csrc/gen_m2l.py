@@ -57,23 +57,25 @@ def comp_xyz(i, n):
 
 
 def lit(v):
-    return repr(float(v)) + "f"
+    v = float(v)
+    return "T(%d)" % int(v) if v == int(v) and abs(v) < 2 ** 24 else "T(%s)" % repr(v)
 
 
 def gen_body(P, out):
     offM = sym_off(P)
     nout = tl_off(P + 1) - 1
     w = out.append
-    w("template <> __device__ __forceinline__ void m2l_body<%d>(const float *__restrict__ Mp, float ux, float uy, float uz,"
-      " float rinv, float (&L)[%d])" % (P, max(nout, 1)))
+    w("template <typename T> struct M2LBody<%d, T>" % P)
+    w("{")
+    w("static __device__ __forceinline__ void run(const T *__restrict__ Mp, T ux, T uy, T uz, T rinv, T (&L)[%d])" % max(nout, 1))
     w("{")
     # powers of the unit vector and of 1/r
     for a in "xy":
         for e in range(2, P + 1):
-            w("\tconst float u%s%d = u%s%d * u%s;" % (a, e, a, e - 1, a) if e > 2 else "\tconst float u%s2 = u%s * u%s;" % (a, a, a))
-    w("\tconst float r1 = rinv;")
+            w("\tconst T u%s%d = u%s%d * u%s;" % (a, e, a, e - 1, a) if e > 2 else "\tconst T u%s2 = u%s * u%s;" % (a, a, a))
+    w("\tconst T r1 = rinv;")
     for e in range(2, P + 2):
-        w("\tconst float r%d = r%d * rinv;" % (e, e - 1))
+        w("\tconst T r%d = r%d * rinv;" % (e, e - 1))
 
     def upow(a, e):
         if e == 0:
@@ -90,11 +92,11 @@ def gen_body(P, out):
             x, y, z = comp_xyz(i, k)
             tri = fact(k) // (fact(x) * fact(y) * fact(z))
             if k == 0:
-                w("\tconst float M%d = Mp[%d];" % (idx, idx))
+                w("\tconst T M%d = Mp[%d];" % (idx, idx))
             elif tri == 1:
-                w("\tconst float M%d = Mp[%d] * r%d;" % (idx, idx, k))
+                w("\tconst T M%d = Mp[%d] * r%d;" % (idx, idx, k))
             else:
-                w("\tconst float M%d = Mp[%d] * (r%d * %s);" % (idx, idx, k, lit(tri)))
+                w("\tconst T M%d = Mp[%d] * (r%d * %s);" % (idx, idx, k, lit(tri)))
     accs = {}
     declared = set()
     for n in range(1, P + 1):
@@ -121,15 +123,15 @@ def gen_body(P, out):
                     if expr is None:
                         expr = "%s * %s" % (lit(c), mono) if mono else lit(c)
                     else:
-                        expr = "fmaf(%s, %s, %s)" % (lit(c), mono, expr) if mono else "(%s + %s)" % (expr, lit(c))
+                        expr = "nb_fma(%s, %s, %s)" % (lit(c), mono, expr) if mono else "(%s + %s)" % (expr, lit(c))
                 if z == 1:
                     expr = "(%s) * uz" % expr
-                w("\tconst float %s = %s;" % (name, expr))
+                w("\tconst T %s = %s;" % (name, expr))
                 g[(x, z)] = name
         for z in range(2, m + 1):
             for x in range(m - z, -1, -1):
                 name = "g%d_%d" % (m, sym_idx(x, z, m))
-                w("\tconst float %s = -(%s + %s);" % (name, g[(x + 2, z - 2)], g[(x, z - 2)]))
+                w("\tconst T %s = -(%s + %s);" % (name, g[(x + 2, z - 2)], g[(x, z - 2)]))
                 g[(x, z)] = name
         # contractions that use G_m: outputs n = m-k
         for n in range(1, m + 1):
@@ -153,9 +155,9 @@ def gen_body(P, out):
                     declared.add(var)
                     expr = var if not first else None
                     for ms, gs in terms:
-                        expr = "%s * %s" % (ms, gs) if expr is None else "fmaf(%s, %s, %s)" % (ms, gs, expr)
+                        expr = "%s * %s" % (ms, gs) if expr is None else "nb_fma(%s, %s, %s)" % (ms, gs, expr)
                     if first:
-                        w("\tfloat %s = %s;" % (var, expr))
+                        w("\tT %s = %s;" % (var, expr))
                     else:
                         w("\t%s = %s;" % (var, expr))
                     accs[(n, o)] = []
@@ -163,6 +165,7 @@ def gen_body(P, out):
         for i in range(2 * n + 1):
             w("\tL[%d] = a%d_%d * (r%d * %s);" % (tl_off(n) + i - 1, n, i, n + 1, lit(1.0 / fact(n))))
     w("}")
+    w("};")
     w("")
 
 

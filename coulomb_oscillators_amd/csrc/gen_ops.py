@@ -44,7 +44,8 @@ def comps(n):
 
 
 def lit(v):
-    return repr(float(v)) + "f"
+    v = float(v)
+    return "T(%d)" % int(v) if v == int(v) and abs(v) < 2 ** 24 else "T(%s)" % repr(v)
 
 
 def full(x, y, z):
@@ -56,8 +57,8 @@ def emit_monomials(w, pmax_order):
     """D{i} = d^K / K! for all |K| <= pmax_order (needs dx, dy, dz)"""
     for a in "xyz":
         for k in range(2, pmax_order + 1):
-            w("\tconst float d%s_%d = d%s * %s;" % (a, k, a, lit(1.0 / k)))
-    w("\tconst float D0 = 1.0f;")
+            w("\tconst T d%s_%d = d%s * %s;" % (a, k, a, lit(1.0 / k)))
+    w("\tconst T D0 = T(1);")
     for n in range(1, pmax_order + 1):
         for (x, y, z) in comps(n):
             i = full(x, y, z)
@@ -68,7 +69,7 @@ def emit_monomials(w, pmax_order):
             else:
                 par, a, k = full(x, y, z - 1), "z", z
             fac = "d%s" % a if k == 1 else "d%s_%d" % (a, k)
-            w("\tconst float D%d = %s;" % (i, fac) if par == 0 else "\tconst float D%d = D%d * %s;" % (i, par, fac))
+            w("\tconst T D%d = %s;" % (i, fac) if par == 0 else "\tconst T D%d = D%d * %s;" % (i, par, fac))
 
 
 def emit_expand_local(w, P, src):
@@ -78,11 +79,11 @@ def emit_expand_local(w, P, src):
         for z in range(0, min(1, n) + 1):
             for x in range(n - z, -1, -1):
                 y = n - x - z
-                w("\tconst float F%d = %s[%d] * %s;" % (full(x, y, z), src, tl_off(n) + tl_idx(x, z, n), lit(fact(n))))
+                w("\tconst T F%d = %s[%d] * %s;" % (full(x, y, z), src, tl_off(n) + tl_idx(x, z, n), lit(fact(n))))
         for z in range(2, n + 1):
             for x in range(n - z, -1, -1):
                 y = n - x - z
-                w("\tconst float F%d = -(F%d + F%d);" % (full(x, y, z), full(x + 2, y, z - 2), full(x, y + 2, z - 2)))
+                w("\tconst T F%d = -(F%d + F%d);" % (full(x, y, z), full(x + 2, y, z - 2), full(x, y + 2, z - 2)))
 
 
 def odfact(n):
@@ -115,10 +116,10 @@ def harmonic_terms(n, x, z):
 
 
 def emit_r2_powers(w, kmax):
-    w("\tconst float R2_0 = 1.0f;")
-    w("\tconst float R2_1 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));")
+    w("\tconst T R2_0 = T(1);")
+    w("\tconst T R2_1 = nb_fma(dx, dx, nb_fma(dy, dy, dz * dz));")
     for k in range(2, kmax + 1):
-        w("\tconst float R2_%d = R2_%d * R2_1;" % (k, k - 1))
+        w("\tconst T R2_%d = R2_%d * R2_1;" % (k, k - 1))
 
 
 def harmonic_expr(n, x, z, scale):
@@ -131,9 +132,9 @@ def harmonic_expr(n, x, z, scale):
         inner = None
         for (c, e) in by_k[k]:
             t = "%s * D%d" % (lit(c * scale), full(*e))
-            inner = t if inner is None else "fmaf(%s, D%d, %s)" % (lit(c * scale), full(*e), inner)
+            inner = t if inner is None else "nb_fma(%s, D%d, %s)" % (lit(c * scale), full(*e), inner)
         t = inner if k == 0 else "(%s) * R2_%d" % (inner, k)
-        expr = t if expr is None else ("fmaf(%s, R2_%d, %s)" % (inner, k, expr) if False else "(%s + %s)" % (expr, t))
+        expr = t if expr is None else ("nb_fma(%s, R2_%d, %s)" % (inner, k, expr) if False else "(%s + %s)" % (expr, t))
     return expr
 
 
@@ -143,7 +144,9 @@ def gen_oct(P, out):
     w = out.append
     offL = tl_off(P + 1)
     # ---------------------------------------------------------------- P2M (traceless), orders 2..P
-    w("template <> __device__ __forceinline__ void p2m_tl_accum<%d>(float dx, float dy, float dz, float (&A)[%d])" % (P, offL))
+    w("template <typename T> struct FmmOctOps<%d, T>" % P)
+    w("{")
+    w("static __device__ __forceinline__ void p2m_tl_accum(T dx, T dy, T dz, T (&A)[%d])" % offL)
     w("{")
     if P >= 2:
         emit_monomials(w, P)
@@ -157,34 +160,33 @@ def gen_oct(P, out):
         w("\t(void)dx; (void)dy; (void)dz; (void)A;")
     w("}")
     # ---------------------------------------------------------------- M2M (traceless), orders 2..P, one child
-    w("template <> __device__ __forceinline__ void m2m_tl_accum<%d>(const float *__restrict__ Mc, float dx, float dy, float dz, float (&A)[%d])"
-      % (P, offL))
+    w("static __device__ __forceinline__ void m2m_tl_accum(const T *__restrict__ Mc, T dx, T dy, T dz, T (&A)[%d])" % offL)
     w("{")
     if P >= 2:
         emit_monomials(w, P)
         emit_r2_powers(w, P // 2)
         # TP{m}_{i}: full symmetric layout of tracelesspow_m(d) / m!
-        w("\tconst float TP%d = 1.0f;" % full(0, 0, 0))
+        w("\tconst T TP%d = T(1);" % full(0, 0, 0))
         for m in range(1, P + 1):
             C = 1.0 / odfact(2 * m - 1) / fact(m)
             for z in range(0, min(1, m) + 1):
                 for x in range(m - z, -1, -1):
-                    w("\tconst float TP%d = %s;" % (full(x, m - x - z, z), harmonic_expr(m, x, z, C)))
+                    w("\tconst T TP%d = %s;" % (full(x, m - x - z, z), harmonic_expr(m, x, z, C)))
             for z in range(2, m + 1):
                 for x in range(m - z, -1, -1):
                     y = m - x - z
-                    w("\tconst float TP%d = -(TP%d + TP%d);" % (full(x, y, z), full(x + 2, y, z - 2), full(x, y + 2, z - 2)))
+                    w("\tconst T TP%d = -(TP%d + TP%d);" % (full(x, y, z), full(x + 2, y, z - 2), full(x, y + 2, z - 2)))
         # F{i}: full layout of the child's multipoles (orders 0, 2..P-... all used orders), from the traceless tuple
         for k in range(0, P + 1):
             if k == 1:
                 continue
             for z in range(0, min(1, k) + 1):
                 for x in range(k - z, -1, -1):
-                    w("\tconst float F%d = Mc[%d];" % (full(x, k - x - z, z), tl_off(k) + tl_idx(x, z, k)))
+                    w("\tconst T F%d = Mc[%d];" % (full(x, k - x - z, z), tl_off(k) + tl_idx(x, z, k)))
             for z in range(2, k + 1):
                 for x in range(k - z, -1, -1):
                     y = k - x - z
-                    w("\tconst float F%d = -(F%d + F%d);" % (full(x, y, z), full(x + 2, y, z - 2), full(x, y + 2, z - 2)))
+                    w("\tconst T F%d = -(F%d + F%d);" % (full(x, y, z), full(x + 2, y, z - 2), full(x, y + 2, z - 2)))
         for n in range(2, P + 1):
             for z in range(0, 2):
                 for x in range(n - z, -1, -1):
@@ -196,11 +198,12 @@ def gen_oct(P, out):
                         for k1 in range(0, min(x, m) + 1):
                             for k3 in range(max(0, m - k1 - y), min(z, m - k1) + 1):
                                 k2 = m - k1 - k3
-                                expr = "fmaf(TP%d, F%d, %s)" % (full(k1, k2, k3), full(x - k1, y - k2, z - k3), expr)
+                                expr = "nb_fma(TP%d, F%d, %s)" % (full(k1, k2, k3), full(x - k1, y - k2, z - k3), expr)
                     w("\tA[%d] = %s;" % (tl_off(n) + tl_idx(x, z, n), expr))
     else:
         w("\t(void)Mc; (void)dx; (void)dy; (void)dz; (void)A;")
     w("}")
+    w("};")
     w("")
 
 
@@ -209,7 +212,9 @@ def gen(P, out):
     offM = sym_off(P)
     offL = tl_off(P + 1)
     # ---------------------------------------------------------------- P2M
-    w("template <> __device__ __forceinline__ void p2m_accum<%d>(float dx, float dy, float dz, float (&A)[%d])" % (P, max(offM, 1)))
+    w("template <typename T> struct FmmOps<%d, T>" % P)
+    w("{")
+    w("static __device__ __forceinline__ void p2m_accum(T dx, T dy, T dz, T (&A)[%d])" % max(offM, 1))
     w("{")
     if P >= 3:
         emit_monomials(w, P - 1)
@@ -220,7 +225,7 @@ def gen(P, out):
     else:
         w("\t(void)dx; (void)dy; (void)dz; (void)A;")
     w("}")
-    w("template <> __device__ __forceinline__ void p2m_store<%d>(const float (&A)[%d], float *__restrict__ M)" % (P, max(offM, 1)))
+    w("static __device__ __forceinline__ void p2m_store(const T (&A)[%d], T *__restrict__ M)" % max(offM, 1))
     w("{")
     for q in range(2, P):
         for (x, y, z) in comps(q):
@@ -230,8 +235,7 @@ def gen(P, out):
         w("\t(void)A; (void)M;")
     w("}")
     # ---------------------------------------------------------------- M2M
-    w("template <> __device__ __forceinline__ void m2m_accum<%d>(const float *__restrict__ Mc, float dx, float dy, float dz,"
-      " float (&A)[%d])" % (P, max(offM, 1)))
+    w("static __device__ __forceinline__ void m2m_accum(const T *__restrict__ Mc, T dx, T dy, T dz, T (&A)[%d])" % max(offM, 1))
     w("{")
     if P >= 3:
         emit_monomials(w, P - 1)
@@ -241,7 +245,7 @@ def gen(P, out):
             for (x, y, z) in comps(k):
                 i = full(x, y, z)
                 c = fact(k) / (fact(x) * fact(y) * fact(z))
-                w("\tconst float T%d = Mc[%d]%s;" % (i, i, "" if c == 1 else " * " + lit(c)))
+                w("\tconst T T%d = Mc[%d]%s;" % (i, i, "" if c == 1 else " * " + lit(c)))
         for n in range(2, P):
             for (x, y, z) in comps(n):
                 o = full(x, y, z)
@@ -252,12 +256,12 @@ def gen(P, out):
                             m = k1 + k2 + k3
                             if n - m == 1:
                                 continue
-                            expr = "fmaf(D%d, T%d, %s)" % (full(k1, k2, k3), full(x - k1, y - k2, z - k3), expr)
+                            expr = "nb_fma(D%d, T%d, %s)" % (full(k1, k2, k3), full(x - k1, y - k2, z - k3), expr)
                 w("\tA[%d] = %s;" % (o, expr))
     else:
         w("\t(void)Mc; (void)dx; (void)dy; (void)dz; (void)A;")
     w("}")
-    w("template <> __device__ __forceinline__ void m2m_store<%d>(const float (&A)[%d], float *__restrict__ M)" % (P, max(offM, 1)))
+    w("static __device__ __forceinline__ void m2m_store(const T (&A)[%d], T *__restrict__ M)" % max(offM, 1))
     w("{")
     for n in range(2, P):
         for (x, y, z) in comps(n):
@@ -267,12 +271,11 @@ def gen(P, out):
         w("\t(void)A; (void)M;")
     w("}")
     # ---------------------------------------------------------------- L2L
-    w("template <> __device__ __forceinline__ void l2l_body<%d>(const float (&Lp)[%d], float dx, float dy, float dz, float (&O)[%d])"
-      % (P, offL, offL))
+    w("static __device__ __forceinline__ void l2l_body(const T (&Lp)[%d], T dx, T dy, T dz, T (&O)[%d])" % (offL, offL))
     w("{")
     emit_monomials(w, P - 1)
     emit_expand_local(w, P, "Lp")
-    w("\tO[0] = 0.0f;")
+    w("\tO[0] = T(0);")
     for n in range(1, P + 1):
         for z in range(0, min(1, n) + 1):
             for x in range(n - z, -1, -1):
@@ -285,12 +288,11 @@ def gen(P, out):
                         if expr is None:
                             expr = t
                         else:
-                            expr = "fmaf(D%d, F%d, %s)" % (full(kx, ky, kz), full(x + kx, y + ky, z + kz), expr)
+                            expr = "nb_fma(D%d, F%d, %s)" % (full(kx, ky, kz), full(x + kx, y + ky, z + kz), expr)
                 w("\tO[%d] = (%s) * %s;" % (tl_off(n) + tl_idx(x, z, n), expr, lit(1.0 / fact(n))))
     w("}")
     # ---------------------------------------------------------------- L2P
-    w("template <> __device__ __forceinline__ void l2p_body<%d>(const float (&Lp)[%d], float dx, float dy, float dz, float &fx, float &fy,"
-      " float &fz)" % (P, offL))
+    w("static __device__ __forceinline__ void l2p_body(const T (&Lp)[%d], T dx, T dy, T dz, T &fx, T &fy, T &fz)" % offL)
     w("{")
     emit_monomials(w, P - 1)
     emit_expand_local(w, P, "Lp")
@@ -302,16 +304,17 @@ def gen(P, out):
             if d == 0:
                 ex, ey, ez = "F%d" % ix, "F%d" % iy, "F%d" % iz
             else:
-                ex = "fmaf(D%d, F%d, %s)" % (d, ix, ex)
-                ey = "fmaf(D%d, F%d, %s)" % (d, iy, ey)
-                ez = "fmaf(D%d, F%d, %s)" % (d, iz, ez)
+                ex = "nb_fma(D%d, F%d, %s)" % (d, ix, ex)
+                ey = "nb_fma(D%d, F%d, %s)" % (d, iy, ey)
+                ez = "nb_fma(D%d, F%d, %s)" % (d, iz, ez)
         # flush per order to keep expressions short
-        w("\tconst float ex%d = %s;" % (q, ex))
-        w("\tconst float ey%d = %s;" % (q, ey))
-        w("\tconst float ez%d = %s;" % (q, ez))
+        w("\tconst T ex%d = %s;" % (q, ex))
+        w("\tconst T ey%d = %s;" % (q, ey))
+        w("\tconst T ez%d = %s;" % (q, ez))
         ex, ey, ez = "ex%d" % q, "ey%d" % q, "ez%d" % q
     w("\tfx = -%s; fy = -%s; fz = -%s;" % (ex, ey, ez))
     w("}")
+    w("};")
     w("")
 
 

@@ -1626,6 +1626,7 @@ int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 {
 	if (n <= 0) return c->fail(NBCO_ERR_ARG, "nbco_fmm_kdtree: n must be positive");
 	if (n > 0x7fffffffLL / 4) return c->fail(NBCO_ERR_UNSUPPORTED, "nbco_fmm_kdtree: n too large for 32-bit tree indices");
+	if (c->o.far_fp64) return c->fail(NBCO_ERR_UNSUPPORTED, "nbco_fmm_kdtree: far_fp64 is implemented by nbco_fmm_traceless only");
 	const int P = c->o.fmm_order;
 	const int L = kd_levels(n, P, c->o.dens_inhom, c->o.tree_L);
 	bool rebuild = false;
@@ -1763,6 +1764,7 @@ TopView top_view(nbco_ctx *c, int ntop)
 
 int kd_dist_layout(nbco_ctx *c, long long n_global, int world, int rank, nbco_dist_layout *out)
 {
+	if (c->o.far_fp64) return c->fail(NBCO_ERR_UNSUPPORTED, "nbco_dist_*: far_fp64 is implemented by nbco_fmm_traceless only");
 	const int d = log2_exact(world);
 	if (d < 0 || world > 64) return c->fail(NBCO_ERR_ARG, "nbco_dist: the number of domains must be a power of two <= 64");
 	if (rank < 0 || rank >= world) return c->fail(NBCO_ERR_ARG, "nbco_dist: rank out of range");

@@ -35,10 +35,13 @@ constexpr int kOctChunk = 64;   // descriptors per P2P chunk
 __host__ __device__ inline int oct_beg(int l) { return ((1 << (3 * l)) - 1) / 7; }
 __host__ __device__ inline int oct_cnt(int l) { return 1 << (3 * l); }
 
+// T = scalar type of the expansions and of all far-field arithmetic: float, or double with opts.far_fp64 (the range of
+// fp32 ends near r^-11 19!! ~ 1e40 at order 10); positions, centres and the near field are fp32 either way
+template <typename T>
 struct OctView
 {
-	float4 *csz;                  // [ntot] centre (w unused)
-	float *mpole, *local, *msym;  // [ntot][offL] traceless tuples, [ntot][offM] symmetric copy of orders 0..P-1 for M2L
+	float4 *csz;              // [ntot] centre (w unused)
+	T *mpole, *local, *msym;  // [ntot][offL] traceless tuples, [ntot][offM] symmetric copy of orders 0..P-1 for M2L
 	int *mult, *index;            // [ntot], [ntot + 1] (index[ntot] = n)
 	int L, ntot, side;
 	long long n;
@@ -93,7 +96,8 @@ __global__ __launch_bounds__(kBlock) void oct_unpack4_kernel(const float4 *__res
 
 // indexLeaves (appel.cuh:141-167): first particle whose key is >= the cell number (empty cells point at the next
 // non-empty one); index[ntot] = n closes the last cell
-__global__ __launch_bounds__(kBlock) void oct_index_kernel(OctView t, const uint32_t *__restrict__ keys)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void oct_index_kernel(OctView<T> t, const uint32_t *__restrict__ keys)
 {
 	const int m = oct_cnt(t.L), beg = oct_beg(t.L);
 	for (int c = blockIdx.x * kBlock + threadIdx.x; c <= m; c += gridDim.x * kBlock)
@@ -109,8 +113,8 @@ __global__ __launch_bounds__(kBlock) void oct_index_kernel(OctView t, const uint
 }
 
 // ---- leaves: multLeaves + centerLeaves + P2M, one wave per cell ------------------------------------------------
-template <int P>
-__global__ __launch_bounds__(kBlock) void oct_leaf_kernel(OctView t, const float4 *__restrict__ pos)
+template <int P, typename T>
+__global__ __launch_bounds__(kBlock) void oct_leaf_kernel(OctView<T> t, const float4 *__restrict__ pos)
 {
 	constexpr int offL = NBCO_OFFL(P);
 	const int m = oct_cnt(t.L), beg = oct_beg(t.L);
@@ -126,23 +130,23 @@ __global__ __launch_bounds__(kBlock) void oct_leaf_kernel(OctView t, const float
 	for (int o = 32; o > 0; o >>= 1) { sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); sz += __shfl_xor(sz, o); }
 	float cx = 0.f, cy = 0.f, cz = 0.f;
 	if (mlt > 0) { const float d = (float)mlt; cx = sx / d; cy = sy / d; cz = sz / d; }
-	float A[offL];
+	T A[offL];
 #pragma unroll
-	for (int q = 0; q < offL; ++q) A[q] = 0.f;
+	for (int q = 0; q < offL; ++q) A[q] = T(0);
 	for (int j = lane; j < mlt; j += 64)
 	{
 		const float4 q = pos[i0 + j];
-		p2m_tl_accum<P>(q.x - cx, q.y - cy, q.z - cz, A);
+		p2m_tl_accum<P>((T)q.x - (T)cx, (T)q.y - (T)cy, (T)q.z - (T)cz, A);
 	}
 #pragma unroll
 	for (int q = 4; q < offL; ++q)
 		for (int o = 32; o > 0; o >>= 1) A[q] += __shfl_xor(A[q], o);
-	float *M = t.mpole + (size_t)node * offL;
+	T *M = t.mpole + (size_t)node * offL;
 	if (lane == 0)
 	{
 		t.mult[node] = mlt;
 		t.csz[node] = make_float4(cx, cy, cz, 0.f);
-		M[0] = (float)mlt; M[1] = 0.f; M[2] = 0.f; M[3] = 0.f;
+		M[0] = (T)mlt; M[1] = T(0); M[2] = T(0); M[3] = T(0);
 	}
 	// lane q stores component q (every lane holds the full sums after the butterfly)
 #pragma unroll
@@ -161,8 +165,8 @@ __device__ inline void oct_children(int l, int c0, int inds[8])
 }
 
 // ---- M2M, one thread per parent (fmm_cart3_traceless.cuh:110-168) ------------------------------------------------
-template <int P>
-__global__ __launch_bounds__(kBlock) void oct_m2m_kernel(OctView t, int l)
+template <int P, typename T>
+__global__ __launch_bounds__(kBlock) void oct_m2m_kernel(OctView<T> t, int l)
 {
 	constexpr int offL = NBCO_OFFL(P);
 	const int c0 = blockIdx.x * kBlock + threadIdx.x;
@@ -181,44 +185,45 @@ __global__ __launch_bounds__(kBlock) void oct_m2m_kernel(OctView t, int l)
 		cx += f * cc.x; cy += f * cc.y; cz += f * cc.z;
 		mlt += mq;
 	}
-	float *M = t.mpole + (size_t)node * offL;
+	T *M = t.mpole + (size_t)node * offL;
 	if (mlt > 0)
 	{
 		const float d = (float)mlt;
 		cx /= d; cy /= d; cz /= d;
-		float A[offL];
+		T A[offL];
 #pragma unroll
-		for (int q = 0; q < offL; ++q) A[q] = 0.f;
+		for (int q = 0; q < offL; ++q) A[q] = T(0);
 		for (int q = 0; q < 8; ++q)
 		{
 			if (t.mult[inds[q]] == 0) continue;
 			const float4 cc = t.csz[inds[q]];
-			m2m_tl_accum<P>(t.mpole + (size_t)inds[q] * offL, cx - cc.x, cy - cc.y, cz - cc.z, A);
+			m2m_tl_accum<P>((const T *)(t.mpole + (size_t)inds[q] * offL), (T)cx - (T)cc.x, (T)cy - (T)cc.y, (T)cz - (T)cc.z, A);
 		}
-		M[0] = (float)mlt; M[1] = 0.f; M[2] = 0.f; M[3] = 0.f;
+		M[0] = (T)mlt; M[1] = T(0); M[2] = T(0); M[3] = T(0);
 #pragma unroll
 		for (int q = 4; q < offL; ++q) M[q] = A[q];
 	}
 	else
-		for (int q = 0; q < offL; ++q) M[q] = 0.f;
+		for (int q = 0; q < offL; ++q) M[q] = T(0);
 	t.mult[node] = mlt;
 	t.csz[node] = make_float4(cx, cy, cz, 0.f);
 }
 
 // symmetric-layout copy of the traceless multipoles, orders 0..P-1 (the first 2n+1 entries of both layouts coincide;
 // the rest follows from tracelessness, fmm_cart_base3.cuh:611-623)
-__global__ __launch_bounds__(kBlock) void oct_expand_kernel(OctView t, int P, int first)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void oct_expand_kernel(OctView<T> t, int P, int first)
 {
 	const int offL = (P + 1) * (P + 1), offM = P * (P + 1) * (P + 2) / 6;
 	for (int node = first + blockIdx.x * kBlock + threadIdx.x; node < t.ntot; node += gridDim.x * kBlock)
 	{
 		if (t.mult[node] == 0) continue;
-		const float *T = t.mpole + (size_t)node * offL;
-		float *S = t.msym + (size_t)node * offM;
+		const T *Tl = t.mpole + (size_t)node * offL;
+		T *S = t.msym + (size_t)node * offM;
 		for (int n = 0; n < P; ++n)
 		{
-			float *Sn = S + n * (n + 1) * (n + 2) / 6;
-			const float *Tn = T + n * n;
+			T *Sn = S + n * (n + 1) * (n + 2) / 6;
+			const T *Tn = Tl + n * n;
 			for (int q = 0; q < 2 * n + 1; ++q) Sn[q] = Tn[q];
 			for (int z = 2; z <= n; ++z)
 				for (int x = n - z; x >= 0; --x)
@@ -239,8 +244,8 @@ __device__ inline int oct_level_of(int node)
 }
 
 // FILL = false: cnt[node] = number of non-empty sources; FILL = true: keys[start[node] ..] = target << shift | source
-template <bool FILL>
-__global__ __launch_bounds__(kBlock) void oct_m2l_list_kernel(OctView t, int radius, int first, int *__restrict__ cnt, const int *__restrict__ start,
+template <bool FILL, typename T>
+__global__ __launch_bounds__(kBlock) void oct_m2l_list_kernel(OctView<T> t, int radius, int first, int *__restrict__ cnt, const int *__restrict__ start,
                                                               int shift, uint64_t *__restrict__ keys)
 {
 	for (int node = blockIdx.x * kBlock + threadIdx.x; node < t.ntot; node += gridDim.x * kBlock)
@@ -272,8 +277,8 @@ __global__ __launch_bounds__(kBlock) void oct_m2l_list_kernel(OctView t, int rad
 }
 
 // ---- L2L: one thread per child cell (fmm_cart3_symmetric.cuh:293-334) ---------------------------------------------
-template <int P>
-__global__ __launch_bounds__(kBlock) void oct_l2l_kernel(OctView t, int lchild)
+template <int P, typename T>
+__global__ __launch_bounds__(kBlock) void oct_l2l_kernel(OctView<T> t, int lchild)
 {
 	constexpr int offL = NBCO_OFFL(P);
 	const int c = blockIdx.x * kBlock + threadIdx.x;
@@ -283,19 +288,20 @@ __global__ __launch_bounds__(kBlock) void oct_l2l_kernel(OctView t, int lchild)
 	const int sl = 1 << lchild, sp = sl >> 1;
 	const int i = c / (sl * sl), jk = c - i * sl * sl, j = jk / sl, k = jk - j * sl;
 	const int parent = oct_beg(lchild - 1) + ((i >> 1) * sp + (j >> 1)) * sp + (k >> 1);
-	float Lp[offL], O[offL];
+	T Lp[offL], O[offL];
 #pragma unroll
 	for (int q = 0; q < offL; ++q) Lp[q] = t.local[(size_t)parent * offL + q];
 	const float4 cc = t.csz[node], cp = t.csz[parent];
-	l2l_body<P>(Lp, cc.x - cp.x, cc.y - cp.y, cc.z - cp.z, O);
-	float *Lc = t.local + (size_t)node * offL;
+	l2l_body<P>(Lp, (T)cc.x - (T)cp.x, (T)cc.y - (T)cp.y, (T)cc.z - (T)cp.z, O);
+	T *Lc = t.local + (size_t)node * offL;
 #pragma unroll
 	for (int q = 1; q < offL; ++q) Lc[q] += O[q];
 }
 
 // ---- P2P work units (appel.cuh:320-366: (2r+1)^2 neighbour columns, contiguous z-runs merged) ----------------------
 // per leaf cell: number of target groups, of source descriptors and of chunks
-__global__ __launch_bounds__(kBlock) void oct_p2p_count_kernel(OctView t, int radius, int tpl, int *__restrict__ ngroup, int *__restrict__ ndesc,
+template <typename T>
+__global__ __launch_bounds__(kBlock) void oct_p2p_count_kernel(OctView<T> t, int radius, int tpl, int *__restrict__ ngroup, int *__restrict__ ndesc,
                                                                int *__restrict__ nchunk)
 {
 	const int m = oct_cnt(t.L), beg = oct_beg(t.L), side = t.side;
@@ -321,7 +327,8 @@ __global__ __launch_bounds__(kBlock) void oct_p2p_count_kernel(OctView t, int ra
 }
 
 // per leaf cell: target groups (first particle, count), the cell of every group, and the cell's source descriptors
-__global__ __launch_bounds__(kBlock) void oct_p2p_fill_kernel(OctView t, int radius, int tpl, const int *__restrict__ group_off,
+template <typename T>
+__global__ __launch_bounds__(kBlock) void oct_p2p_fill_kernel(OctView<T> t, int radius, int tpl, const int *__restrict__ group_off,
                                                               const int *__restrict__ desc_off, int *__restrict__ grp_index,
                                                               int *__restrict__ grp_mult, int *__restrict__ grp_cell, int2 *__restrict__ desc)
 {
@@ -369,8 +376,8 @@ __global__ __launch_bounds__(kBlock) void oct_p2p_chunk_kernel(const int *__rest
 }
 
 // ---- L2P + near field + rescale: one thread per particle in cell order (fmm_cart3_symmetric.cuh:362-385) ---------
-template <int P>
-__global__ __launch_bounds__(kBlock) void oct_l2p_kernel(OctView t, const float4 *__restrict__ pos, const uint32_t *__restrict__ keys,
+template <int P, typename T>
+__global__ __launch_bounds__(kBlock) void oct_l2p_kernel(OctView<T> t, const float4 *__restrict__ pos, const uint32_t *__restrict__ keys,
                                                          const float4 *__restrict__ near, const int *__restrict__ group_off,
                                                          const int *__restrict__ desc_off, const int *__restrict__ chunk_off, int tpl,
                                                          int have_near, const float *__restrict__ param, float *__restrict__ a_out)
@@ -380,11 +387,11 @@ __global__ __launch_bounds__(kBlock) void oct_l2p_kernel(OctView t, const float4
 	if (i >= t.n) return;
 	const int c = (int)keys[i], leaf = oct_beg(t.L) + c;
 	const float4 p = pos[i], cc = t.csz[leaf];
-	float Lp[offL];
+	T Lp[offL];
 #pragma unroll
 	for (int q = 0; q < offL; ++q) Lp[q] = t.local[(size_t)leaf * offL + q];
-	float fx, fy, fz;
-	l2p_body<P>(Lp, p.x - cc.x, p.y - cc.y, p.z - cc.z, fx, fy, fz);
+	T fx, fy, fz;
+	l2p_body<P>(Lp, (T)p.x - (T)cc.x, (T)p.y - (T)cc.y, (T)p.z - (T)cc.z, fx, fy, fz);
 	if (have_near)
 	{
 		const int rel = (int)(i - t.index[leaf]), g = rel / tpl, j = rel - g * tpl;
@@ -396,10 +403,10 @@ __global__ __launch_bounds__(kBlock) void oct_l2p_kernel(OctView t, const float4
 			const float4 nr = near[(size_t)ck * tpl + j];
 			nx += nr.x; ny += nr.y; nz += nr.z;
 		}
-		fx += nx; fy += ny; fz += nz;
+		fx += (T)nx; fy += (T)ny; fz += (T)nz;
 	}
-	const float scale = param ? param[0] : 1.f;
-	a_out[3 * i] = fx * scale; a_out[3 * i + 1] = fy * scale; a_out[3 * i + 2] = fz * scale;
+	const T scale = param ? (T)param[0] : T(1);
+	a_out[3 * i] = (float)(fx * scale); a_out[3 * i + 1] = (float)(fy * scale); a_out[3 * i + 2] = (float)(fz * scale);
 }
 
 static int oct_levels(long long n, int p, float dens_inhom)   // fmm_cart3_traceless.cuh:304 / :452-455
@@ -419,7 +426,16 @@ static int scan_ints(nbco_ctx *c, int *in, int *out, size_t count)
 	return NBCO_OK;
 }
 
-template <int P>
+static int m2l_lanes(nbco_ctx *c, int P, const float4 *csz, const float *mpole, float *local, const uint64_t *keys, const int *start, int shift, int ntot)
+{
+	return launch_m2l_lanes(c, P, csz, mpole, local, keys, start, shift, ntot);
+}
+static int m2l_lanes(nbco_ctx *c, int P, const float4 *csz, const double *mpole, double *local, const uint64_t *keys, const int *start, int shift, int ntot)
+{
+	return launch_m2l_lanes_f64(c, P, csz, mpole, local, keys, start, shift, ntot);
+}
+
+template <int P, typename T>
 static int oct_eval(nbco_ctx *c, float *p, float *a, long long n, const float *param)
 {
 	constexpr int offL = NBCO_OFFL(P), offM = P * (P + 1) * (P + 2) / 6;
@@ -433,16 +449,16 @@ static int oct_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 
 	// ---- storage -----------------------------------------------------------------------------------------
 	{
-		size_t bytes = (size_t)ntot * (sizeof(float4) + sizeof(float) * (2 * (size_t)offL + offM) + 2 * sizeof(int)) + 256;
+		size_t bytes = (size_t)ntot * (sizeof(float4) + sizeof(T) * (2 * (size_t)offL + offM) + 2 * sizeof(int)) + 256;
 		NBCO_TRY(c->reserve(c->oct_tree, bytes));
 	}
-	OctView t;
+	OctView<T> t;
 	{
 		char *q = (char *)c->oct_tree.ptr;
 		t.csz = (float4 *)q; q += sizeof(float4) * (size_t)ntot;
-		t.mpole = (float *)q; q += sizeof(float) * (size_t)ntot * offL;
-		t.local = (float *)q; q += sizeof(float) * (size_t)ntot * offL;
-		t.msym = (float *)q; q += sizeof(float) * (size_t)ntot * offM;
+		t.mpole = (T *)q; q += sizeof(T) * (size_t)ntot * offL;
+		t.local = (T *)q; q += sizeof(T) * (size_t)ntot * offL;
+		t.msym = (T *)q; q += sizeof(T) * (size_t)ntot * offM;
 		t.mult = (int *)q; q += sizeof(int) * (size_t)ntot;
 		t.index = (int *)q;   // ntot + 1 entries
 		t.L = L; t.ntot = ntot; t.side = side; t.n = n;
@@ -477,15 +493,15 @@ static int oct_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 		bytes = c->sort_tmp.bytes;
 		NBCO_HIP(rocprim::radix_sort_pairs(c->sort_tmp.ptr, bytes, keys_in, keys, idx_in, idx, (size_t)n, 0u, (unsigned)(3 * L), st));
 		hipLaunchKernelGGL(oct_gather4_kernel, dim3(grid1d(n)), dim3(kBlock), 0, st, (const float4 *)pos_in, (const uint32_t *)idx, pos, n);
-		hipLaunchKernelGGL(oct_index_kernel, dim3(grid1d(m + 1)), dim3(kBlock), 0, st, t, (const uint32_t *)keys);
+		hipLaunchKernelGGL(oct_index_kernel<T>, dim3(grid1d(m + 1)), dim3(kBlock), 0, st, t, (const uint32_t *)keys);
 		NBCO_HIP(hipGetLastError());
 	}
 	// ---- P2M, M2M ----------------------------------------------------------------------------------------
 	{
 		PhaseScope ph(c, NBCO_PH_P2M_M2M);
-		hipLaunchKernelGGL(oct_leaf_kernel<P>, dim3((m + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, t, (const float4 *)pos);
-		for (int l = L - 1; l >= 2; --l) hipLaunchKernelGGL(oct_m2m_kernel<P>, dim3((oct_cnt(l) + kBlock - 1) / kBlock), dim3(kBlock), 0, st, t, l);
-		hipLaunchKernelGGL(oct_expand_kernel, dim3(grid1d(ntot - first)), dim3(kBlock), 0, st, t, P, first);
+		hipLaunchKernelGGL((oct_leaf_kernel<P, T>), dim3((m + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, t, (const float4 *)pos);
+		for (int l = L - 1; l >= 2; --l) hipLaunchKernelGGL((oct_m2m_kernel<P, T>), dim3((oct_cnt(l) + kBlock - 1) / kBlock), dim3(kBlock), 0, st, t, l);
+		hipLaunchKernelGGL(oct_expand_kernel<T>, dim3(grid1d(ntot - first)), dim3(kBlock), 0, st, t, P, first);
 		NBCO_HIP(hipGetLastError());
 	}
 	// ---- work lists: M2L stencil entries, P2P groups / descriptors / chunks -----------------------------------------
@@ -500,12 +516,12 @@ static int oct_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 	while ((1LL << shift) < ntot) ++shift;
 	{
 		PhaseScope ph(c, NBCO_PH_LISTS);
-		hipLaunchKernelGGL(oct_m2l_list_kernel<false>, dim3(grid1d(ntot)), dim3(kBlock), 0, st, t, radius, first, m2l_cnt, (const int *)nullptr, shift,
+		hipLaunchKernelGGL((oct_m2l_list_kernel<false, T>), dim3(grid1d(ntot)), dim3(kBlock), 0, st, t, radius, first, m2l_cnt, (const int *)nullptr, shift,
 		                   (uint64_t *)nullptr);
 		NBCO_TRY(scan_ints(c, m2l_cnt, m2l_start, (size_t)ntot + 1));
 		if (c->o.coll)
 		{
-			hipLaunchKernelGGL(oct_p2p_count_kernel, dim3(grid1d(m + 1)), dim3(kBlock), 0, st, t, radius, tpl, ngroup, ndesc, nchunk);
+			hipLaunchKernelGGL(oct_p2p_count_kernel<T>, dim3(grid1d(m + 1)), dim3(kBlock), 0, st, t, radius, tpl, ngroup, ndesc, nchunk);
 			NBCO_TRY(scan_ints(c, ngroup, group_off, (size_t)m + 1));
 			NBCO_TRY(scan_ints(c, ndesc, desc_off, (size_t)m + 1));
 			NBCO_TRY(scan_ints(c, nchunk, chunk_off, (size_t)m + 1));
@@ -522,7 +538,7 @@ static int oct_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 		if (nm2l < 0 || nck < 0) return c->fail(NBCO_ERR_CAPACITY, "nbco_fmm_traceless: work list size overflows 32 bits");
 		NBCO_TRY(c->reserve(c->m2l_keys_alt, sizeof(uint64_t) * (size_t)(nm2l + 1)));
 		if (nm2l > 0)
-			hipLaunchKernelGGL(oct_m2l_list_kernel<true>, dim3(grid1d(ntot)), dim3(kBlock), 0, st, t, radius, first, (int *)nullptr, (const int *)m2l_start,
+			hipLaunchKernelGGL((oct_m2l_list_kernel<true, T>), dim3(grid1d(ntot)), dim3(kBlock), 0, st, t, radius, first, (int *)nullptr, (const int *)m2l_start,
 			                   shift, c->m2l_keys_alt.as<uint64_t>());
 		if (c->o.coll)
 		{
@@ -531,7 +547,7 @@ static int oct_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 			NBCO_TRY(c->reserve(c->p2p_chunks, sizeof(int4) * (size_t)(nck + 1)));
 			NBCO_TRY(c->reserve(c->part, sizeof(float4) * (size_t)nck * (size_t)tpl + 256));
 			int *grp_index = c->oct_groups.as<int>(), *grp_mult = grp_index + (ngr + 1), *grp_cell = grp_mult + (ngr + 1);
-			hipLaunchKernelGGL(oct_p2p_fill_kernel, dim3(grid1d(m)), dim3(kBlock), 0, st, t, radius, tpl, (const int *)group_off, (const int *)desc_off,
+			hipLaunchKernelGGL(oct_p2p_fill_kernel<T>, dim3(grid1d(m)), dim3(kBlock), 0, st, t, radius, tpl, (const int *)group_off, (const int *)desc_off,
 			                   grp_index, grp_mult, grp_cell, c->p2p_keys.as<int2>());
 			hipLaunchKernelGGL(oct_p2p_chunk_kernel, dim3(grid1d(std::max<long long>(ngr, 1))), dim3(kBlock), 0, st, (const int *)(group_off + m),
 			                   (const int *)grp_cell, (const int *)group_off, (const int *)desc_off, (const int *)chunk_off, (const int *)grp_index,
@@ -558,18 +574,18 @@ static int oct_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 	// ---- M2L, L2L ------------------------------------------------------------------------------------------
 	{
 		PhaseScope ph(c, NBCO_PH_M2L);
-		NBCO_HIP(hipMemsetAsync(t.local, 0, sizeof(float) * (size_t)ntot * offL, st));
-		if (nm2l > 0) NBCO_TRY(launch_m2l_lanes(c, P, t.csz, t.msym, t.local, c->m2l_keys_alt.as<uint64_t>(), m2l_start, shift, ntot));
+		NBCO_HIP(hipMemsetAsync(t.local, 0, sizeof(T) * (size_t)ntot * offL, st));
+		if (nm2l > 0) NBCO_TRY(m2l_lanes(c, P, t.csz, t.msym, t.local, c->m2l_keys_alt.as<uint64_t>(), m2l_start, shift, ntot));
 	}
 	{
 		PhaseScope ph(c, NBCO_PH_L2L);
-		for (int lc = 3; lc <= L; ++lc) hipLaunchKernelGGL(oct_l2l_kernel<P>, dim3((oct_cnt(lc) + kBlock - 1) / kBlock), dim3(kBlock), 0, st, t, lc);
+		for (int lc = 3; lc <= L; ++lc) hipLaunchKernelGGL((oct_l2l_kernel<P, T>), dim3((oct_cnt(lc) + kBlock - 1) / kBlock), dim3(kBlock), 0, st, t, lc);
 		NBCO_HIP(hipGetLastError());
 	}
 	// ---- L2P + near field + rescale -------------------------------------------------------------------------
 	{
 		PhaseScope ph(c, NBCO_PH_L2P);
-		hipLaunchKernelGGL(oct_l2p_kernel<P>, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, t, (const float4 *)pos, (const uint32_t *)keys,
+		hipLaunchKernelGGL((oct_l2p_kernel<P, T>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, t, (const float4 *)pos, (const uint32_t *)keys,
 		                   (const float4 *)near, (const int *)group_off, (const int *)desc_off, (const int *)chunk_off, tpl, have_near ? 1 : 0, param, a);
 		NBCO_HIP(hipGetLastError());
 	}
@@ -585,6 +601,7 @@ static int oct_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 	OctTreeDev &o = c->oct;
 	o.L = L; o.ntot = ntot; o.order = P; o.n = n; o.csz = t.csz; o.mpole = t.mpole; o.local = t.local; o.mult = t.mult; o.index = t.index;
 	o.keys = keys; o.perm = idx; o.m2l_entries = nm2l; o.p2p_groups = ngr; o.p2p_desc = h_tot[2]; o.p2p_chunks = nck; o.tpl = tpl;
+	o.real_bytes = (int)sizeof(T);
 	o.valid = true;
 	return NBCO_OK;
 }
@@ -595,20 +612,15 @@ int fmm_oct_traceless_eval(nbco_ctx *c, float *p, float *a, long long n, const f
 {
 	if (n <= 0) return c->fail(NBCO_ERR_ARG, "nbco_fmm_traceless: n must be positive");
 	if (n > 0x7fffffffLL / 4) return c->fail(NBCO_ERR_UNSUPPORTED, "nbco_fmm_traceless: n too large for 32-bit indices");
+	const bool f64 = c->o.far_fp64 != 0;
+#define NBCO_OCT_CASE(PP) case PP: return f64 ? oct_eval<PP, double>(c, p, a, n, param) : oct_eval<PP, float>(c, p, a, n, param);
 	switch (c->o.fmm_order)
 	{
-	case 1: return oct_eval<1>(c, p, a, n, param);
-	case 2: return oct_eval<2>(c, p, a, n, param);
-	case 3: return oct_eval<3>(c, p, a, n, param);
-	case 4: return oct_eval<4>(c, p, a, n, param);
-	case 5: return oct_eval<5>(c, p, a, n, param);
-	case 6: return oct_eval<6>(c, p, a, n, param);
-	case 7: return oct_eval<7>(c, p, a, n, param);
-	case 8: return oct_eval<8>(c, p, a, n, param);
-	case 9: return oct_eval<9>(c, p, a, n, param);
-	case 10: return oct_eval<10>(c, p, a, n, param);
+	NBCO_OCT_CASE(1) NBCO_OCT_CASE(2) NBCO_OCT_CASE(3) NBCO_OCT_CASE(4) NBCO_OCT_CASE(5)
+	NBCO_OCT_CASE(6) NBCO_OCT_CASE(7) NBCO_OCT_CASE(8) NBCO_OCT_CASE(9) NBCO_OCT_CASE(10)
 	default: return c->fail(NBCO_ERR_UNSUPPORTED, "nbco_fmm_traceless: generated operators exist for orders 1..10");
 	}
+#undef NBCO_OCT_CASE
 }
 
 int oct_copy_out(nbco_ctx *c, int which, void *dst, long long bytes)
@@ -623,8 +635,8 @@ int oct_copy_out(nbco_ctx *c, int which, void *dst, long long bytes)
 	case NBCO_OCT_MULT: src = o.mult; need = 4 * (size_t)o.ntot; break;
 	case NBCO_OCT_INDEX: src = o.index; need = 4 * (size_t)o.ntot; break;
 	case NBCO_OCT_CENTER4: src = o.csz; need = 16 * (size_t)o.ntot; break;
-	case NBCO_OCT_MPOLE: src = o.mpole; need = 4 * (size_t)o.ntot * offL; break;
-	case NBCO_OCT_LOCAL: src = o.local; need = 4 * (size_t)o.ntot * offL; break;
+	case NBCO_OCT_MPOLE: src = o.mpole; need = (size_t)o.real_bytes * (size_t)o.ntot * offL; break;
+	case NBCO_OCT_LOCAL: src = o.local; need = (size_t)o.real_bytes * (size_t)o.ntot * offL; break;
 	case NBCO_OCT_KEYS: src = o.keys; need = 4 * (size_t)o.n; break;
 	case NBCO_OCT_PERM: src = o.perm; need = 4 * (size_t)o.n; break;
 	default: return c->fail(NBCO_ERR_ARG, "nbco_oct_copy: unknown array");

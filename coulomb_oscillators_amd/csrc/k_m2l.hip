@@ -11,51 +11,54 @@
 
 namespace {
 
-template <int P>
-__device__ __forceinline__ void m2l_body(const float *__restrict__ Mp, float ux, float uy, float uz, float rinv,
-                                         float (&L)[(P + 1) * (P + 1) - 1]);
+__device__ __forceinline__ float nb_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double nb_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float nb_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double nb_sqrt(double x) { return sqrt(x); }
+
+template <int P, typename T> struct M2LBody;   // generic in the scalar type: float, or double for the fp64 far field
 
 #include "m2l_gen.inc"
 
 constexpr int kTargets = 8;   // target nodes per wave
 
-template <int P>
-__global__ __launch_bounds__(64) void m2l_lane_kernel(const float4 *__restrict__ csz, const float *__restrict__ mpole,
-                                                      float *__restrict__ local, const uint64_t *__restrict__ keys,
+template <int P, typename T>
+__global__ __launch_bounds__(64) void m2l_lane_kernel(const float4 *__restrict__ csz, const T *__restrict__ mpole,
+                                                      T *__restrict__ local, const uint64_t *__restrict__ keys,
                                                       const int *__restrict__ start, int shift, int ntot, float eps2)
 {
 	constexpr int offM = P * (P + 1) * (P + 2) / 6, offL = (P + 1) * (P + 1), NOUT = offL - 1;
 	constexpr int CPL = (NOUT + 63) / 64;   // components per lane in the reduction walk
-	__shared__ float buf[64][NOUT + 1 + (NOUT % 2)];   // odd row stride: conflict-free column writes
+	__shared__ T buf[64][NOUT + 1 + (NOUT % 2)];   // odd row stride: conflict-free column writes
 	__shared__ int tg[64];
 	const int lane = threadIdx.x;
 	const int t0 = blockIdx.x * kTargets, t1 = min(t0 + kTargets, ntot);
 	const int i0 = start[t0], i1 = start[t1];
 	const uint64_t mask = (1ull << shift) - 1;
-	float acc[CPL];
+	T acc[CPL];
 #pragma unroll
-	for (int q = 0; q < CPL; ++q) acc[q] = 0.f;
+	for (int q = 0; q < CPL; ++q) acc[q] = T(0);
 	int cur = -1;
 	for (int base = i0; base < i1; base += 64)
 	{
 		const int i = base + lane;
 		int tgt = -1;
-		float L[NOUT];
+		T L[NOUT];
 		if (i < i1)
 		{
 			const uint64_t key = keys[i];
 			tgt = (int)(key >> shift);
 			const int src = (int)(key & mask);
 			const float4 ct = csz[tgt], cs = csz[src];
-			float dx = ct.x - cs.x, dy = ct.y - cs.y, dz = ct.z - cs.z;
-			const float r = sqrtf(dx * dx + dy * dy + dz * dz + eps2);
-			const float rinv = 1.f / r;
-			m2l_body<P>(mpole + (size_t)src * offM, dx * rinv, dy * rinv, dz * rinv, rinv, L);
+			const T dx = (T)ct.x - (T)cs.x, dy = (T)ct.y - (T)cs.y, dz = (T)ct.z - (T)cs.z;
+			const T r = nb_sqrt(dx * dx + dy * dy + dz * dz + (T)eps2);
+			const T rinv = T(1) / r;
+			M2LBody<P, T>::run(mpole + (size_t)src * offM, dx * rinv, dy * rinv, dz * rinv, rinv, L);
 		}
 		else
 		{
 #pragma unroll
-			for (int c = 0; c < NOUT; ++c) L[c] = 0.f;
+			for (int c = 0; c < NOUT; ++c) L[c] = T(0);
 		}
 #pragma unroll
 		for (int c = 0; c < NOUT; ++c) buf[lane][c] = L[c];
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(64) void m2l_lane_kernel(const float4 *__restrict__
 					}
 				}
 #pragma unroll
-				for (int q = 0; q < CPL; ++q) acc[q] = 0.f;
+				for (int q = 0; q < CPL; ++q) acc[q] = T(0);
 				cur = t;
 			}
 #pragma unroll
@@ -100,12 +103,32 @@ __global__ __launch_bounds__(64) void m2l_lane_kernel(const float4 *__restrict__
 	}
 }
 
-template <int P>
-static void launch(nbco_ctx *c, const float4 *csz, const float *mpole, float *local, const uint64_t *keys, const int *start, int shift,
-                   int ntot)
+template <int P, typename T>
+static void launch(nbco_ctx *c, const float4 *csz, const T *mpole, T *local, const uint64_t *keys, const int *start, int shift, int ntot)
 {
 	const int grid = (ntot + kTargets - 1) / kTargets;
-	hipLaunchKernelGGL(m2l_lane_kernel<P>, dim3(grid), dim3(64), 0, c->stream, csz, mpole, local, keys, start, shift, ntot, c->o.eps2);
+	hipLaunchKernelGGL((m2l_lane_kernel<P, T>), dim3(grid), dim3(64), 0, c->stream, csz, mpole, local, keys, start, shift, ntot, c->o.eps2);
+}
+
+template <typename T>
+static int dispatch(nbco_ctx *c, int P, const float4 *csz, const T *mpole, T *local, const uint64_t *keys, const int *start, int shift, int ntot)
+{
+	switch (P)
+	{
+	case 1: launch<1, T>(c, csz, mpole, local, keys, start, shift, ntot); break;
+	case 2: launch<2, T>(c, csz, mpole, local, keys, start, shift, ntot); break;
+	case 3: launch<3, T>(c, csz, mpole, local, keys, start, shift, ntot); break;
+	case 4: launch<4, T>(c, csz, mpole, local, keys, start, shift, ntot); break;
+	case 5: launch<5, T>(c, csz, mpole, local, keys, start, shift, ntot); break;
+	case 6: launch<6, T>(c, csz, mpole, local, keys, start, shift, ntot); break;
+	case 7: launch<7, T>(c, csz, mpole, local, keys, start, shift, ntot); break;
+	case 8: launch<8, T>(c, csz, mpole, local, keys, start, shift, ntot); break;
+	case 9: launch<9, T>(c, csz, mpole, local, keys, start, shift, ntot); break;
+	case 10: launch<10, T>(c, csz, mpole, local, keys, start, shift, ntot); break;
+	default: return c->fail(NBCO_ERR_UNSUPPORTED, "launch_m2l_lanes: order not generated");
+	}
+	NBCO_HIP(hipGetLastError());
+	return NBCO_OK;
 }
 
 } // namespace
@@ -114,20 +137,11 @@ static void launch(nbco_ctx *c, const float4 *csz, const float *mpole, float *lo
 int launch_m2l_lanes(nbco_ctx *c, int P, const float4 *csz, const float *mpole, float *local, const uint64_t *keys, const int *start,
                      int shift, int ntot)
 {
-	switch (P)
-	{
-	case 1: launch<1>(c, csz, mpole, local, keys, start, shift, ntot); break;
-	case 2: launch<2>(c, csz, mpole, local, keys, start, shift, ntot); break;
-	case 3: launch<3>(c, csz, mpole, local, keys, start, shift, ntot); break;
-	case 4: launch<4>(c, csz, mpole, local, keys, start, shift, ntot); break;
-	case 5: launch<5>(c, csz, mpole, local, keys, start, shift, ntot); break;
-	case 6: launch<6>(c, csz, mpole, local, keys, start, shift, ntot); break;
-	case 7: launch<7>(c, csz, mpole, local, keys, start, shift, ntot); break;
-	case 8: launch<8>(c, csz, mpole, local, keys, start, shift, ntot); break;
-	case 9: launch<9>(c, csz, mpole, local, keys, start, shift, ntot); break;
-	case 10: launch<10>(c, csz, mpole, local, keys, start, shift, ntot); break;
-	default: return c->fail(NBCO_ERR_UNSUPPORTED, "launch_m2l_lanes: order not generated");
-	}
-	NBCO_HIP(hipGetLastError());
-	return NBCO_OK;
+	return dispatch<float>(c, P, csz, mpole, local, keys, start, shift, ntot);
+}
+// fp64 far field (octree evaluator with opts.far_fp64): centres stay fp32, everything else is double
+int launch_m2l_lanes_f64(nbco_ctx *c, int P, const float4 *csz, const double *mpole, double *local, const uint64_t *keys, const int *start,
+                         int shift, int ntot)
+{
+	return dispatch<double>(c, P, csz, mpole, local, keys, start, shift, ntot);
 }

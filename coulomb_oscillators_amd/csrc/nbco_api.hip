@@ -116,6 +116,7 @@ int nbco_opts_default(nbco_opts *o)
 	o->m2l_first = 0;
 	o->sync = 1;
 	o->list_factor = 48;
+	o->far_fp64 = 0;
 	o->stream = nullptr;
 	return NBCO_OK;
 }
@@ -280,6 +281,7 @@ int nbco_oct_get_info(nbco_ctx *c, nbco_oct_info *out)
 	const OctTreeDev &o = c->oct;
 	out->L = o.L; out->ntot = o.ntot; out->order = o.order; out->tpl = o.tpl; out->n = o.n;
 	out->m2l_entries = o.m2l_entries; out->p2p_groups = o.p2p_groups; out->p2p_desc = o.p2p_desc; out->p2p_chunks = o.p2p_chunks;
+	out->real_bytes = o.real_bytes;
 	return NBCO_OK;
 }
 int nbco_oct_copy(nbco_ctx *c, int which, void *host_dst, long long host_bytes)

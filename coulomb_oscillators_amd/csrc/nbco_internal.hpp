@@ -64,7 +64,8 @@ struct OctTreeDev
 	int L = 0, ntot = 0, order = 0, tpl = 0;
 	long long n = 0, m2l_entries = 0, p2p_groups = 0, p2p_desc = 0, p2p_chunks = 0;
 	float4 *csz = nullptr;
-	float *mpole = nullptr, *local = nullptr;
+	void *mpole = nullptr, *local = nullptr;   // float or double (real_bytes)
+	int real_bytes = 4;
 	int *mult = nullptr, *index = nullptr;
 	uint32_t *keys = nullptr, *perm = nullptr;
 };
@@ -213,3 +214,5 @@ int launch_l2p_gen(nbco_ctx *c, int P, const float4 *pos, const float *center, c
 // k_m2l.hip
 int launch_m2l_lanes(nbco_ctx *c, int P, const float4 *csz, const float *mpole, float *local, const uint64_t *keys, const int *start,
                      int shift, int ntot);
+int launch_m2l_lanes_f64(nbco_ctx *c, int P, const float4 *csz, const double *mpole, double *local, const uint64_t *keys, const int *start,
+                         int shift, int ntot);

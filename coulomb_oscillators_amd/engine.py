@@ -30,7 +30,8 @@ class EngineError(RuntimeError):
 class Opts(C.Structure):
     _fields_ = [("fmm_order", C.c_int), ("tree_radius", C.c_float), ("eps2", C.c_float), ("coll", C.c_int),
                 ("unsort", C.c_int), ("dens_inhom", C.c_float), ("tree_L", C.c_int), ("tree_steps", C.c_int),
-                ("m2l_first", C.c_int), ("sync", C.c_int), ("list_factor", C.c_int), ("stream", C.c_void_p)]
+                ("m2l_first", C.c_int), ("sync", C.c_int), ("list_factor", C.c_int), ("far_fp64", C.c_int),
+                ("stream", C.c_void_p)]
 
 
 class KdInfo(C.Structure):
@@ -42,7 +43,7 @@ class KdInfo(C.Structure):
 class OctInfo(C.Structure):
     _fields_ = [("L", C.c_int), ("ntot", C.c_int), ("order", C.c_int), ("tpl", C.c_int), ("n", C.c_longlong),
                 ("m2l_entries", C.c_longlong), ("p2p_groups", C.c_longlong), ("p2p_desc", C.c_longlong),
-                ("p2p_chunks", C.c_longlong)]
+                ("p2p_chunks", C.c_longlong), ("real_bytes", C.c_int)]
 
 
 OCT_FIELDS = {"mult": 0, "index": 1, "center4": 2, "mpole": 3, "local": 4, "keys": 5, "perm": 6}
@@ -304,8 +305,9 @@ class Engine:
         import numpy as np
         info = self.oct_info()
         off = (info.order + 1) ** 2
+        real = np.float64 if info.real_bytes == 8 else np.float32
         shapes = {"mult": ((info.ntot,), np.int32), "index": ((info.ntot,), np.int32), "center4": ((info.ntot, 4), np.float32),
-                  "mpole": ((info.ntot, off), np.float32), "local": ((info.ntot, off), np.float32),
+                  "mpole": ((info.ntot, off), real), "local": ((info.ntot, off), real),
                   "keys": ((info.n,), np.uint32), "perm": ((info.n,), np.uint32)}
         shape, dt = shapes[name]
         out = np.empty(shape, dtype=dt)

@@ -75,6 +75,12 @@ typedef struct nbco_opts {
 	                       lists are kept in 16 regions of list_factor * nodes / 8 pairs each; a region
 	                       that runs full makes the evaluation return NBCO_ERR_CAPACITY with the
 	                       caller's arrays untouched (default 48: ~10x the lists of the BASELINE runs) */
+	int   far_fp64;     /* != 0: nbco_fmm_traceless keeps multipole / local expansions in double and does
+	                       P2M, M2M, M2L, L2L and L2P in fp64 (BASELINE config 5: fp64 far field, fp32 P2P).
+	                       Positions, cell centres and the near field stay fp32.  The fp32 far field overflows
+	                       beyond N ~ 1e5 at orders 9-10 (r^-11 19!! ~ 1e40); this mode does not.
+	                       No reference counterpart other than the -DSCAL=double build.  nbco_fmm_kdtree
+	                       rejects it (NBCO_ERR_UNSUPPORTED). */
 	void *stream;       /* hipStream_t; NULL = the null stream */
 } nbco_opts;
 
@@ -143,19 +149,21 @@ int nbco_kd_copy(nbco_ctx *c, int which, void *host_dst, long long host_bytes);
 
 /* ---- octree-traceless evaluator introspection (fmmTree, fmm_cart3_symmetric.cuh:24-30) ---------------------
  * Valid after nbco_fmm_traceless.  Cells are level-major (level l starts at (8^l - 1) / 7), row-major inside a
- * level; tuples are traceless, (order + 1)^2 floats per cell (orders 0..order). */
+ * level; tuples are traceless, (order + 1)^2 reals per cell (orders 0..order); a real is a float, or a double
+ * when the evaluation ran with opts.far_fp64 (nbco_oct_info.real_bytes). */
 typedef struct nbco_oct_info {
 	int L, ntot, order;
 	int tpl;                /* target-group width of the near-field work units */
 	long long n;
 	long long m2l_entries;  /* directed (target, source) stencil entries with a non-empty source */
 	long long p2p_groups, p2p_desc, p2p_chunks;
+	int real_bytes;         /* 4 or 8: element size of NBCO_OCT_MPOLE / NBCO_OCT_LOCAL */
 } nbco_oct_info;
 int nbco_oct_get_info(nbco_ctx *c, nbco_oct_info *out);
 enum {
 	NBCO_OCT_MULT = 0, NBCO_OCT_INDEX = 1,   /* int[ntot] (index: leaves only) */
 	NBCO_OCT_CENTER4 = 2,                    /* float[ntot][4]: centre xyz, 0 */
-	NBCO_OCT_MPOLE = 3, NBCO_OCT_LOCAL = 4,  /* float[ntot][(order+1)^2] */
+	NBCO_OCT_MPOLE = 3, NBCO_OCT_LOCAL = 4,  /* real[ntot][(order+1)^2] */
 	NBCO_OCT_KEYS = 5,                       /* uint32[n]: sorted cell keys (appel.cuh:44-55) */
 	NBCO_OCT_PERM = 6                        /* uint32[n]: cell-order position -> caller's index */
 };

@@ -185,3 +185,86 @@ def test_integrate_with_octree_evaluator(engine, oracle32):
     ka, kb = key(got[0]), key(ref[0])
     np.testing.assert_allclose(got[0][ka], ref[0][kb], rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(got[1][ka], ref[1][kb], rtol=1e-4, atol=1e-6)
+
+
+# ---- fp64 far field (opts.far_fp64; BASELINE config 5: fp64 far field / fp32 P2P) ---------------------------------
+@pytest.mark.parametrize("n,p,kind", [(20000, 6, "blob"), (8000, 10, "blob"), (4096, 10, "gauss"), (3000, 3, "cube")])
+def test_far_fp64_against_double_oracle(engine, oracle32, oracle64, n, p, kind):
+    """expansions kept and shifted in double: the yardstick is the oracle built with SCAL = double, run on the same
+    (fp32-valued) positions.  Cell centres stay fp32 here, so the tuples agree to fp32 centre rounding, not to 1e-15."""
+    o, o64 = oracle32, oracle64
+    buf = state(o, n, kind)
+    par = o.params(n)
+    pv64, want64 = o64.fmm_oct_traceless(buf[:2].astype(np.float64), par.astype(np.float64), p=p, threads=8)
+    tree64 = o64.oct_tree(n)
+    ex64 = o64.oct_expansions(p)
+    got_pv, got = run_gpu(engine, buf, par, n, fmm_order=p, far_fp64=1)
+    info = engine.oct_info()
+    assert info.real_bytes == 8
+    mp, lc = engine.oct_array("mpole"), engine.oct_array("local")
+    assert mp.dtype == np.float64 and lc.dtype == np.float64
+    same_cells = np.array_equal(engine.oct_array("keys").astype(np.int64), tree64["keys"])
+    _, got32 = run_gpu(engine, buf, par, n, fmm_order=p, far_fp64=0)
+    assert engine.oct_info().real_bytes == 4
+    engine.set(far_fp64=0)
+    if not same_cells:
+        pytest.skip("a particle sits within fp32 rounding of a cell face: the double oracle bins it differently")
+    np.testing.assert_array_equal(got_pv, pv64.astype(np.float32))
+    e64, e32 = force_err(got, want64), force_err(got32, want64)
+    assert e64 < 1e-5
+    assert e64 < 1.5 * e32 + 2e-7          # never worse than the all-fp32 evaluation
+    first = 9
+    occupied = tree64["mult"][first:] > 0
+    for name, g in (("mpole", mp), ("local", lc)):
+        w = ex64[name][first:][occupied]
+        sc = np.abs(w).max(axis=0, keepdims=True).clip(1e-300)
+        assert (np.abs(g[first:][occupied] - w) / sc).max() < 2e-5, name
+
+
+def test_far_fp64_keeps_high_orders_in_range(engine, oracle32):
+    """p = 10 on the BASELINE Gaussian ball with six octree levels (config 5 has seven): the fp32 far field leaves its
+    range (r^-11 19!! ~ 1e40, SURVEY N8: NaN / inf in the result), the fp64 far field stays finite and follows the
+    direct sum.  With the reference's default stencil radius 1 the error is truncation-bound (3e-4, the same in both
+    precisions wherever fp32 survives); radius 2 shows what is left: 1.5e-5, the fp32 near field."""
+    import torch
+    o = oracle32
+    n, p = 1 << 20, 10
+    buf = state(o, n, "gauss")
+    par = o.params(n)
+    prm = dev(par)
+    a = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+    ref = torch.zeros_like(a)
+    for radius, bound in ((1.0, 6e-4), (2.0, 4e-5)):
+        d = dev(buf[:2])
+        engine.set(fmm_order=p, far_fp64=1, dens_inhom=4.0, tree_radius=radius)
+        engine.fmm_cart3_traceless(d, a, n, prm)
+        torch.cuda.synchronize()
+        assert engine.oct_info().L == 6
+        assert bool(torch.isfinite(a).all())
+        engine.direct(d, ref, n, prm)          # d is now in cell order; the direct sum runs on the same order
+        torch.cuda.synchronize()
+        err = engine.mean_relerr(a, ref, n)
+        assert err < bound, (radius, err)
+    # the all-fp32 evaluation of the same system overflows
+    d32 = dev(buf[:2])
+    engine.set(far_fp64=0, tree_radius=1.0)
+    engine.fmm_cart3_traceless(d32, a, n, prm)
+    torch.cuda.synchronize()
+    assert not bool(torch.isfinite(a).all())
+    engine.set(dens_inhom=1.0)
+
+
+def test_far_fp64_is_rejected_by_the_kdtree_evaluator(engine, oracle32):
+    import torch
+    from coulomb_oscillators_amd import EngineError
+    n = 4096
+    buf = state(oracle32, n, "cube")
+    d = dev(buf[:2])
+    a = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+    engine.set(far_fp64=1)
+    with pytest.raises(EngineError):
+        engine.fmm_cart3_kdtree(d, a, n, None)
+    engine.set(far_fp64=0)
+    engine.fmm_cart3_kdtree(d, a, n, None)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(a).all())
