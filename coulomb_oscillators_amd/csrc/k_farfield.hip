@@ -324,6 +324,47 @@ __global__ __launch_bounds__(kTopNodes) void l2l_top_kernel(const float *__restr
 	}
 }
 
+// child levels lroot + 1 .. L of the subtrees hanging off level lroot, one workgroup per subtree: the level just
+// finished stays in LDS as the next level's parents, so the whole lower part of the downward pass is one launch
+// (per-level launches cost 10-25 us each while the near-field kernel fills the chip on the other stream).
+// Same arithmetic per node as l2l_node: bit-identical locals.
+template <int P>
+__global__ __launch_bounds__(256) void l2l_sub_kernel(const float *__restrict__ center, float *local, int lroot, int L, int first)
+{
+	constexpr int offL = (P + 1) * (P + 1);
+	extern __shared__ float lds[];   // [2^(L - lroot - 1)][offL]
+	const int t = threadIdx.x, r = first + blockIdx.x;
+	for (int q = t; q < offL; q += blockDim.x) lds[q] = local[(size_t)((1 << lroot) - 1 + r) * offL + q];
+	__syncthreads();
+	for (int lc = lroot + 1; lc <= L; ++lc)
+	{
+		const bool on = t < (1 << (lc - lroot));
+		const int c = (1 << lc) - 1 + (r << (lc - lroot)) + t, p = (c - 1) >> 1;
+		float O[offL];
+		if (on)
+		{
+			float Lp[offL];
+			const float *src = lds + (size_t)(t >> 1) * offL;
+#pragma unroll
+			for (int q = 0; q < offL; ++q) Lp[q] = src[q];
+			l2l_body<P>(Lp, center[3 * c] - center[3 * p], center[3 * c + 1] - center[3 * p + 1], center[3 * c + 2] - center[3 * p + 2], O);
+			float *Lc = local + (size_t)c * offL;
+#pragma unroll
+			for (int q = 1; q < offL; ++q) { O[q] += Lc[q]; Lc[q] = O[q]; }
+			O[0] = 0.f;
+		}
+		if (lc == L) break;
+		__syncthreads();
+		if (on)
+		{
+			float *dst = lds + (size_t)t * offL;
+#pragma unroll
+			for (int q = 0; q < offL; ++q) dst[q] = O[q];
+		}
+		__syncthreads();
+	}
+}
+
 // ---- L2P + near field + rescale + (un)sort -------------------------------------------------------------
 // one thread per particle in tree order; its leaf is floor(2^L i / n) (the inverse of evalBox's ranges)
 template <int P>
@@ -404,11 +445,25 @@ static int run_downward(nbco_ctx *c, const float *center, float *local, int L, i
 	while (ltop + 1 <= L && (1 << (ltop + 1)) <= top) ++ltop;
 	if (ltop >= 2)
 		hipLaunchKernelGGL(l2l_top_kernel<P>, dim3(1), dim3(kTopNodes), (size_t)(1 << ltop) * offL * sizeof(float), c->stream, center, local, ltop);
-	for (int lc = ltop + 1; lc <= L; ++lc)
+	// the lowest levels in one launch, a workgroup per subtree (<= 256 leaves, parents' tuples in <= 60 KB of LDS)
+	int lroot = L;
+	if (ltop >= 2)
+	{
+		lroot = std::max(ltop, L - 8);
+		while (lroot < L && (size_t)(1 << (L - lroot - 1)) * offL * sizeof(float) > 60 * 1024) ++lroot;
+		if (lroot < dom_d) lroot = L;   // never with <= 8 domains; keep the per-level path for that case
+	}
+	for (int lc = ltop + 1; lc <= lroot; ++lc)
 	{
 		// below the domain level only the own subtree's nodes are needed
 		const int first = lc >= dom_d ? dom_g << (lc - dom_d) : 0, count = lc >= dom_d ? 1 << (lc - dom_d) : 1 << lc;
 		hipLaunchKernelGGL(l2l_gen_kernel<P>, dim3(grid_for(count)), dim3(kBlock), 0, c->stream, center, local, lc, first, count);
+	}
+	if (lroot < L)
+	{
+		const int first = dom_g << (lroot - dom_d), count = 1 << (lroot - dom_d);
+		hipLaunchKernelGGL(l2l_sub_kernel<P>, dim3(count), dim3(std::max(64, 1 << (L - lroot))), (size_t)(1 << (L - lroot - 1)) * offL * sizeof(float),
+		                   c->stream, center, local, lroot, L, first);
 	}
 	NBCO_HIP(hipGetLastError());
 	return NBCO_OK;

@@ -1090,7 +1090,10 @@ __global__ __launch_bounds__(kBlock) void list_fill_kernel(const int2 *__restric
 // one wave per target: rank sort of its source range (distinct keys); ranges of up to kSegLds entries are
 // staged in LDS, longer ones (not seen in practice) are ranked straight from global memory
 constexpr int kSegLds = 512;
-constexpr int kP2PChunk = 16;   // source leaves per near-field work unit (see the P2P section)
+#ifndef NBCO_P2P_CHUNK
+#define NBCO_P2P_CHUNK 16
+#endif
+constexpr int kP2PChunk = NBCO_P2P_CHUNK;   // source leaves per near-field work unit (see the P2P section)
 // DESC: the list is the P2P list -- also emit the source descriptor (first particle, multiplicity) of every sorted entry
 // and the number of chunks of every target, so the pair kernel does no dependent index -> mult -> position loads
 template <bool DESC>
@@ -1180,7 +1183,10 @@ __global__ __launch_bounds__(kBlock) void p2p_chunk_fill_kernel(const int *__res
 	{
 		const int b = start[i], e = start[i + 1], o = off[i], n = off[i + 1] - o;
 		const int ind = leaf_index[i], mlt = leaf_mult[i];
-		for (int k = 0; k < n; ++k) chunk[o + k] = make_int4(ind, min(b + k * kP2PChunk, e), min(b + (k + 1) * kP2PChunk, e), mlt);
+		// equal shares (a list of 17 becomes 9 + 8, not 16 + 1: a wave that only gets one source leaf spends its life
+		// in the chain of dependent loads at the head of a chunk)
+		const int per = n > 0 ? (e - b + n - 1) / n : 0;
+		for (int k = 0; k < n; ++k) chunk[o + k] = make_int4(ind, min(b + k * per, e), min(b + (k + 1) * per, e), mlt);
 	}
 }
 

@@ -41,10 +41,18 @@ __device__ __forceinline__ void wave_lds_sync()
 		az = fmaf(dz, ri3, az);                                            \
 	}
 
-constexpr int kP2PWaves = 4;   // waves per 256-thread block; 64-thread blocks would cap a CU at 8 waves
+#ifndef NBCO_P2P_WAVES
+#define NBCO_P2P_WAVES 4
+#endif
+#ifndef NBCO_P2P_ATTR
+// six waves per SIMD (<= 80 VGPRs instead of the 95 the allocator takes when left alone): +8 % pair rate on the kd-tree
+// lists, whose chunks start with a chain of dependent loads that more resident waves hide
+#define NBCO_P2P_ATTR __attribute__((amdgpu_waves_per_eu(6, 6)))
+#endif
+constexpr int kP2PWaves = NBCO_P2P_WAVES;   // waves per 256-thread block; 64-thread blocks would cap a CU at 8 waves
 
 template <int TPL>
-__global__ __launch_bounds__(64 * kP2PWaves) void p2p_kernel(const float4 *__restrict__ pos, const int2 *__restrict__ desc,
+__global__ __launch_bounds__(64 * kP2PWaves) NBCO_P2P_ATTR void p2p_kernel(const float4 *__restrict__ pos, const int2 *__restrict__ desc,
                                                              const int4 *__restrict__ chunk, const int *__restrict__ nchunks_total,
                                                              float eps2, int src_max, int stride, float4 *__restrict__ partial)
 {
