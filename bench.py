@@ -191,6 +191,23 @@ def main():
     else:
         pairs_per_eval = n * n
         extra = {}
+    # the reference's GPU driver rebuilds the kd-tree every tree_steps = 8 evaluations (fmm_cart3_kdtree.cuh:1619); the
+    # headline value above rebuilds every step (CPU-driver semantics), this is the amortised figure beside it
+    reuse = None
+    if world == 1 and args.workload == "fmm_kd" and args.tree_steps == 1:
+        eng.set(tree_steps=8)
+        for _ in range(8):
+            step()
+        barrier()
+        t1 = time.perf_counter()
+        k8 = max(8, (args.steps // 8) * 8)
+        for _ in range(k8):
+            step()
+        barrier()
+        e8 = time.perf_counter() - t1
+        reuse = {"tree_steps": 8, "steps": k8, "ms_per_step": 1e3 * e8 / k8, "value": n * k8 / e8, "unit": "particle-steps/s"}
+        eng.set(tree_steps=1)
+
     state = run.buf if sharded else d
     assert torch.isfinite(state).all(), "non-finite state after the timed steps"
     pairs_all = reduce(float(pairs_per_eval), dist.ReduceOp.SUM)
@@ -210,6 +227,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "gpair_per_s": pairs_all * args.steps / elapsed / 1e9,
+        "tree_reuse": reuse,
         "config": {"workload": ("FMM-3D kd-tree p=%d, N=%d per GPU (one system of %d), leapfrog, Gaussian ball, tree rebuilt every %d step(s)"
                                 % (args.order, n, n_sys, args.tree_steps)) if args.workload == "fmm_kd"
                    else ("FMM-3D uniform octree, traceless multipoles p=%d, N=%d per GPU, leapfrog, Gaussian ball" % (args.order, n))
