@@ -220,7 +220,9 @@ int nbco_profile_get(nbco_ctx *c, int phase, double *total_ms, long long *launch
 /* ---- operator tables (host only, no GPU needed) ------------------------------------------------
  * Copies the flattened coefficient / index table `name` for expansion order `order` into `out`
  * (int32 or float32 elements, at most `cap` of them) and stores the element count in *count.
- * Lets the table-driven FMM operators be checked against the oracle on a machine without a GPU. */
+ * The tables are the term lists (index pairs + coefficients) of P2M / M2M / M2L / L2L / L2P that the code
+ * generators of csrc/ (gen_ops.py, gen_m2l.py) unroll into straight-line device code; applying them on the
+ * host checks those term lists against the oracle on a machine without a GPU (tests/test_tables.py). */
 int nbco_debug_table(int order, const char *name, void *out, long long cap, long long *count);
 
 #ifdef __cplusplus
