@@ -1087,8 +1087,9 @@ __global__ __launch_bounds__(kBlock) void list_fill_kernel(const int2 *__restric
 	}
 }
 
-// one wave per target: rank sort of its source range (distinct keys); ranges of up to kSegLds entries are
-// staged in LDS, longer ones (not seen in practice) are ranked straight from global memory
+// one wave per target: rank sort of its source range (distinct keys) in registers up to 256 entries (the BASELINE ball
+// has 17 on average, 254 at most), a bitonic network in LDS up to kSegLds, and beyond that (not seen in practice) a
+// rank sort straight from global memory
 constexpr int kSegLds = 512;
 #ifndef NBCO_P2P_CHUNK
 #define NBCO_P2P_CHUNK 16
@@ -1113,29 +1114,67 @@ __global__ __launch_bounds__(kBlock) void list_segsort_kernel(const int *__restr
 	};
 	__shared__ uint64_t stage[kBlock / 64][kSegLds];
 	const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	// ranges of up to 64 * J entries: every lane keeps J entries in registers and ranks them against all entries of the
+	// range, which are broadcast one by one with v_readlane (an SGPR lane index: the loop is scalar, no LDS or memory
+	// latency inside).  All entries of a range share the target, so comparing the 32-bit source indices orders the keys.
+	auto rank_in_registers = [&](auto jtag, int s, int cnt) {
+		constexpr int J = decltype(jtag)::value;
+		uint64_t key[J];
+		unsigned src[J];
+		int rank[J];
+#pragma unroll
+		for (int j = 0; j < J; ++j)
+		{
+			key[j] = lane + 64 * j < cnt ? in[s + lane + 64 * j] : ~0ull;
+			src[j] = (unsigned)(key[j] & smask);
+			rank[j] = 0;
+		}
+#pragma unroll
+		for (int jb = 0; jb < J; ++jb)
+		{
+			const int lim = min(64, cnt - 64 * jb);   // wave-uniform
+			for (int q = 0; q < lim; ++q)
+			{
+				const unsigned other = (unsigned)__builtin_amdgcn_readlane((int)src[jb], q);
+#pragma unroll
+				for (int j = 0; j < J; ++j) rank[j] += other < src[j] ? 1 : 0;
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < J; ++j)
+			if (lane + 64 * j < cnt) emit(s + rank[j], key[j]);
+	};
 	for (int t = blockIdx.x * (kBlock / 64) + wv; t < ntargets; t += gridDim.x * (kBlock / 64))
 	{
-		const int s = start[t], cnt = start[t + 1] - s;
-		if (cnt <= 64)
-		{
-			const uint64_t key = lane < cnt ? in[s + lane] : ~0ull;
-			int rank = 0;
-			for (int q = 0; q < cnt; ++q) rank += __shfl(key, q) < key ? 1 : 0;
-			if (lane < cnt) emit(s + rank, key);
-			if (DESC && lane == 0) chunk_cnt[t] = (cnt + kP2PChunk - 1) / kP2PChunk;   // leaves of other domains have no entries
-		}
+		// wave-uniform by construction; telling the compiler so keeps the loops scalar
+		const int s = __builtin_amdgcn_readfirstlane(start[t]), cnt = __builtin_amdgcn_readfirstlane(start[t + 1]) - s;
+		if (DESC && lane == 0) chunk_cnt[t] = (cnt + kP2PChunk - 1) / kP2PChunk;   // leaves of other domains have no entries
+		if (cnt <= 64) rank_in_registers(std::integral_constant<int, 1>{}, s, cnt);
+		else if (cnt <= 128) rank_in_registers(std::integral_constant<int, 2>{}, s, cnt);
+		else if (cnt <= 256) rank_in_registers(std::integral_constant<int, 4>{}, s, cnt);
 		else if (cnt <= kSegLds)
 		{
-			for (int i = lane; i < cnt; i += 64) stage[wv][i] = in[s + i];
+			// bitonic network over the next power of two (padded with the largest key): ~45 wave-synchronous LDS steps at
+			// most, where ranking every key against every other would be cnt^2 / 64 dependent LDS reads per lane
+			int n2 = 128;
+			while (n2 < cnt) n2 <<= 1;
+			for (int i = lane; i < n2; i += 64) stage[wv][i] = i < cnt ? in[s + i] : ~0ull;
 			wave_lds_sync();
-			for (int i = lane; i < cnt; i += 64)
-			{
-				const uint64_t key = stage[wv][i];
-				int rank = 0;
-				for (int q = 0; q < cnt; ++q) rank += stage[wv][q] < key ? 1 : 0;
-				emit(s + rank, key);
-			}
-			if (DESC && lane == 0) chunk_cnt[t] = (cnt + kP2PChunk - 1) / kP2PChunk;
+			for (int k = 2; k <= n2; k <<= 1)
+				for (int j = k >> 1; j > 0; j >>= 1)
+				{
+					for (int i = lane; i < n2; i += 64)
+					{
+						const int x = i ^ j;
+						if (x > i)
+						{
+							const uint64_t ka = stage[wv][i], kb = stage[wv][x];
+							if ((ka > kb) == ((i & k) == 0)) { stage[wv][i] = kb; stage[wv][x] = ka; }
+						}
+					}
+					wave_lds_sync();
+				}
+			for (int i = lane; i < cnt; i += 64) emit(s + i, stage[wv][i]);
 			wave_lds_sync();
 		}
 		else
@@ -1147,7 +1186,6 @@ __global__ __launch_bounds__(kBlock) void list_segsort_kernel(const int *__restr
 				for (int q = 0; q < cnt; ++q) rank += in[s + q] < key ? 1 : 0;
 				emit(s + rank, key);
 			}
-			if (DESC && lane == 0) chunk_cnt[t] = (cnt + kP2PChunk - 1) / kP2PChunk;
 		}
 	}
 	if (DESC && blockIdx.x == 0 && threadIdx.x == 0) chunk_cnt[ntargets] = 0;   // closes the exclusive scan

@@ -41,14 +41,15 @@ void nbco_ctx::phase_end(int ph)
 
 int nbco_ctx::fork_mark()
 {
-	if (!aux)
+	if (!aux && !aux_is_main)
 	{
 		// high priority: its kernels are small, latency-bound links of the far-field chain and must not queue up behind
 		// the thousands of workgroups of the near-field kernel running on the main stream
 		int prio_lo = 0, prio_hi = 0;
 		NBCO_HIP_M(this, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
 		if (getenv("NBCO_AUX_PRIO") && atoi(getenv("NBCO_AUX_PRIO")) == 0) prio_hi = prio_lo;   // A/B switch (diagnostics)
-		NBCO_HIP_M(this, hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, prio_hi));
+		if (getenv("NBCO_AUX_SERIAL") && atoi(getenv("NBCO_AUX_SERIAL")) != 0) { aux = stream; aux_is_main = true; }   // diagnostics: one stream
+		else NBCO_HIP_M(this, hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, prio_hi));
 		NBCO_HIP_M(this, hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
 		NBCO_HIP_M(this, hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
 	}
@@ -160,7 +161,7 @@ int nbco_destroy(nbco_ctx *c)
 	                  &c->m2l_list, &c->counters, &c->p2p_keys, &c->p2p_keys_alt, &c->m2l_keys, &c->m2l_keys_alt,
 	                  &c->p2p_start, &c->m2l_start, &c->p2p_chunk_cnt, &c->p2p_chunk_off, &c->p2p_chunks, &c->sel_hist, &c->sel_nodes, &c->sel_ties, &c->list_cnt,
 	                  &c->dist_top, &c->dist_tree, &c->oct_tree, &c->oct_groups, &c->scan_tmp_aux, &c->p2p_desc, &c->trav_ctr, &c->prep_state};
-	if (c->aux) { hipStreamSynchronize(c->aux); hipStreamDestroy(c->aux); }
+	if (c->aux && !c->aux_is_main) { hipStreamSynchronize(c->aux); hipStreamDestroy(c->aux); }
 	if (c->ev_fork) hipEventDestroy(c->ev_fork);
 	if (c->ev_join) hipEventDestroy(c->ev_join);
 	if (c->ev_flags) hipEventDestroy(c->ev_flags);

@@ -73,6 +73,27 @@ def test_accelerations_match_oracle(engine, oracle32, n, p):
     assert abs(o.mean_relerr(a, ref) - o.mean_relerr(a_ref, ref)) <= 0.02 * o.mean_relerr(a_ref, ref) + 2e-6
 
 
+@pytest.mark.parametrize("radius,n,p", [(2.0, 20000, 3), (3.0, 8000, 2)])
+def test_long_interaction_lists(engine, oracle32, radius, n, p):
+    """a wide opening radius gives per-target lists of hundreds of entries (614 / 1189 at most here, against 254 on the
+    BASELINE run): every size class of the per-target list sort is exercised, lists stay bit-exact, forces within 1e-5"""
+    o = oracle32
+    buf = o.init_reference(n)
+    par = o.params(n)
+    _, a_ref = o.fmm_kd(buf[:2], par, p=p, threads=8, unsort=True, radius=radius)
+    want = o.kd_tree()
+    beg = (1 << want["L"]) - 1
+    pairs = np.asarray(want["p2p"]).reshape(-1, 2)
+    per_target = np.bincount(np.concatenate([pairs[:, 0], pairs[:, 1]]) - beg, minlength=1 << want["L"]) + 1
+    assert per_target.max() > 512 and (per_target <= 64).any() and ((per_target > 256) & (per_target <= 512)).any()
+    _, a = run_gpu(engine, buf, par, n, fmm_order=p, unsort=1, tree_radius=radius)
+    for name in ("p2p", "m2l"):
+        np.testing.assert_array_equal(canon_pairs(engine.kd_array(name)), canon_pairs(want[name]), err_msg=name)
+    assert engine.kd_info().directed_p2p == directed_pairs(want["mult"], want["p2p"], want["L"])
+    assert force_err(a, a_ref) < 1e-5
+    engine.set(tree_radius=1.0)
+
+
 def test_reference_test_mode_error_table_on_gpu(engine, oracle32):
     """The GPU evaluator reproduces the reference's recorded `-test` error table (main3.cu:790-811)."""
     with open(os.path.join(GOLD, "reference_recorded.json")) as f:
