@@ -887,7 +887,8 @@ __device__ inline long long region_slot(const int *__restrict__ pref, long long 
 }
 
 __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab_arg, const int2 *__restrict__ fin, int2 *__restrict__ fout,
-                                                          int2 *__restrict__ p2p, int2 *__restrict__ m2l, int *__restrict__ counters,
+                                                          int2 *__restrict__ p2p, int2 *__restrict__ m2l, int2 *__restrict__ p2p_rank,
+                                                          int2 *__restrict__ m2l_rank, int *__restrict__ counters,
                                                           int *__restrict__ tctr, int it, long long capR, float par, int m2l_first,
                                                           unsigned *__restrict__ cnt_p2p, unsigned *__restrict__ cnt_m2l, const Dom dm)
 {
@@ -944,20 +945,28 @@ __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab
 		const bool okf = bf + tf <= capR, okp = bp + tp <= capR, okm = bm + tm <= capR;
 		if (threadIdx.x == 0 && !(okf && okp && okm)) counters[2] = 1;
 		bf += (long long)(off & 0xFFFFF); bp += (long long)((off >> 20) & 0xFFFFF); bm += (long long)(off >> 40);
-		auto emit = [&](int q, int2 np) {
-			// the per-target entry counts of the directed lists are accumulated here, under the traversal's latency
-			if (q == 1 && okp)
+		// the per-target entry counts of the directed lists are accumulated here, under the traversal's latency; the value
+		// an atomic returns is the entry's slot inside its target's range, kept beside the pair so that filling the
+		// directed lists needs no second round of atomics (device-scope atomics retire at ~17 G/s on this part: two
+		// per entry were 60 us of every evaluation).  -1: the node belongs to another domain.  All atomics of a thread
+		// are issued before any of their results is used, so they share one round trip.
+		auto slots = [&](int q, int2 np, bool ok) {
+			int2 r = make_int2(-1, -1);
+			if (q == 1 && ok && okp)
 			{
-				p2p[obase + bp] = np;
-				if (dm.d == 0 || dom_touch(dm, np.x)) atomicAdd(&cnt_p2p[np.x - lbeg], 1u);
-				if (dm.d == 0 || dom_touch(dm, np.y)) atomicAdd(&cnt_p2p[np.y - lbeg], 1u);
+				if (dm.d == 0 || dom_touch(dm, np.x)) r.x = (int)atomicAdd(&cnt_p2p[np.x - lbeg], 1u);
+				if (dm.d == 0 || dom_touch(dm, np.y)) r.y = (int)atomicAdd(&cnt_p2p[np.y - lbeg], 1u);
 			}
-			if (q == 2 && okm)
+			if (q == 2 && ok && okm)
 			{
-				m2l[obase + bm] = np;
-				if (dm.d == 0 || dom_touch(dm, np.x)) atomicAdd(&cnt_m2l[np.x], 1u);
-				if (dm.d == 0 || dom_touch(dm, np.y)) atomicAdd(&cnt_m2l[np.y], 1u);
+				if (dm.d == 0 || dom_touch(dm, np.x)) r.x = (int)atomicAdd(&cnt_m2l[np.x], 1u);
+				if (dm.d == 0 || dom_touch(dm, np.y)) r.y = (int)atomicAdd(&cnt_m2l[np.y], 1u);
 			}
+			return r;
+		};
+		auto emit = [&](int q, int2 np, int2 r) {
+			if (q == 1 && okp) { p2p[obase + bp] = np; p2p_rank[obase + bp] = r; }
+			if (q == 2 && okm) { m2l[obase + bm] = np; m2l_rank[obase + bm] = r; }
 			const PairKids g = pair_children(q, np);
 			if (q >= 3 && okf)
 			{
@@ -970,12 +979,13 @@ __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab
 			bm += q == 2 ? 1 : 0;
 			bf += g.n;
 		};
-		if (nch == 0) emit(k0, p0);
+		const int2 r0 = slots(k0, p0, nch == 0 && i < nin), r1 = slots(k1, ch.a, nch > 0), r2 = slots(k2, ch.b, nch > 1), r3 = slots(k3, ch.c, nch > 2);
+		if (nch == 0) emit(k0, p0, r0);
 		else
 		{
-			emit(k1, ch.a);
-			emit(k2, ch.b);
-			if (nch > 2) emit(k3, ch.c);
+			emit(k1, ch.a, r1);
+			emit(k2, ch.b, r2);
+			if (nch > 2) emit(k3, ch.c, r3);
 		}
 		__syncthreads();
 	}
@@ -1060,13 +1070,13 @@ __global__ __launch_bounds__(kBlock) void list_starts_kernel(const uint64_t *__r
 }
 
 // ---- directed lists by counting sort ---------------------------------------------------------------
-// count -> exclusive scan -> scatter (slot order inside a target is whatever the atomics give) ->
+// count (during the traversal, which also hands every entry its slot) -> exclusive scan -> scatter ->
 // per-target sort of the (short) source ranges.  The last step makes the lists, and with them every
 // floating-point sum downstream, identical from run to run.
 
-__global__ __launch_bounds__(kBlock) void list_fill_kernel(const int2 *__restrict__ pairs, const int *__restrict__ pref, long long capR, int sub,
-                                                           int self0, int nself, int shift, const int *__restrict__ start,
-                                                           unsigned *__restrict__ fill, uint64_t *__restrict__ keys, const Dom dm)
+__global__ __launch_bounds__(kBlock) void list_fill_kernel(const int2 *__restrict__ pairs, const int2 *__restrict__ ranks, const int *__restrict__ pref,
+                                                           long long capR, int sub, int self0, int nself, int shift, const int *__restrict__ start,
+                                                           uint64_t *__restrict__ keys)
 {
 	const long long npairs = pref[kTravK];   // the pair count never leaves the device (regions are clamped to their capacity)
 	const long long total = npairs + nself;
@@ -1074,15 +1084,17 @@ __global__ __launch_bounds__(kBlock) void list_fill_kernel(const int2 *__restric
 	{
 		if (i < npairs)
 		{
-			const int2 p = pairs[region_slot(pref, capR, i)];
+			const long long slot = region_slot(pref, capR, i);
+			const int2 p = pairs[slot], r = ranks[slot];
 			const uint64_t a = (uint64_t)(p.x - sub), b = (uint64_t)(p.y - sub);
-			if (dm.d == 0 || dom_touch(dm, p.x)) keys[start[a] + atomicAdd(&fill[a], 1u)] = (a << shift) | b;
-			if (dm.d == 0 || dom_touch(dm, p.y)) keys[start[b] + atomicAdd(&fill[b], 1u)] = (b << shift) | a;
+			if (r.x >= 0) keys[start[a] + r.x] = (a << shift) | b;
+			if (r.y >= 0) keys[start[b] + r.y] = (b << shift) | a;
 		}
 		else
 		{
-			const uint64_t t = (uint64_t)(self0 + (i - npairs));   // self entries of the domain's own leaves
-			keys[start[t] + atomicAdd(&fill[t], 1u)] = (t << shift) | t;
+			// self entries of the domain's own leaves: counted last (traverse_finish_kernel), so they own the last slot
+			const uint64_t t = (uint64_t)(self0 + (i - npairs));
+			keys[start[t + 1] - 1] = (t << shift) | t;
 		}
 	}
 }
@@ -1321,15 +1333,15 @@ static int exclusive_scan_ints(nbco_ctx *c, int *in, int *out, size_t count, Dev
 	return NBCO_OK;
 }
 
-static int build_directed_list(nbco_ctx *c, const int2 *pairs, const int *pref_dev, long long capR, long long npairs_hint, int sub, int self0, int nself,
-                               int ntargets, int shift, unsigned *cnt, unsigned *fill, int *start, uint64_t *keys_tmp, uint64_t *keys_out, const Dom dm,
+static int build_directed_list(nbco_ctx *c, const int2 *pairs, const int2 *ranks, const int *pref_dev, long long capR, long long npairs_hint, int sub,
+                               int self0, int nself, int ntargets, int shift, unsigned *cnt, int *start, uint64_t *keys_tmp, uint64_t *keys_out,
                                DevBuf &scan_tmp, const int *leaf_index = nullptr, const int *leaf_mult = nullptr, int2 *desc = nullptr,
                                int *chunk_cnt = nullptr)
 {
 	hipStream_t st = c->stream;   // (the self entries were added to cnt by traverse_finish_kernel)
 	NBCO_TRY(exclusive_scan_ints(c, (int *)cnt, start, (size_t)(ntargets + 1), scan_tmp));
-	hipLaunchKernelGGL(list_fill_kernel, dim3(grid1d(npairs_hint + nself)), dim3(kBlock), 0, st, pairs, pref_dev, capR, sub, self0, nself, shift,
-	                   (const int *)start, fill, keys_tmp, dm);
+	hipLaunchKernelGGL(list_fill_kernel, dim3(grid1d(npairs_hint + nself)), dim3(kBlock), 0, st, pairs, ranks, pref_dev, capR, sub, self0, nself, shift,
+	                   (const int *)start, keys_tmp);
 	if (desc)
 		hipLaunchKernelGGL(list_segsort_kernel<true>, dim3((ntargets + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, (const int *)start, ntargets,
 		                   (const uint64_t *)keys_tmp, keys_out, shift, leaf_index, leaf_mult, desc, chunk_cnt);
@@ -1506,8 +1518,9 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 	const long long capR = 2 * (((long long)c->o.list_factor * ntot + 4096 + kTravK - 1) / kTravK), cap = capR * kTravK;
 	NBCO_TRY(c->reserve(c->frontier_a, sizeof(int2) * (size_t)cap));
 	NBCO_TRY(c->reserve(c->frontier_b, sizeof(int2) * (size_t)cap));
-	NBCO_TRY(c->reserve(c->p2p_list, sizeof(int2) * (size_t)cap));
-	NBCO_TRY(c->reserve(c->m2l_list, sizeof(int2) * (size_t)cap));
+	// pairs [0, cap) and, behind them, the slot of either direction inside its target's range [cap, 2 cap)
+	NBCO_TRY(c->reserve(c->p2p_list, sizeof(int2) * 2 * (size_t)cap));
+	NBCO_TRY(c->reserve(c->m2l_list, sizeof(int2) * 2 * (size_t)cap));
 	NBCO_TRY(c->reserve(c->counters, sizeof(int) * 128));
 	c->list_cap = cap;
 
@@ -1539,7 +1552,8 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		for (int it = 0; it < iters; ++it)
 		{
 			hipLaunchKernelGGL(traverse_kernel, dim3(1024), dim3(kBlock), 0, st, tv, tab, (const int2 *)fa, fb, c->p2p_list.as<int2>(),
-			                   c->m2l_list.as<int2>(), ctr, tctr, it, capR, c->o.tree_radius, c->o.m2l_first, cnt_p2p, cnt_m2l, dm);
+			                   c->m2l_list.as<int2>(), c->p2p_list.as<int2>() + cap, c->m2l_list.as<int2>() + cap, ctr, tctr, it, capR,
+			                   c->o.tree_radius, c->o.m2l_first, cnt_p2p, cnt_m2l, dm);
 			std::swap(fa, fb);
 		}
 		hipLaunchKernelGGL(traverse_finish_kernel, dim3(1), dim3(1024), 0, st, ctr, tctr, capR, c->list_cnt.as<unsigned>(), (long long)(2 * (np_ + nm_)),
@@ -1580,8 +1594,8 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 			NBCO_TRY(c->reserve(c->p2p_chunk_cnt, sizeof(int) * (size_t)(nleaf + 2)));
 			NBCO_TRY(c->reserve(c->p2p_chunk_off, sizeof(int) * (size_t)(nleaf + 2)));
 			NBCO_TRY(c->reserve(c->p2p_chunks, sizeof(int4) * (size_t)max_chunks));
-			NBCO_TRY(build_directed_list(c, c->p2p_list.as<int2>(), p2p_pref, capR, np2p_hint, beg, self0, nself, nleaf, shift, cp, cp + ((size_t)nleaf + 2),
-			                             c->p2p_start.as<int>(), c->p2p_keys.as<uint64_t>(), c->p2p_keys_alt.as<uint64_t>(), dm, c->sort_tmp,
+			NBCO_TRY(build_directed_list(c, c->p2p_list.as<int2>(), c->p2p_list.as<int2>() + cap, p2p_pref, capR, np2p_hint, beg, self0, nself, nleaf, shift, cp,
+			                             c->p2p_start.as<int>(), c->p2p_keys.as<uint64_t>(), c->p2p_keys_alt.as<uint64_t>(), c->sort_tmp,
 			                             tv.index + beg, tv.mult + beg, c->p2p_desc.as<int2>(), c->p2p_chunk_cnt.as<int>()));
 			// chunked work units: (counts from the sort) -> exclusive scan -> descriptors
 			NBCO_TRY(exclusive_scan_ints(c, c->p2p_chunk_cnt.as<int>(), c->p2p_chunk_off.as<int>(), (size_t)(nleaf + 1), c->sort_tmp));
@@ -1597,8 +1611,8 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		{
 			StreamScope on_aux(c, c->aux);
 			unsigned *cm = c->list_cnt.as<unsigned>() + 2 * ((size_t)nleaf + 2);
-			NBCO_TRY(build_directed_list(c, c->m2l_list.as<int2>(), m2l_pref, capR, nm2l_hint, 0, 0, 0, ntot, shift, cm, cm + ((size_t)ntot + 2),
-			                             c->m2l_start.as<int>(), c->m2l_keys.as<uint64_t>(), c->m2l_keys_alt.as<uint64_t>(), dm, c->scan_tmp_aux));
+			NBCO_TRY(build_directed_list(c, c->m2l_list.as<int2>(), c->m2l_list.as<int2>() + cap, m2l_pref, capR, nm2l_hint, 0, 0, 0, ntot, shift, cm,
+			                             c->m2l_start.as<int>(), c->m2l_keys.as<uint64_t>(), c->m2l_keys_alt.as<uint64_t>(), c->scan_tmp_aux));
 			{
 				PhaseScope ph(c, NBCO_PH_M2L);
 				// register-resident generated bodies, one interaction per lane (k_m2l.hip)
