@@ -944,6 +944,13 @@ __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab
 		long long bf = sh_base[0], bp = sh_base[1], bm = sh_base[2];
 		const bool okf = bf + tf <= capR, okp = bp + tp <= capR, okm = bm + tm <= capR;
 		if (threadIdx.x == 0 && !(okf && okp && okm)) counters[2] = 1;
+		// The workgroup whose reservation crosses the end of a frontier region writes nothing, and the next launch reads the
+		// region up to its capacity: give the unwritten tail a well-formed pair (the root against itself), or that launch
+		// would classify whatever the buffer held before.  (The evaluation is lost anyway -- NBCO_ERR_CAPACITY -- but every
+		// kernel queued behind the traversal must still run on valid indices.)  The P2P / M2L regions are not read back on
+		// overflow (traverse_finish_kernel declares the lists empty).
+		if (!okf && bf < capR)
+			for (long long k = bf + threadIdx.x; k < capR; k += kBlock) fout[obase + k] = make_int2(0, 0);
 		bf += (long long)(off & 0xFFFFF); bp += (long long)((off >> 20) & 0xFFFFF); bm += (long long)(off >> 40);
 		// the per-target entry counts of the directed lists are accumulated here, under the traversal's latency; the value
 		// an atomic returns is the entry's slot inside its target's range, kept beside the pair so that filling the
@@ -1107,13 +1114,12 @@ constexpr int kSegLds = 512;
 #define NBCO_P2P_CHUNK 16
 #endif
 constexpr int kP2PChunk = NBCO_P2P_CHUNK;   // source leaves per near-field work unit (see the P2P section)
-// DESC: the list is the P2P list -- also emit the source descriptor (first particle, multiplicity) of every sorted entry
-// and the number of chunks of every target, so the pair kernel does no dependent index -> mult -> position loads
+// DESC: the list is the P2P list -- also emit the source descriptor (first particle, multiplicity) of every sorted entry,
+// so the pair kernel does no dependent index -> mult -> position loads
 template <bool DESC>
 __global__ __launch_bounds__(kBlock) void list_segsort_kernel(const int *__restrict__ start, int ntargets, const uint64_t *__restrict__ in,
                                                               uint64_t *__restrict__ out, int shift, const int *__restrict__ leaf_index,
-                                                              const int *__restrict__ leaf_mult, int2 *__restrict__ desc,
-                                                              int *__restrict__ chunk_cnt)
+                                                              const int *__restrict__ leaf_mult, int2 *__restrict__ desc)
 {
 	const uint64_t smask = (1ull << shift) - 1;
 	auto emit = [&](int slot, uint64_t key) {
@@ -1160,7 +1166,6 @@ __global__ __launch_bounds__(kBlock) void list_segsort_kernel(const int *__restr
 	{
 		// wave-uniform by construction; telling the compiler so keeps the loops scalar
 		const int s = __builtin_amdgcn_readfirstlane(start[t]), cnt = __builtin_amdgcn_readfirstlane(start[t + 1]) - s;
-		if (DESC && lane == 0) chunk_cnt[t] = (cnt + kP2PChunk - 1) / kP2PChunk;   // leaves of other domains have no entries
 		if (cnt <= 64) rank_in_registers(std::integral_constant<int, 1>{}, s, cnt);
 		else if (cnt <= 128) rank_in_registers(std::integral_constant<int, 2>{}, s, cnt);
 		else if (cnt <= 256) rank_in_registers(std::integral_constant<int, 4>{}, s, cnt);
@@ -1200,7 +1205,6 @@ __global__ __launch_bounds__(kBlock) void list_segsort_kernel(const int *__restr
 			}
 		}
 	}
-	if (DESC && blockIdx.x == 0 && threadIdx.x == 0) chunk_cnt[ntargets] = 0;   // closes the exclusive scan
 }
 
 // directed pair interactions = sum over the directed P2P entries of mult[target] * mult[source]
@@ -1333,22 +1337,68 @@ static int exclusive_scan_ints(nbco_ctx *c, int *in, int *out, size_t count, Dev
 	return NBCO_OK;
 }
 
+// One scan for two prefix sums of the P2P list: entries per target (low word -> start[]) and chunks per target (high
+// word -> chunk_off[]); the chunk count follows from the entry count, so the work-unit table no longer waits for the sort.
+struct PackCounts
+{
+	__host__ __device__ uint64_t operator()(unsigned cnt) const { return (uint64_t)cnt | ((uint64_t)((cnt + kP2PChunk - 1) / kP2PChunk) << 32); }
+};
+struct SplitRef
+{
+	int *s, *o;
+	__host__ __device__ SplitRef &operator=(uint64_t v) { *s = (int)(uint32_t)v; *o = (int)(v >> 32); return *this; }
+};
+struct SplitIter
+{
+	using iterator_category = std::random_access_iterator_tag;
+	using value_type = uint64_t;
+	using difference_type = std::ptrdiff_t;
+	using pointer = uint64_t *;
+	using reference = SplitRef;
+	int *s, *o;
+	__host__ __device__ SplitRef operator*() const { return SplitRef{s, o}; }
+	__host__ __device__ SplitRef operator[](difference_type i) const { return SplitRef{s + i, o + i}; }
+	__host__ __device__ SplitIter operator+(difference_type i) const { return SplitIter{s + i, o + i}; }
+	__host__ __device__ SplitIter operator-(difference_type i) const { return SplitIter{s - i, o - i}; }
+	__host__ __device__ SplitIter &operator+=(difference_type i) { s += i; o += i; return *this; }
+	__host__ __device__ SplitIter &operator++() { ++s; ++o; return *this; }
+	__host__ __device__ difference_type operator-(const SplitIter &b) const { return s - b.s; }
+};
+static int exclusive_scan_counts_and_chunks(nbco_ctx *c, const unsigned *cnt, int *start, int *chunk_off, size_t count, DevBuf &tmp)
+{
+	hipStream_t st = c->stream;
+	auto in = rocprim::make_transform_iterator(cnt, PackCounts{});
+	size_t bytes = 0;
+	NBCO_HIP(rocprim::exclusive_scan(nullptr, bytes, in, SplitIter{start, chunk_off}, (uint64_t)0, count, rocprim::plus<uint64_t>(), st));
+	NBCO_TRY(c->reserve(tmp, bytes));
+	bytes = tmp.bytes;
+	NBCO_HIP(rocprim::exclusive_scan(tmp.ptr, bytes, in, SplitIter{start, chunk_off}, (uint64_t)0, count, rocprim::plus<uint64_t>(), st));
+	return NBCO_OK;
+}
+
 static int build_directed_list(nbco_ctx *c, const int2 *pairs, const int2 *ranks, const int *pref_dev, long long capR, long long npairs_hint, int sub,
                                int self0, int nself, int ntargets, int shift, unsigned *cnt, int *start, uint64_t *keys_tmp, uint64_t *keys_out,
                                DevBuf &scan_tmp, const int *leaf_index = nullptr, const int *leaf_mult = nullptr, int2 *desc = nullptr,
-                               int *chunk_cnt = nullptr)
+                               int *chunk_off = nullptr, int4 *chunks = nullptr)
 {
 	hipStream_t st = c->stream;   // (the self entries were added to cnt by traverse_finish_kernel)
-	NBCO_TRY(exclusive_scan_ints(c, (int *)cnt, start, (size_t)(ntargets + 1), scan_tmp));
+	if (desc)
+	{
+		// P2P list: entry offsets and chunk offsets from one scan, then the work-unit table (it only needs the offsets)
+		NBCO_TRY(exclusive_scan_counts_and_chunks(c, cnt, start, chunk_off, (size_t)(ntargets + 1), scan_tmp));
+		hipLaunchKernelGGL(p2p_chunk_fill_kernel, dim3(grid1d(ntargets)), dim3(kBlock), 0, st, (const int *)start, (const int *)chunk_off, ntargets, leaf_index,
+		                   leaf_mult, chunks);
+	}
+	else
+		NBCO_TRY(exclusive_scan_ints(c, (int *)cnt, start, (size_t)(ntargets + 1), scan_tmp));
 	hipLaunchKernelGGL(list_fill_kernel, dim3(grid1d(npairs_hint + nself)), dim3(kBlock), 0, st, pairs, ranks, pref_dev, capR, sub, self0, nself, shift,
 	                   (const int *)start, keys_tmp);
 	if (desc)
 		hipLaunchKernelGGL(list_segsort_kernel<true>, dim3((ntargets + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, (const int *)start, ntargets,
-		                   (const uint64_t *)keys_tmp, keys_out, shift, leaf_index, leaf_mult, desc, chunk_cnt);
+		                   (const uint64_t *)keys_tmp, keys_out, shift, leaf_index, leaf_mult, desc);
 	else
 		hipLaunchKernelGGL(list_segsort_kernel<false>, dim3((ntargets + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, (const int *)start,
-		                   ntargets, (const uint64_t *)keys_tmp, keys_out, shift, (const int *)nullptr, (const int *)nullptr, (int2 *)nullptr,
-		                   (int *)nullptr);
+		                   ntargets, (const uint64_t *)keys_tmp, keys_out, shift, (const int *)nullptr, (const int *)nullptr, (int2 *)nullptr);
 	NBCO_HIP(hipGetLastError());
 	return NBCO_OK;
 }
@@ -1591,22 +1641,18 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		{
 			unsigned *cp = c->list_cnt.as<unsigned>();
 			NBCO_TRY(c->reserve(c->p2p_desc, sizeof(int2) * (size_t)(dp2p_cap + 1)));
-			NBCO_TRY(c->reserve(c->p2p_chunk_cnt, sizeof(int) * (size_t)(nleaf + 2)));
 			NBCO_TRY(c->reserve(c->p2p_chunk_off, sizeof(int) * (size_t)(nleaf + 2)));
 			NBCO_TRY(c->reserve(c->p2p_chunks, sizeof(int4) * (size_t)max_chunks));
 			NBCO_TRY(build_directed_list(c, c->p2p_list.as<int2>(), c->p2p_list.as<int2>() + cap, p2p_pref, capR, np2p_hint, beg, self0, nself, nleaf, shift, cp,
 			                             c->p2p_start.as<int>(), c->p2p_keys.as<uint64_t>(), c->p2p_keys_alt.as<uint64_t>(), c->sort_tmp,
-			                             tv.index + beg, tv.mult + beg, c->p2p_desc.as<int2>(), c->p2p_chunk_cnt.as<int>()));
-			// chunked work units: (counts from the sort) -> exclusive scan -> descriptors
-			NBCO_TRY(exclusive_scan_ints(c, c->p2p_chunk_cnt.as<int>(), c->p2p_chunk_off.as<int>(), (size_t)(nleaf + 1), c->sort_tmp));
-			hipLaunchKernelGGL(p2p_chunk_fill_kernel, dim3(grid1d(nleaf)), dim3(kBlock), 0, st, (const int *)c->p2p_start.as<int>(),
-			                   (const int *)c->p2p_chunk_off.as<int>(), nleaf, (const int *)(tv.index + beg), (const int *)(tv.mult + beg),
-			                   c->p2p_chunks.as<int4>());
+			                             tv.index + beg, tv.mult + beg, c->p2p_desc.as<int2>(), c->p2p_chunk_off.as<int>(), c->p2p_chunks.as<int4>()));
 			// remembered for nbco_kd_get_info (the directed pair count is evaluated on demand)
 			c->pc_mult = tv.mult + beg; c->pc_shift = shift; c->pc_total = c->p2p_start.as<int>() + nleaf;
 		}
 		// the far field does not depend on the P2P list: M2L list, M2L and L2L run on the second stream, behind the
 		// multipole chain, and overlap the P2P list chain and the start of P2P
+		// (the locals are cleared on the second stream before it starts waiting for the traversal)
+		NBCO_HIP(hipMemsetAsync(tv.local, 0, sizeof(float) * (size_t)ntot * offL, c->aux));
 		NBCO_TRY(c->fork_wait());
 		{
 			StreamScope on_aux(c, c->aux);
@@ -1616,7 +1662,6 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 			{
 				PhaseScope ph(c, NBCO_PH_M2L);
 				// register-resident generated bodies, one interaction per lane (k_m2l.hip)
-				NBCO_HIP(hipMemsetAsync(tv.local, 0, sizeof(float) * (size_t)ntot * offL, c->stream));
 				NBCO_TRY(launch_m2l_lanes(c, P, tv.csz, tv.mpole, tv.local, c->m2l_keys_alt.as<uint64_t>(), c->m2l_start.as<int>(), shift, ntot));
 			}
 			{

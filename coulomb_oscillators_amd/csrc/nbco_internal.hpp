@@ -107,7 +107,7 @@ struct nbco_ctx
 	// traversal and interaction lists
 	DevBuf frontier_a, frontier_b, p2p_list, m2l_list, counters;
 	DevBuf p2p_keys, p2p_keys_alt, m2l_keys, m2l_keys_alt, p2p_start, m2l_start;
-	DevBuf p2p_chunk_cnt, p2p_chunk_off, p2p_chunks, p2p_desc;
+	DevBuf p2p_chunk_off, p2p_chunks, p2p_desc;
 	const int *pc_mult = nullptr, *pc_total = nullptr;   // inputs of the on-demand directed pair count
 	int pc_shift = 0;
 	DevBuf list_cnt, trav_ctr;
