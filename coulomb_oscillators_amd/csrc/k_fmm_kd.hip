@@ -1507,6 +1507,16 @@ static int kd_build_upward(nbco_ctx *c, const float *p, long long n, int L, cons
 				NBCO_HIP(hipMemcpyAsync(c->prep_state.ptr, arm, sizeof arm, hipMemcpyHostToDevice, st));
 				NBCO_HIP(hipStreamSynchronize(st));   // `arm` lives on this stack frame; happens once per context
 			}
+			// A pivot with more ties than the resolver takes (flag -> the sorting build redoes the evaluation) leaves slots
+			// of a level's output unwritten, and the rest of this evaluation still runs on them: every slot of both
+			// permutation buffers must hold an index below n at all times.  From the second level on the buffers hold older
+			// permutations; the alternate buffer is primed once per particle count.
+			if (c->perm_primed_n != n)
+			{
+				hipLaunchKernelGGL(iota_kernel, dim3(grid1d(n)), dim3(kBlock), 0, st, unsort_alt, n);
+				hipLaunchKernelGGL(iota_kernel, dim3(grid1d(n)), dim3(kBlock), 0, st, unsort, n);
+				c->perm_primed_n = n;
+			}
 			// pack + identity permutation + bounding box + root node + cleared selection state: one launch
 			hipLaunchKernelGGL(kd_prep_kernel, dim3(kPrepGrid), dim3(kPrepBlock), 0, st, p, n, pos, unsort, c->sel_hist.as<uint32_t>(), words_a,
 			                   c->sel_nodes.as<uint32_t>(), words_b, c->counters.as<int>() + 110, c->prep_state.as<unsigned>(), tv, root6);

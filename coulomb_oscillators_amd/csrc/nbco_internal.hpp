@@ -79,6 +79,7 @@ struct nbco_ctx
 	hipStream_t aux = nullptr;
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	bool aux_pending = false;
+	long long perm_primed_n = -1;   // particle count for which both permutation buffers were last filled with valid indices
 	bool aux_is_main = false;   // NBCO_AUX_SERIAL=1 (diagnostics): the second stream is the main stream
 	// traversal counts / flags land in pinned host memory; looked at after the rest of the evaluation is enqueued
 	int *h_flags = nullptr;
