@@ -491,12 +491,17 @@ static int run_l2p(nbco_ctx *c, const float4 *pos, const float *center, const fl
 	default: return c->fail(NBCO_ERR_UNSUPPORTED, "generated far-field operators exist for orders 1..10"); \
 	}
 
-// centres + multiplicities of all internal nodes from the leaves' (2 launches)
+// centres + multiplicities of all internal nodes from the leaves' (2 launches up to 16 levels)
 int launch_kd_centres(nbco_ctx *c, float *center, int *mult, int L)
 {
 	if (L == 0) return NBCO_OK;
-	const int lr = L > 8 ? L - 8 : 0;
-	hipLaunchKernelGGL(kd_centres_kernel, dim3(1 << lr), dim3(kBlock), 0, c->stream, center, mult, L, lr);
+	// a workgroup walks 8 levels (256 leaves of its subtree in LDS), the last launch (one workgroup) the <= 8 levels left:
+	// trees deeper than 16 levels (N > 2M at p = 6) take one more subtree stage per 8 levels
+	int bottom = L;
+	for (; bottom > 16; bottom -= 8)
+		hipLaunchKernelGGL(kd_centres_kernel, dim3(1 << (bottom - 8)), dim3(kBlock), 0, c->stream, center, mult, bottom, bottom - 8);
+	const int lr = bottom > 8 ? bottom - 8 : 0;
+	hipLaunchKernelGGL(kd_centres_kernel, dim3(1 << lr), dim3(kBlock), 0, c->stream, center, mult, bottom, lr);
 	if (lr > 0) hipLaunchKernelGGL(kd_centres_top_kernel, dim3(1), dim3(kBlock), 0, c->stream, center, mult, lr - 1);
 	NBCO_HIP(hipGetLastError());
 	return NBCO_OK;

@@ -264,6 +264,27 @@ def test_large_tree_bit_exact_selection_build(engine, oracle32, n, p, quant):
     assert force_err(a, a_ref) < 1e-5
 
 
+@pytest.mark.parametrize("n,p,dens,levels", [(1 << 18, 2, 2.0, 17), (1 << 19, 2, 4.0, 19)])
+def test_deep_trees(engine, oracle32, n, p, dens, levels):
+    """trees of 17 and 19 levels (what N = 4M and N = 16M give at p = 6, here reached with the reference's -i option and
+    one-particle leaves): every per-level launcher has to cope with more than 16 levels"""
+    o = oracle32
+    buf = o.init_reference(n)
+    par = o.params(n)
+    _, a_ref = o.fmm_kd(buf[:2], par, p=p, threads=8, unsort=True, dens_inhom=dens)
+    want = o.kd_tree()
+    assert want["L"] == levels
+    _, a = run_gpu(engine, buf, par, n, fmm_order=p, unsort=1, dens_inhom=dens)
+    info = engine.kd_info()
+    assert (info.L, info.ntot) == (want["L"], want["ntot"])
+    for name in ("index", "mult", "splitdim", "lbound", "rbound", "center"):
+        np.testing.assert_array_equal(engine.kd_array(name), want[name], err_msg=name)
+    for name in ("p2p", "m2l"):
+        np.testing.assert_array_equal(canon_pairs(engine.kd_array(name)), canon_pairs(want[name]), err_msg=name)
+    assert force_err(a, a_ref) < 1e-5
+    engine.set(dens_inhom=1.0)
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 7, 33, 100, 513, 4097, 8191, 8193, 12289])
 def test_edge_sizes(oracle32, n):
     """sizes around every switch of the build (one-node trees, the 4096-particle LDS slice, the 8192-particle
