@@ -100,12 +100,6 @@ __global__ __launch_bounds__(kBlock) void gather3_kernel(float *__restrict__ dst
 	}
 }
 
-__global__ __launch_bounds__(kBlock) void copy_kernel(float *__restrict__ dst, const float *__restrict__ src, long long n)
-{
-	for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock)
-		dst[i] = src[i];
-}
-
 __global__ __launch_bounds__(kBlock) void pack4_kernel(float4 *__restrict__ dst, const float *__restrict__ src, long long n)
 {
 	for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock)

@@ -99,13 +99,6 @@ __global__ void kd_root_kernel(TreeView t, const float *__restrict__ minmax6)   
 	t.index[0] = 0;
 }
 
-__global__ void root_union_kernel(const float *__restrict__ box6, float *__restrict__ minmax6)
-{
-	const int i = threadIdx.x;
-	if (i < 3) minmax6[i] = fminf(minmax6[i], box6[i]);
-	else if (i < 6) minmax6[i] = fmaxf(minmax6[i], box6[i]);
-}
-
 // ---- build prologue, one launch ------------------------------------------------------------------------------
 // Packs the caller's xyz triplets into float4, writes the identity permutation, clears the selection build's histograms
 // and node states, and reduces the bounding box: per-workgroup min / max go into six ordered-bit words with device
@@ -1039,44 +1032,9 @@ __global__ __launch_bounds__(kBlock) void list_compact_kernel(const int2 *__rest
 	for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) dst[i] = src[region_slot(pref, capR, i)];
 }
 
-// ---- directed, sorted interaction lists ------------------------------------------------------------
-// key = target << shift | source.  P2P works on leaf numbers (node - kd_beg(L)) and gets one
-// (leaf, leaf) self entry per leaf (fmm_cart3_kdtree.cuh:1059-1071); M2L works on node numbers.
-__global__ __launch_bounds__(kBlock) void expand_pairs_kernel(const int2 *__restrict__ pairs, long long npairs, int sub, int shift,
-                                                              long long nself, uint64_t *__restrict__ keys)
-{
-	const long long total = npairs + nself;
-	for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock)
-	{
-		if (i < npairs)
-		{
-			int2 p = pairs[i];
-			uint64_t a = (uint64_t)(p.x - sub), b = (uint64_t)(p.y - sub);
-			keys[2 * i] = (a << shift) | b;
-			keys[2 * i + 1] = (b << shift) | a;
-		}
-		else
-		{
-			uint64_t s = (uint64_t)(i - npairs);
-			keys[2 * npairs + s] = (s << shift) | s;
-		}
-	}
-}
-
-__global__ __launch_bounds__(kBlock) void list_starts_kernel(const uint64_t *__restrict__ keys, long long count, int shift, int ntargets,
-                                                             int *__restrict__ start)
-{
-	for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < count; i += (long long)gridDim.x * kBlock)
-	{
-		int tg = (int)(keys[i] >> shift);
-		int prev = i > 0 ? (int)(keys[i - 1] >> shift) : -1;
-		for (int q = prev + 1; q <= tg; ++q) start[q] = (int)i;
-		if (i == count - 1)
-			for (int q = tg + 1; q <= ntargets; ++q) start[q] = (int)count;
-	}
-}
-
 // ---- directed lists by counting sort ---------------------------------------------------------------
+// key = target << shift | source.  P2P works on leaf numbers (node - kd_beg(L)) and gets one (leaf, leaf) self entry per
+// leaf (fmm_cart3_kdtree.cuh:1059-1071); M2L works on node numbers.
 // count (during the traversal, which also hands every entry its slot) -> exclusive scan -> scatter ->
 // per-target sort of the (short) source ranges.  The last step makes the lists, and with them every
 // floating-point sum downstream, identical from run to run.
@@ -1310,16 +1268,6 @@ static int sort_pairs_u64(nbco_ctx *c, uint64_t *kin, uint64_t *kout, uint32_t *
 	NBCO_TRY(c->reserve(c->sort_tmp, bytes));
 	bytes = c->sort_tmp.bytes;
 	NBCO_HIP(rocprim::radix_sort_pairs(c->sort_tmp.ptr, bytes, kin, kout, vin, vout, (size_t)n, 0u, (unsigned)end_bit, c->stream));
-	return NBCO_OK;
-}
-
-static int sort_keys_u64(nbco_ctx *c, uint64_t *kin, uint64_t *kout, long long n, int end_bit)
-{
-	size_t bytes = 0;
-	NBCO_HIP(rocprim::radix_sort_keys(nullptr, bytes, kin, kout, (size_t)n, 0u, (unsigned)end_bit, c->stream));
-	NBCO_TRY(c->reserve(c->sort_tmp, bytes));
-	bytes = c->sort_tmp.bytes;
-	NBCO_HIP(rocprim::radix_sort_keys(c->sort_tmp.ptr, bytes, kin, kout, (size_t)n, 0u, (unsigned)end_bit, c->stream));
 	return NBCO_OK;
 }
 
