@@ -1697,8 +1697,8 @@ int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 	NBCO_TRY(kd_interact(c, view_of(c->kd), c->pos4.as<float4>(), n, c->kd.mlt_max, whole, 0, n, c->unsort.as<int>(), a, param, cnt));
 	if (cnt.sel_overflow)
 	{
-		if (c->force_sort_build) return c->fail(NBCO_ERR_UNSUPPORTED, "kd-tree build: tie flag raised by the sorting build");
-		c->force_sort_build = true;
+		// next more conservative build: three radix passes, then the sorting build
+		if (!c->escalate_build()) return c->fail(NBCO_ERR_UNSUPPORTED, "kd-tree build: tie flag raised by the sorting build");
 		c->tree_valid = false;
 		return fmm_kdtree_eval(c, p, a, n, param);
 	}
@@ -1857,7 +1857,7 @@ int kd_dist_partition(nbco_ctx *c, const float *state_all, long long n_global, i
 	TopView top = top_view(c, ntop);
 	TreeView tv{};
 	tv.lbound = top.lbound; tv.rbound = top.rbound; tv.splitdim = top.splitdim; tv.index = top.index; tv.L = d; tv.ntot = ntop;
-	for (int attempt = 0; attempt < 2; ++attempt)
+	for (int attempt = 0; attempt < 3; ++attempt)
 	{
 		float4 *pos = c->pos4.as<float4>(), *pos_alt = c->pos4_alt.as<float4>();
 		int *unsort = c->unsort.as<int>(), *unsort_alt = c->unsort_alt.as<int>();
@@ -1873,7 +1873,7 @@ int kd_dist_partition(nbco_ctx *c, const float *state_all, long long n_global, i
 		int flag = 0;
 		NBCO_HIP(hipMemcpyAsync(&flag, c->counters.as<int>() + 110, sizeof(int), hipMemcpyDeviceToHost, st));
 		NBCO_HIP(hipStreamSynchronize(st));
-		if (flag && use_select) { c->force_sort_build = true; continue; }
+		if (flag && use_select) { c->escalate_build(); continue; }
 		// the domain's slice of the partitioned state
 		hipLaunchKernelGGL(unpack4_kernel, dim3(grid1d(nl)), dim3(kBlock), 0, st, (const float4 *)(pos + (size_t)rank * nl), state_local, nl);
 		NBCO_TRY(launch_gather3(c, state_local + 3 * nl, state_all + 3 * n, unsort + (size_t)rank * nl, nl, false));
@@ -1906,19 +1906,17 @@ int kd_dist_local(nbco_ctx *c, float *buf_local, long long n_local, void *nodes_
 		float *root6 = c->small.as<float>() + 80;
 		hipLaunchKernelGGL(dist_root6_kernel, dim3(1), dim3(64), 0, st, (const float *)top.lbound, (const float *)top.rbound, (1 << d) - 1 + lay.rank, root6);
 		NBCO_TRY(kd_build_upward(c, buf_local, n_local, lay.L_local, root6, rebuild, 1));
-		if (rebuild && !c->force_sort_build)
+		while (rebuild && !c->force_sort_build)
 		{
 			// A tie overflow of the selection build has to be caught BEFORE the exchange (the other domains are
-			// about to consume these positions and nodes); the retry with the sorting build is purely local.
+			// about to consume these positions and nodes); the retry with a more conservative build is purely local.
 			int flag = 0;
 			NBCO_HIP(hipMemcpyAsync(&flag, c->counters.as<int>() + 110, sizeof(int), hipMemcpyDeviceToHost, st));
 			NBCO_HIP(hipStreamSynchronize(st));
-			if (flag)
-			{
-				c->force_sort_build = true;
-				c->tree_valid = false;
-				NBCO_TRY(kd_build_upward(c, buf_local, n_local, lay.L_local, root6, rebuild, 1));
-			}
+			if (!flag) break;
+			c->escalate_build();
+			c->tree_valid = false;
+			NBCO_TRY(kd_build_upward(c, buf_local, n_local, lay.L_local, root6, rebuild, 1));
 		}
 		c->dist.rebuilt = rebuild;
 		NBCO_HIP(hipMemcpyAsync(pos_send, c->pos4.ptr, sizeof(float4) * (size_t)n_local, hipMemcpyDeviceToDevice, st));

@@ -7,9 +7,11 @@
 // and the remaining elements of that order.  Only the children's particle SETS and the two boundary
 // coordinates enter the tree, so while a node is too large for one workgroup's LDS the level is
 // built by
-//   1. a three-pass (11 + 11 + 10 bit) radix select of the k-th smallest ordered key c[a1] per node,
+//   1. a radix select of the k-th smallest ordered key c[a1] per node: 11 + 11 bits, which leaves a handful of candidates
+//      in the pivot's bucket (a third, 10-bit pass for nodes above 2^21 particles or after a bucket overflow),
 //   2. an unordered partition into < pivot | > pivot with per-node atomics (block-aggregated),
-//   3. an exact resolution of the elements that tie with the pivot (a handful) by (c[a2], c[a3], index),
+//   3. an exact resolution of the candidates -- the elements that share the pivot's bucket or tie with the pivot -- by
+//      (c[a1], c[a2], c[a3], index),
 //   4. evalBox for the children from the pivot value and the smallest key of the right part.
 // The canonical order is re-established in LDS when the subtree kernel takes over (k_fmm_kd.hip).
 // If more than kTieCap elements tie with a pivot (degenerate inputs) a flag is raised and the caller
@@ -212,12 +214,13 @@ __device__ inline void ties_and_boxes(const float4 *__restrict__ pos_in, const i
                                       int *__restrict__ unsort_out, float *__restrict__ lbound, float *__restrict__ rbound,
                                       int *__restrict__ splitdim, int *__restrict__ index, SelNode *__restrict__ nodes,
                                       const uint32_t *__restrict__ tielist, int *__restrict__ flag, long long n, int l, int j, int lane,
-                                      const SelPivot pv /* prefix = the pivot as an ordered key */)
+                                      const SelPivot pv /* three passes: prefix = the pivot as an ordered key */)
 {
 	const int m = 1 << l;
 	const int node = m - 1 + j, a1 = splitdim[node];
 	const uint32_t nt = ld_agent_u32(&nodes[j].tiecnt);
-	bool tie_right = false;
+	// the pivot (largest key of the left child) and the smallest candidate key that went right
+	uint32_t pivot = pv.prefix, cand_right = 0xFFFFFFFFu;
 	if (nt > kTieCap) { if (lane == 0) *flag = 1; }
 	else if (nt > 0)
 	{
@@ -230,11 +233,14 @@ __device__ inline void ties_and_boxes(const float4 *__restrict__ pos_in, const i
 			if (a2 < 0) a2 = a;
 			else { a3 = a; break; }
 		}
-		uint32_t idx = 0, k2 = 0, k3 = 0, org = 0;
+		// candidates: the elements that tie with the pivot (three passes) or share its 22-bit bucket (two passes).  Their
+		// order in the stable-sort chain is (c[a1], c[a2], c[a3], original index); the first `need` belong to the left child.
+		uint32_t idx = 0, k1 = 0, k2 = 0, k3 = 0, org = 0;
 		if ((uint32_t)lane < nt)
 		{
 			idx = ld_agent_u32(&tielist[(size_t)j * kTieCap + lane]);
 			const float4 p = pos_in[idx];
+			k1 = ordered_bits(axis_of(p, a1));
 			k2 = a2 >= 0 ? ordered_bits(axis_of(p, a2)) : 0;
 			k3 = a3 >= 0 ? ordered_bits(axis_of(p, a3)) : 0;
 			org = (uint32_t)unsort_in[idx];
@@ -242,24 +248,22 @@ __device__ inline void ties_and_boxes(const float4 *__restrict__ pos_in, const i
 		uint32_t rank = 0;
 		for (uint32_t q = 0; q < nt; ++q)
 		{
-			const uint32_t q2 = __shfl(k2, q), q3 = __shfl(k3, q), qo = __shfl(org, q);
-			const bool before = q2 < k2 || (q2 == k2 && (q3 < k3 || (q3 == k3 && qo < org)));
+			const uint32_t q1 = __shfl(k1, q), q2 = __shfl(k2, q), q3 = __shfl(k3, q), qo = __shfl(org, q);
+			const bool before = q1 < k1 || (q1 == k1 && (q2 < k2 || (q2 == k2 && (q3 < k3 || (q3 == k3 && qo < org)))));
 			rank += before ? 1u : 0u;
 		}
-		bool right = false;
-		if ((uint32_t)lane < nt)
+		const bool mine = (uint32_t)lane < nt;
+		if (mine)
 		{
 			long long dst;
 			if (rank < pv.need) dst = range_start(n, j, m) + atomicAdd(&nodes[j].cntL, 1u);
-			else
-			{
-				dst = range_start(n, 2 * j + 1, 2LL * m) + atomicAdd(&nodes[j].cntR, 1u);
-				right = true;   // a pivot-valued element went right: it is the right child's smallest key
-			}
+			else dst = range_start(n, 2 * j + 1, 2LL * m) + atomicAdd(&nodes[j].cntR, 1u);
 			pos_out[dst] = pos_in[idx];
 			unsort_out[dst] = unsort_in[idx];
 		}
-		tie_right = __ballot(right) != 0;
+		const unsigned long long at_pivot = __ballot(mine && rank + 1 == pv.need), after = __ballot(mine && rank == pv.need);
+		if (at_pivot) pivot = __shfl(k1, __ffsll((long long)at_pivot) - 1);
+		if (after) cand_right = __shfl(k1, __ffsll((long long)after) - 1);
 	}
 	if (lane < 2)
 	{
@@ -268,13 +272,14 @@ __device__ inline void ties_and_boxes(const float4 *__restrict__ pos_in, const i
 		float rb[3] = {rbound[3 * node], rbound[3 * node + 1], rbound[3 * node + 2]};
 		if (c & 1)
 		{
-			const uint32_t mr = tie_right ? pv.prefix : ~ld_agent_u32(&nodes[j].minR);
-			const float v = unordered_bits(mr);
+			const uint32_t inv = ld_agent_u32(&nodes[j].minR);   // inverted, 0 = no element above the candidates
+			const uint32_t above = inv ? ~inv : 0xFFFFFFFFu;
+			const float v = unordered_bits(cand_right < above ? cand_right : above);
 			if (a1 == 0) lb[0] = v; else if (a1 == 1) lb[1] = v; else lb[2] = v;
 		}
 		else
 		{
-			const float v = unordered_bits(pv.prefix);
+			const float v = unordered_bits(pivot);
 			if (a1 == 0) rb[0] = v; else if (a1 == 1) rb[1] = v; else rb[2] = v;
 		}
 		lbound[3 * child] = lb[0]; lbound[3 * child + 1] = lb[1]; lbound[3 * child + 2] = lb[2];
@@ -288,7 +293,7 @@ __device__ inline void ties_and_boxes(const float4 *__restrict__ pos_in, const i
 // Unordered partition of every node into [keys below the pivot | keys above the pivot]; elements equal to the
 // pivot go left when all of them belong there and to the tie list otherwise.  All loads of a thread's 8 elements
 // are issued up front, slots are reserved with one packed block scan and four concurrent global atomics.
-template <int BLOCK>
+template <int BLOCK, bool TWO>
 __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__restrict__ pos_in, const int *__restrict__ unsort_in,
                                                                float4 *__restrict__ pos_out, int *__restrict__ unsort_out,
                                                                const int *__restrict__ sd_l, SelNode *__restrict__ nodes,
@@ -317,23 +322,24 @@ __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__re
 	const long long split = j1 > j0 ? range_start(n, j1, m) : n;
 	// the third pass's histogram is descended here (see resolve_before): pivot back to the un-normalised ordered key
 	__shared__ uint32_t sh[BLOCK / 64 + 4];
-	uint32_t piv[2] = {0, 0}, all_left[2] = {0, 0};
+	// TWO: the select stopped after two passes -- piv is the 22-bit bucket of the pivot in the node's normalised key space
+	// (window kmin / shl), every element of that bucket is a candidate for the resolver; otherwise piv is the pivot itself
+	uint32_t piv[2] = {0, 0}, all_left[2] = {0, 0}, kmin[2] = {0, 0};
+	int shl[2] = {0, 0};
 	SelPivot pvs[2];
 	for (int jj = 0; jj < 2; ++jj)
 	{
 		pvs[jj] = SelPivot{0, 0, 0, 0};
 		if (j0 + jj <= j1)
 		{
-			uint32_t kmin;
-			int shl;
-			key_window(lbound, rbound, sd_l, l, j0 + jj, kmin, shl);
-			pvs[jj] = resolve_before<3, BLOCK>(hist, nodes, n, l, j0 + jj, i0, sh);
-			pvs[jj].prefix = (pvs[jj].prefix >> shl) + kmin;
+			key_window(lbound, rbound, sd_l, l, j0 + jj, kmin[jj], shl[jj]);
+			pvs[jj] = resolve_before<TWO ? 2 : 3, BLOCK>(hist, nodes, n, l, j0 + jj, i0, sh);
+			if (!TWO) pvs[jj].prefix = (pvs[jj].prefix >> shl[jj]) + kmin[jj];
 			piv[jj] = pvs[jj].prefix;
-			all_left[jj] = pvs[jj].need == pvs[jj].neq;
+			all_left[jj] = !TWO && pvs[jj].need == pvs[jj].neq;
 		}
 	}
-	if (j1 == j0) { piv[1] = piv[0]; all_left[1] = all_left[0]; }
+	if (j1 == j0) { piv[1] = piv[0]; all_left[1] = all_left[0]; kmin[1] = kmin[0]; shl[1] = shl[0]; }
 	const int sd[2] = {sd_l[j0], sd_l[j1]};
 	if (threadIdx.x < 2) mR[threadIdx.x] = 0xFFFFFFFFu;
 	// Destination slots.  The four output streams of the chunk (left / right of its one or two nodes) are filled in
@@ -357,8 +363,9 @@ __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__re
 		{
 			const int jj = i >= split ? 1 : 0;
 			const uint32_t key = ordered_bits(axis_of(p[e], sd[jj]));
-			if (key < piv[jj] || (key == piv[jj] && all_left[jj])) cat[e] = 2 * jj;
-			else if (key > piv[jj]) { cat[e] = 2 * jj + 1; tmin[jj] = key < tmin[jj] ? key : tmin[jj]; }
+			const uint32_t cmp = TWO ? ((key - kmin[jj]) << shl[jj]) >> 10 : key;
+			if (cmp < piv[jj] || (cmp == piv[jj] && all_left[jj])) cat[e] = 2 * jj;
+			else if (cmp > piv[jj]) { cat[e] = 2 * jj + 1; tmin[jj] = key < tmin[jj] ? key : tmin[jj]; }
 			else
 			{
 				const uint32_t t = atomicAdd(&nodes[j0 + jj].tiecnt, 1u);
@@ -464,7 +471,7 @@ int kd_select_begin(nbco_ctx *c, int l0, bool zero, long long *words_a, long lon
 
 // Split every node of level l (all of which hold more than 4096 particles) and write the boxes of level
 // l + 1.  `flag` (device int) is set when a node had more ties than the resolver handles.
-template <int BLOCK>
+template <int BLOCK, bool TWO>
 static void select_level_launch(nbco_ctx *c, int l, long long n, const float4 *pos_in, const int *unsort_in, float4 *pos_out, int *unsort_out,
                                 float *lbound, float *rbound, int *splitdim, int *index, int *flag)
 {
@@ -479,18 +486,25 @@ static void select_level_launch(nbco_ctx *c, int l, long long n, const float4 *p
 	const int gchunks = (int)((n + CHUNK - 1) / CHUNK);
 	hipLaunchKernelGGL((sel_hist_kernel<0, BLOCK>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l);
 	hipLaunchKernelGGL((sel_hist_kernel<1, BLOCK>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l);
-	hipLaunchKernelGGL((sel_hist_kernel<2, BLOCK>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l);
-	hipLaunchKernelGGL(sel_partition_kernel<BLOCK>, dim3(gchunks), dim3(BLOCK), 0, st, pos_in, unsort_in, pos_out, unsort_out, sd_l, nodes, ties, n, l,
+	if (!TWO)
+		hipLaunchKernelGGL((sel_hist_kernel<2, BLOCK>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l);
+	hipLaunchKernelGGL((sel_partition_kernel<BLOCK, TWO>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, unsort_in, pos_out, unsort_out, sd_l, nodes, ties, n, l,
 	                   lbound, rbound, splitdim, index, flag, (const uint32_t *)hist);
 }
 
 int kd_select_level(nbco_ctx *c, int l, long long n, const float4 *pos_in, const int *unsort_in, float4 *pos_out, int *unsort_out,
                     float *lbound, float *rbound, int *splitdim, int *index, int *flag)
 {
-	if ((n >> l) >= 8 * kBlockBig)
-		select_level_launch<kBlockBig>(c, l, n, pos_in, unsort_in, pos_out, unsort_out, lbound, rbound, splitdim, index, flag);
-	else
-		select_level_launch<kBlockSmall>(c, l, n, pos_in, unsort_in, pos_out, unsort_out, lbound, rbound, splitdim, index, flag);
+	// Two radix passes (22 of the 32 key bits, spread over the node's box by the key window) leave the pivot's bucket with
+	// about node size / 2^22 elements -- a handful, which the tie resolver orders exactly -- so nodes of up to 2^21 particles
+	// skip the third pass.  A bucket with more than kTieCap elements (tightly clustered input) raises the tie flag and
+	// the caller falls back to three passes (sel_three_pass), then to the sorting build.
+	const bool two = !c->sel_three_pass && (n >> l) <= (1LL << 21);
+	const bool big = (n >> l) >= 8 * kBlockBig;
+#define NBCO_SEL_ARGS c, l, n, pos_in, unsort_in, pos_out, unsort_out, lbound, rbound, splitdim, index, flag
+	if (big) { if (two) select_level_launch<kBlockBig, true>(NBCO_SEL_ARGS); else select_level_launch<kBlockBig, false>(NBCO_SEL_ARGS); }
+	else { if (two) select_level_launch<kBlockSmall, true>(NBCO_SEL_ARGS); else select_level_launch<kBlockSmall, false>(NBCO_SEL_ARGS); }
+#undef NBCO_SEL_ARGS
 	NBCO_HIP(hipGetLastError());
 	return NBCO_OK;
 }

@@ -125,7 +125,14 @@ struct nbco_ctx
 		long long n_global = 0, n_local = 0;
 		bool partitioned = false, build_done = false, local_done = false, rebuilt = false;
 	} dist;
-	bool force_sort_build = false;          // set after a tie overflow: use the sorting build from then on
+	bool sel_three_pass = false;            // set after the first tie / bucket overflow: three radix passes per select
+	bool force_sort_build = false;          // set after the second: use the sorting build from then on
+	bool escalate_build()                   // next more conservative build; false when there is none left
+	{
+		if (!sel_three_pass) { sel_three_pass = true; return true; }
+		if (!force_sort_build) { force_sort_build = true; return true; }
+		return false;
+	}
 	long long list_cap = 0;
 	// bookkeeping of the last evaluation
 	nbco_kd_info info{};
