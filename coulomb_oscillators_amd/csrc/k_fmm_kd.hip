@@ -312,7 +312,7 @@ constexpr int kSelNodes = kSubS / kSelSeg;   // nodes of the first level whose s
 constexpr int kSubTieCap = 64;   // pivot ties resolved per node; more -> flag, the caller falls back to the sorting build
 struct SubSel
 {
-	uint32_t prefix, minR;
+	uint32_t prefix, minR, pivot;   // digits chosen so far; smallest key of the right part; the pivot's key
 	int rank, neq, cntL, cntR, ntie;
 };
 
@@ -321,7 +321,7 @@ __device__ inline void st_agent(float *p, float v) { __hip_atomic_store(p, v, __
 
 __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const float4 *__restrict__ pos_in, const int *__restrict__ unsort_in,
                                                            float4 *__restrict__ pos_out, int *__restrict__ unsort_out, long long n, int l0,
-                                                           int canon, int *__restrict__ flag)
+                                                           int canon, int two_pass, int *__restrict__ flag)
 {
 	__shared__ uint64_t keys[kSubS];
 	__shared__ int prio[3];
@@ -535,8 +535,12 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 		{
 			const int l = l0 + s, nodes = 1 << s, seg = P2 >> s, half = seg >> 1, lseg = 31 - __clz(seg);
 			// radix digits of 8 bits (4 passes) while the histograms of all nodes fit the 32 KB key buffer, 7 bits (5 passes) below
-			const int db = nodes <= 32 ? 8 : 7, bins = 1 << db, npass = (32 + db - 1) / db;
-			if (tid < nodes) sel[tid] = SubSel{0u, 0xFFFFFFFFu, half, 0, 0, 0, 0};
+			// two_pass: stop after two digits (16 or 14 bits of the box-normalised key): the pivot's bucket then holds
+			// segment / 2^16 elements -- the pivot and its exact ties, practically -- and all of them go to the resolver below,
+			// which orders them by (key, ancestor axes, original index)
+			const int db = nodes <= 32 ? 8 : 7, bins = 1 << db, npass = two_pass ? 2 : (32 + db - 1) / db;
+			const int rest = 32 - min(32, db * npass);   // key bits not looked at by the passes
+			if (tid < nodes) sel[tid] = SubSel{0u, 0xFFFFFFFFu, 0u, half, 0, 0, 0, 0};
 			for (int q = tid; q < nodes * bins; q += kSubT) hist[q] = 0;
 			__syncthreads();
 			uint32_t key[kSubE];
@@ -593,7 +597,9 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 				}
 				__syncthreads();
 			}
-			// classify: 0 left, 1 right, 2 pivot tie (side decided by its rank among the node's ties)
+			if (!two_pass && tid < nodes) sel[tid].pivot = sel[tid].prefix;   // all digits known: the prefix is the pivot
+			// classify: 0 left, 1 right, 2 candidate (pivot tie, or pivot bucket after two passes: side decided by its rank
+			// among the node's candidates)
 			int side[kSubE];
 #pragma unroll
 			for (int e = 0; e < kSubE; ++e)
@@ -602,9 +608,9 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 				side[e] = 0;
 				if (i >= cnt) continue;
 				const int j = i >> lseg;
-				const uint32_t pv = sel[j].prefix;
-				if (key[e] > pv) side[e] = 1;
-				else if (key[e] == pv && sel[j].rank < sel[j].neq)
+				const uint32_t pv = sel[j].prefix, kh = two_pass ? key[e] >> rest : key[e];
+				if (kh > pv) side[e] = 1;
+				else if (kh == pv && (two_pass || sel[j].rank < sel[j].neq))
 				{
 					side[e] = 2;
 					const int slot = atomicAdd(&sel[j].ntie, 1);
@@ -624,13 +630,24 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 				if (side[e] == 2)
 				{
 					const int nt = min(sel[j].ntie, kSubTieCap);
+					// candidates differ in the split coordinate itself when the select stopped early: it is the first key, the
+					// ancestors' axes other than it follow
+					const int a1 = sdl[j];
+					int b2 = -1, b3 = -1;
+					for (int q = 0; q < 3; ++q)
+					{
+						const int a = anc[j][q];
+						if (a < 0 || a == a1) continue;
+						if (b2 < 0) b2 = a; else if (b3 < 0) b3 = a;
+					}
 					int rk = 0;
 					for (int q = 0; q < nt; ++q)
 					{
 						const int o = tie_idx[j][q];
-						if (o != i && chain_less(o, i, anc[j][0], anc[j][1], anc[j][2])) ++rk;
+						if (o != i && chain_less(o, i, a1, b2, b3)) ++rk;
 					}
 					side[e] = rk < sel[j].rank ? 0 : 1;
+					if (rk + 1 == sel[j].rank) sel[j].pivot = key[e];   // the last element of the left child
 				}
 				rx[e] = px[i]; ry[e] = py[i]; rz[e] = pz[i]; ro[e] = orig[i];
 			}
@@ -681,7 +698,7 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 				float lb[3], rb[3];
 				for (int a = 0; a < 3; ++a) { lb[a] = ld_agent(&t.lbound[3 * parent + a]); rb[a] = ld_agent(&t.rbound[3 * parent + a]); }
 				if (cidx & 1) lb[split] = unordered_bits((sel[j].minR >> wshl[j]) + wmin[j]);
-				else rb[split] = unordered_bits((sel[j].prefix >> wshl[j]) + wmin[j]);
+				else rb[split] = unordered_bits((sel[j].pivot >> wshl[j]) + wmin[j]);
 				for (int a = 0; a < 3; ++a) { st_agent(&t.lbound[3 * node + a], lb[a]); st_agent(&t.rbound[3 * node + a], rb[a]); }
 				sdc = longest_axis(rb[0] - lb[0], rb[1] - lb[1], rb[2] - lb[2]);
 				t.splitdim[node] = sdc;
@@ -1471,7 +1488,7 @@ static int kd_build_upward(nbco_ctx *c, const float *p, long long n, int L, cons
 			NBCO_TRY(kd_build_top(c, tv, pos, pos_alt, unsort, unsort_alt, n, l0, use_select, true));
 			// the rest of every level-l0 subtree inside one workgroup's LDS
 			hipLaunchKernelGGL(kd_subtree_kernel, dim3(kd_cnt(l0)), dim3(kSubT), 0, st, tv, (const float4 *)pos, (const int *)unsort, pos_alt, unsort_alt, n, l0,
-			                   use_select ? 1 : 0, c->counters.as<int>() + 110);
+			                   use_select ? 1 : 0, c->sel_three_pass ? 0 : 1, c->counters.as<int>() + 110);
 			std::swap(pos, pos_alt);
 			std::swap(unsort, unsort_alt);
 			NBCO_HIP(hipGetLastError());
