@@ -179,7 +179,7 @@ def main():
     if args.workload == "fmm_kd":
         info = eng.kd_info()
         pairs_per_eval = int(info.directed_p2p)   # this rank's directed pair interactions per evaluation
-        extra = {"L": info.L, "p2p_pairs": int(info.p2p_pairs), "m2l_pairs": int(info.m2l_pairs)}
+        extra = {"L": info.L, "p2p_pairs": int(info.p2p_pairs), "m2l_pairs": int(info.m2l_pairs), "build_mode": int(info.build_mode)}
         if sharded:
             extra.update({"n_system": n_sys, "rebalance_every": args.rebalance,
                           "allgather_bytes_per_eval_per_gpu": run.exchange_bytes(), "backend": args.backend})

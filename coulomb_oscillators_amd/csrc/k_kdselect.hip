@@ -8,7 +8,7 @@
 // coordinates enter the tree, so while a node is too large for one workgroup's LDS the level is
 // built by
 //   1. a radix select of the k-th smallest ordered key c[a1] per node: 11 + 11 bits, which leaves a handful of candidates
-//      in the pivot's bucket (a third, 10-bit pass for nodes above 2^21 particles or after a bucket overflow),
+//      in the pivot's bucket (a third, 10-bit pass for nodes above 2^19 particles or after a bucket overflow),
 //   2. an unordered partition into < pivot | > pivot with per-node atomics (block-aggregated),
 //   3. an exact resolution of the candidates -- the elements that share the pivot's bucket or tie with the pivot -- by
 //      (c[a1], c[a2], c[a3], index),
@@ -293,7 +293,7 @@ __device__ inline void ties_and_boxes(const float4 *__restrict__ pos_in, const i
 // Unordered partition of every node into [keys below the pivot | keys above the pivot]; elements equal to the
 // pivot go left when all of them belong there and to the tie list otherwise.  All loads of a thread's 8 elements
 // are issued up front, slots are reserved with one packed block scan and four concurrent global atomics.
-template <int BLOCK, bool TWO>
+template <int BLOCK, int NP>
 __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__restrict__ pos_in, const int *__restrict__ unsort_in,
                                                                float4 *__restrict__ pos_out, int *__restrict__ unsort_out,
                                                                const int *__restrict__ sd_l, SelNode *__restrict__ nodes,
@@ -322,8 +322,10 @@ __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__re
 	const long long split = j1 > j0 ? range_start(n, j1, m) : n;
 	// the third pass's histogram is descended here (see resolve_before): pivot back to the un-normalised ordered key
 	__shared__ uint32_t sh[BLOCK / 64 + 4];
-	// TWO: the select stopped after two passes -- piv is the 22-bit bucket of the pivot in the node's normalised key space
-	// (window kmin / shl), every element of that bucket is a candidate for the resolver; otherwise piv is the pivot itself
+	// NP = 2: the select stopped after two passes -- piv is the 22-bit bucket of the pivot in the node's normalised key space
+	// (window kmin / shl), every element of that bucket is a candidate for the resolver; NP = 3: piv is the pivot itself
+	constexpr bool EARLY = NP < 3;
+	constexpr int kDrop = 10;   // key bits below the bucket
 	uint32_t piv[2] = {0, 0}, all_left[2] = {0, 0}, kmin[2] = {0, 0};
 	int shl[2] = {0, 0};
 	SelPivot pvs[2];
@@ -333,10 +335,10 @@ __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__re
 		if (j0 + jj <= j1)
 		{
 			key_window(lbound, rbound, sd_l, l, j0 + jj, kmin[jj], shl[jj]);
-			pvs[jj] = resolve_before<TWO ? 2 : 3, BLOCK>(hist, nodes, n, l, j0 + jj, i0, sh);
-			if (!TWO) pvs[jj].prefix = (pvs[jj].prefix >> shl[jj]) + kmin[jj];
+			pvs[jj] = resolve_before<NP, BLOCK>(hist, nodes, n, l, j0 + jj, i0, sh);
+			if (!EARLY) pvs[jj].prefix = (pvs[jj].prefix >> shl[jj]) + kmin[jj];
 			piv[jj] = pvs[jj].prefix;
-			all_left[jj] = !TWO && pvs[jj].need == pvs[jj].neq;
+			all_left[jj] = !EARLY && pvs[jj].need == pvs[jj].neq;
 		}
 	}
 	if (j1 == j0) { piv[1] = piv[0]; all_left[1] = all_left[0]; kmin[1] = kmin[0]; shl[1] = shl[0]; }
@@ -363,7 +365,7 @@ __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__re
 		{
 			const int jj = i >= split ? 1 : 0;
 			const uint32_t key = ordered_bits(axis_of(p[e], sd[jj]));
-			const uint32_t cmp = TWO ? ((key - kmin[jj]) << shl[jj]) >> 10 : key;
+			const uint32_t cmp = EARLY ? ((key - kmin[jj]) << shl[jj]) >> kDrop : key;
 			if (cmp < piv[jj] || (cmp == piv[jj] && all_left[jj])) cat[e] = 2 * jj;
 			else if (cmp > piv[jj]) { cat[e] = 2 * jj + 1; tmin[jj] = key < tmin[jj] ? key : tmin[jj]; }
 			else
@@ -471,7 +473,7 @@ int kd_select_begin(nbco_ctx *c, int l0, bool zero, long long *words_a, long lon
 
 // Split every node of level l (all of which hold more than 4096 particles) and write the boxes of level
 // l + 1.  `flag` (device int) is set when a node had more ties than the resolver handles.
-template <int BLOCK, bool TWO>
+template <int BLOCK, int NP>
 static void select_level_launch(nbco_ctx *c, int l, long long n, const float4 *pos_in, const int *unsort_in, float4 *pos_out, int *unsort_out,
                                 float *lbound, float *rbound, int *splitdim, int *index, int *flag)
 {
@@ -486,24 +488,37 @@ static void select_level_launch(nbco_ctx *c, int l, long long n, const float4 *p
 	const int gchunks = (int)((n + CHUNK - 1) / CHUNK);
 	hipLaunchKernelGGL((sel_hist_kernel<0, BLOCK>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l);
 	hipLaunchKernelGGL((sel_hist_kernel<1, BLOCK>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l);
-	if (!TWO)
+	if (NP >= 3)
 		hipLaunchKernelGGL((sel_hist_kernel<2, BLOCK>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l);
-	hipLaunchKernelGGL((sel_partition_kernel<BLOCK, TWO>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, unsort_in, pos_out, unsort_out, sd_l, nodes, ties, n, l,
+	hipLaunchKernelGGL((sel_partition_kernel<BLOCK, NP>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, unsort_in, pos_out, unsort_out, sd_l, nodes, ties, n, l,
 	                   lbound, rbound, splitdim, index, flag, (const uint32_t *)hist);
 }
 
 int kd_select_level(nbco_ctx *c, int l, long long n, const float4 *pos_in, const int *unsort_in, float4 *pos_out, int *unsort_out,
                     float *lbound, float *rbound, int *splitdim, int *index, int *flag)
 {
-	// Two radix passes (22 of the 32 key bits, spread over the node's box by the key window) leave the pivot's bucket with
-	// about node size / 2^22 elements -- a handful, which the tie resolver orders exactly -- so nodes of up to 2^21 particles
-	// skip the third pass.  A bucket with more than kTieCap elements (tightly clustered input) raises the tie flag and
-	// the caller falls back to three passes (sel_three_pass), then to the sorting build.
-	const bool two = !c->sel_three_pass && (n >> l) <= (1LL << 21);
-	const bool big = (n >> l) >= 8 * kBlockBig;
+	// Two radix passes look at the first 22 bits of the key, spread over the node's box by the key window.  Ordered float
+	// bits are piecewise linear in the coordinate (every binade has 2^23 keys), so in a box that reaches down to ~0 the upper
+	// half of the box shares as few as 2^13 buckets: the pivot's bucket then holds up to node size / 2^14 elements, which the
+	// tie resolver orders exactly as long as they are at most kTieCap -- nodes of up to 2^19 particles stop after two passes
+	// (<= 32 candidates in that worst case, a handful normally), larger ones run the third.  (One pass is not enough even for
+	// 4096-particle nodes: a box that crosses zero keeps half its particles in 8 of the 2048 first-digit bins.)  A fuller
+	// bucket (tightly clustered input) raises the tie flag and the caller falls back to three passes everywhere
+	// (sel_three_pass), then to the sorting build.
+	const long long node = n >> l;
+	const int np = (c->sel_three_pass || node > (1LL << 19)) ? 3 : 2;
+	const bool big = node >= 8 * kBlockBig;
 #define NBCO_SEL_ARGS c, l, n, pos_in, unsort_in, pos_out, unsort_out, lbound, rbound, splitdim, index, flag
-	if (big) { if (two) select_level_launch<kBlockBig, true>(NBCO_SEL_ARGS); else select_level_launch<kBlockBig, false>(NBCO_SEL_ARGS); }
-	else { if (two) select_level_launch<kBlockSmall, true>(NBCO_SEL_ARGS); else select_level_launch<kBlockSmall, false>(NBCO_SEL_ARGS); }
+	if (big)
+	{
+		if (np == 2) select_level_launch<kBlockBig, 2>(NBCO_SEL_ARGS);
+		else select_level_launch<kBlockBig, 3>(NBCO_SEL_ARGS);
+	}
+	else
+	{
+		if (np == 2) select_level_launch<kBlockSmall, 2>(NBCO_SEL_ARGS);
+		else select_level_launch<kBlockSmall, 3>(NBCO_SEL_ARGS);
+	}
 #undef NBCO_SEL_ARGS
 	NBCO_HIP(hipGetLastError());
 	return NBCO_OK;

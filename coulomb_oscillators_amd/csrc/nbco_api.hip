@@ -458,6 +458,7 @@ int nbco_kd_get_info(nbco_ctx *c, nbco_kd_info *info)
 		c->info.directed_p2p = v;
 	}
 	*info = c->info;
+	info->build_mode = c->force_sort_build ? 2 : (c->sel_three_pass ? 1 : 0);
 	return NBCO_OK;
 }
 int nbco_kd_copy(nbco_ctx *c, int which, void *host_dst, long long host_bytes)

@@ -134,6 +134,10 @@ typedef struct nbco_kd_info {
 	long long m2l_pairs;        /* unordered node pairs in the M2L list */
 	long long directed_p2p;     /* sum 2*m1*m2 over the list + sum m^2 over leaves */
 	int rebuilt;                /* the last evaluation rebuilt the tree */
+	int build_mode;             /* how this context builds trees: 0 = median selection with two radix passes + exact
+	                               resolution of the pivot bucket (default), 1 = three radix passes (after a bucket held
+	                               more candidates than the resolver takes), 2 = stable-sort chain (after a pivot had
+	                               more exact ties than that).  The trees are identical; only the speed differs. */
 } nbco_kd_info;
 int nbco_kd_get_info(nbco_ctx *c, nbco_kd_info *info);
 
