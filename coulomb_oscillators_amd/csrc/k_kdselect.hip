@@ -8,7 +8,8 @@
 // coordinates enter the tree, so while a node is too large for one workgroup's LDS the level is
 // built by
 //   1. a radix select of the k-th smallest ordered key c[a1] per node: 11 + 11 bits, which leaves a handful of candidates
-//      in the pivot's bucket (a third, 10-bit pass for nodes above 2^19 particles or after a bucket overflow),
+//      in the pivot's bucket (three passes, 11 + 11 + 10 bits of the ordered float, for nodes above 2^22 particles or after a
+//      bucket overflow),
 //   2. an unordered partition into < pivot | > pivot with per-node atomics (block-aggregated),
 //   3. an exact resolution of the candidates -- the elements that share the pivot's bucket or tie with the pivot -- by
 //      (c[a1], c[a2], c[a3], index),
@@ -90,6 +91,25 @@ __device__ inline void key_window(const float *__restrict__ lbound, const float 
 	shl = span ? __clz(span) : 0;
 }
 
+// Bucket key of the early-stop select (two passes): any monotone non-decreasing map of the coordinate will do, because the
+// elements of the pivot's bucket are ordered exactly afterwards.  The ordered float bits are piecewise linear (2^23 keys per
+// binade: a box that reaches down to ~0 keeps half of its particles in 1/256 of the key range); this map is linear over the
+// node's box, so buckets hold node size / 2^22 elements times the density contrast inside the box.  Subtraction,
+// multiplication and the truncating conversion are each monotone, and every kernel evaluates the same expression.
+__device__ inline void lin_window(const float *__restrict__ lbound, const float *__restrict__ rbound, const int *__restrict__ sd_l, int l,
+                                  long long j, float &lo, float &scale)
+{
+	const int node = (1 << l) - 1 + (int)j, a = sd_l[j];
+	lo = lbound[3 * node + a];
+	const float span = __fsub_rn(rbound[3 * node + a], lo);
+	scale = span > 0.f ? __fdiv_rn(4294967040.f, span) : 0.f;
+}
+__device__ inline uint32_t lin_key(float x, float lo, float scale)
+{
+	const float v = __fmul_rn(__fsub_rn(x, lo), scale);
+	return (uint32_t)fminf(fmaxf(v, 0.f), 4294967040.f);
+}
+
 // number of CHUNK-sized blocks whose element range overlaps node j
 template <int CHUNK>
 __device__ inline uint32_t chunks_of_node(long long n, long long j, long long m)
@@ -123,7 +143,7 @@ __device__ inline SelPivot resolve_before(const uint32_t *__restrict__ hist, Sel
 	return pv;
 }
 
-template <int PASS, int BLOCK>
+template <int PASS, int BLOCK, bool LIN>
 __global__ __launch_bounds__(BLOCK) void sel_hist_kernel(const float4 *__restrict__ pos, const int *__restrict__ sd_l, uint32_t *__restrict__ hist,
                                                           SelNode *__restrict__ nodes, const float *__restrict__ lbound,
                                                           const float *__restrict__ rbound, long long n, int l)
@@ -147,11 +167,13 @@ __global__ __launch_bounds__(BLOCK) void sel_hist_kernel(const float4 *__restric
 	const long long j0 = (m * i0) / n, j1 = (m * ilast) / n;
 	uint32_t pfx[2] = {0, 0}, kmin[2] = {0, 0};
 	int shl[2] = {0, 0};
+	float lo[2] = {0.f, 0.f}, scale[2] = {0.f, 0.f};
 	for (int jj = 0; jj < 2; ++jj)
 		if (j0 + jj <= j1)
 		{
 			pfx[jj] = resolve_before<PASS, BLOCK>(hist, nodes, n, l, j0 + jj, i0, sh).prefix;   // uniform over the block
-			key_window(lbound, rbound, sd_l, l, j0 + jj, kmin[jj], shl[jj]);
+			if (LIN) lin_window(lbound, rbound, sd_l, l, j0 + jj, lo[jj], scale[jj]);
+			else key_window(lbound, rbound, sd_l, l, j0 + jj, kmin[jj], shl[jj]);
 		}
 	__syncthreads();
 	const long long split = j1 > j0 ? range_start(n, j1, m) : n;
@@ -163,7 +185,8 @@ __global__ __launch_bounds__(BLOCK) void sel_hist_kernel(const float4 *__restric
 		if (i < n)
 		{
 			const int jj = i >= split ? 1 : 0;
-			const uint32_t key = (ordered_bits(axis_of(p[e], sd[jj])) - kmin[jj]) << shl[jj];
+			const float x = axis_of(p[e], sd[jj]);
+			const uint32_t key = LIN ? lin_key(x, lo[jj], scale[jj]) : (ordered_bits(x) - kmin[jj]) << shl[jj];
 			bool ok = true;
 			uint32_t d = key >> 21;
 			if (PASS == 1) { ok = (key >> 21) == pfx[jj]; d = (key >> 10) & 0x7FFu; }
@@ -322,26 +345,33 @@ __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__re
 	const long long split = j1 > j0 ? range_start(n, j1, m) : n;
 	// the third pass's histogram is descended here (see resolve_before): pivot back to the un-normalised ordered key
 	__shared__ uint32_t sh[BLOCK / 64 + 4];
-	// NP = 2: the select stopped after two passes -- piv is the 22-bit bucket of the pivot in the node's normalised key space
-	// (window kmin / shl), every element of that bucket is a candidate for the resolver; NP = 3: piv is the pivot itself
+	// NP = 2: the select stopped after two passes -- piv is the 22-bit bucket of the pivot under the box-linear bucket key,
+	// every element of that bucket is a candidate for the resolver; NP = 3: piv is the pivot itself (an ordered key)
 	constexpr bool EARLY = NP < 3;
 	constexpr int kDrop = 10;   // key bits below the bucket
-	uint32_t piv[2] = {0, 0}, all_left[2] = {0, 0}, kmin[2] = {0, 0};
-	int shl[2] = {0, 0};
+	uint32_t piv[2] = {0, 0}, all_left[2] = {0, 0};
+	float lo[2] = {0.f, 0.f}, scale[2] = {0.f, 0.f};
 	SelPivot pvs[2];
 	for (int jj = 0; jj < 2; ++jj)
 	{
 		pvs[jj] = SelPivot{0, 0, 0, 0};
 		if (j0 + jj <= j1)
 		{
-			key_window(lbound, rbound, sd_l, l, j0 + jj, kmin[jj], shl[jj]);
 			pvs[jj] = resolve_before<NP, BLOCK>(hist, nodes, n, l, j0 + jj, i0, sh);
-			if (!EARLY) pvs[jj].prefix = (pvs[jj].prefix >> shl[jj]) + kmin[jj];
+			if (EARLY) lin_window(lbound, rbound, sd_l, l, j0 + jj, lo[jj], scale[jj]);
+			else
+			{
+				// all passes done: back from the node's key window to the pivot as an ordered key
+				uint32_t kmin;
+				int shl;
+				key_window(lbound, rbound, sd_l, l, j0 + jj, kmin, shl);
+				pvs[jj].prefix = (pvs[jj].prefix >> shl) + kmin;
+			}
 			piv[jj] = pvs[jj].prefix;
 			all_left[jj] = !EARLY && pvs[jj].need == pvs[jj].neq;
 		}
 	}
-	if (j1 == j0) { piv[1] = piv[0]; all_left[1] = all_left[0]; kmin[1] = kmin[0]; shl[1] = shl[0]; }
+	if (j1 == j0) { piv[1] = piv[0]; all_left[1] = all_left[0]; lo[1] = lo[0]; scale[1] = scale[0]; }
 	const int sd[2] = {sd_l[j0], sd_l[j1]};
 	if (threadIdx.x < 2) mR[threadIdx.x] = 0xFFFFFFFFu;
 	// Destination slots.  The four output streams of the chunk (left / right of its one or two nodes) are filled in
@@ -365,7 +395,7 @@ __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__re
 		{
 			const int jj = i >= split ? 1 : 0;
 			const uint32_t key = ordered_bits(axis_of(p[e], sd[jj]));
-			const uint32_t cmp = EARLY ? ((key - kmin[jj]) << shl[jj]) >> kDrop : key;
+			const uint32_t cmp = EARLY ? lin_key(axis_of(p[e], sd[jj]), lo[jj], scale[jj]) >> kDrop : key;
 			if (cmp < piv[jj] || (cmp == piv[jj] && all_left[jj])) cat[e] = 2 * jj;
 			else if (cmp > piv[jj]) { cat[e] = 2 * jj + 1; tmin[jj] = key < tmin[jj] ? key : tmin[jj]; }
 			else
@@ -486,10 +516,10 @@ static void select_level_launch(nbco_ctx *c, int l, long long n, const float4 *p
 	hipStream_t st = c->stream;
 	constexpr int CHUNK = 8 * BLOCK;
 	const int gchunks = (int)((n + CHUNK - 1) / CHUNK);
-	hipLaunchKernelGGL((sel_hist_kernel<0, BLOCK>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l);
-	hipLaunchKernelGGL((sel_hist_kernel<1, BLOCK>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l);
+	hipLaunchKernelGGL((sel_hist_kernel<0, BLOCK, NP == 2>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l);
+	hipLaunchKernelGGL((sel_hist_kernel<1, BLOCK, NP == 2>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l);
 	if (NP >= 3)
-		hipLaunchKernelGGL((sel_hist_kernel<2, BLOCK>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l);
+		hipLaunchKernelGGL((sel_hist_kernel<2, BLOCK, false>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l);
 	hipLaunchKernelGGL((sel_partition_kernel<BLOCK, NP>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, unsort_in, pos_out, unsort_out, sd_l, nodes, ties, n, l,
 	                   lbound, rbound, splitdim, index, flag, (const uint32_t *)hist);
 }
@@ -497,16 +527,13 @@ static void select_level_launch(nbco_ctx *c, int l, long long n, const float4 *p
 int kd_select_level(nbco_ctx *c, int l, long long n, const float4 *pos_in, const int *unsort_in, float4 *pos_out, int *unsort_out,
                     float *lbound, float *rbound, int *splitdim, int *index, int *flag)
 {
-	// Two radix passes look at the first 22 bits of the key, spread over the node's box by the key window.  Ordered float
-	// bits are piecewise linear in the coordinate (every binade has 2^23 keys), so in a box that reaches down to ~0 the upper
-	// half of the box shares as few as 2^13 buckets: the pivot's bucket then holds up to node size / 2^14 elements, which the
-	// tie resolver orders exactly as long as they are at most kTieCap -- nodes of up to 2^19 particles stop after two passes
-	// (<= 32 candidates in that worst case, a handful normally), larger ones run the third.  (One pass is not enough even for
-	// 4096-particle nodes: a box that crosses zero keeps half its particles in 8 of the 2048 first-digit bins.)  A fuller
-	// bucket (tightly clustered input) raises the tie flag and the caller falls back to three passes everywhere
-	// (sel_three_pass), then to the sorting build.
+	// Two radix passes over a bucket key that is linear across the node's box (lin_key) leave the pivot's bucket with about
+	// node size / 2^22 elements times the density contrast inside the box; the tie resolver orders them exactly as long as
+	// they are at most kTieCap.  Nodes of up to 2^22 particles stop after two passes (a handful of candidates), larger ones
+	// run all three passes over the ordered float bits.  A fuller bucket (tightly clustered input) raises the tie flag and the
+	// caller falls back to three passes everywhere (sel_three_pass), then to the sorting build.
 	const long long node = n >> l;
-	const int np = (c->sel_three_pass || node > (1LL << 19)) ? 3 : 2;
+	const int np = (c->sel_three_pass || node > (1LL << 22)) ? 3 : 2;
 	const bool big = node >= 8 * kBlockBig;
 #define NBCO_SEL_ARGS c, l, n, pos_in, unsort_in, pos_out, unsort_out, lbound, rbound, splitdim, index, flag
 	if (big)
