@@ -31,6 +31,7 @@
 #include "fmm_tables.hpp"
 #include "k_p2p.hpp"
 #include <rocprim/rocprim.hpp>
+#include <chrono>
 #include <cmath>
 #include <algorithm>
 
@@ -1669,7 +1670,11 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		                        param, a, c->o.coll ? 1 : 0, n, L, own0, own_n));
 	}
 	// ---- now look at what the traversal reported (long finished: the GPU is busy with the work queued above) ----------
-	NBCO_HIP(hipEventSynchronize(c->ev_flags));
+	{
+		const auto t0 = std::chrono::steady_clock::now();
+		NBCO_HIP(hipEventSynchronize(c->ev_flags));
+		c->host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	}
 	const int *h = c->h_flags;
 	if (h[3] != 0)
 	{

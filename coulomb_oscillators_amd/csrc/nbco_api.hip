@@ -2,6 +2,8 @@
 // of compute_force (integrator.cuh:22-28 over main3.cu:47-69) and the symplectic integrators
 // (integrator.cuh:32-167).
 #include "nbco_internal.hpp"
+#include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <new>
 #include "fmm_tables.hpp"
@@ -154,6 +156,9 @@ int nbco_create(nbco_ctx **out, const nbco_opts *o)
 
 int nbco_destroy(nbco_ctx *c)
 {
+	if (c && getenv("NBCO_HOST_TIMING") && c->host_calls)
+		fprintf(stderr, "[nbco] nbco_integrate: %lld calls, %.1f us host time per call, of which %.1f us waiting for the traversal flags\n", c->host_calls,
+		        1e6 * c->host_call_s / c->host_calls, 1e6 * c->host_wait_s / c->host_calls);
 	if (!c) return NBCO_OK;
 	hipStreamSynchronize(c->stream);
 	DevBuf *bufs[] = {&c->pos4, &c->pos4_alt, &c->part, &c->small, &c->tmp3, &c->keys, &c->keys_alt, &c->idx, &c->idx_alt,
@@ -359,6 +364,12 @@ int nbco_integrate(nbco_ctx *c, int scheme, int kind, float *buf, long long n, c
                    int elastic)
 {
 	if (!c || !buf || !param || n <= 0) return c ? c->fail(NBCO_ERR_ARG, "nbco_integrate: bad arguments") : NBCO_ERR_ARG;
+	struct HostTimer
+	{
+		nbco_ctx *c;
+		std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+		~HostTimer() { c->host_call_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); ++c->host_calls; }
+	} host_timer{c};
 	float *x = buf, *v = buf + 3 * n, *a = buf + 6 * n;
 	const long long n3 = 3 * n;
 	const long double dt = dt_, scale = scale_;

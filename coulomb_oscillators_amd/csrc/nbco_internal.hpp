@@ -80,6 +80,8 @@ struct nbco_ctx
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	bool aux_pending = false;
 	long long perm_primed_n = -1;   // particle count for which both permutation buffers were last filled with valid indices
+	double host_wait_s = 0, host_call_s = 0;   // diagnostics (NBCO_HOST_TIMING): time blocked on the flags event / inside nbco_integrate
+	long long host_calls = 0;
 	bool aux_is_main = false;   // NBCO_AUX_SERIAL=1 (diagnostics): the second stream is the main stream
 	// traversal counts / flags land in pinned host memory; looked at after the rest of the evaluation is enqueued
 	int *h_flags = nullptr;
