@@ -20,7 +20,9 @@ template <int P, typename T> struct M2LBody;   // generic in the scalar type: fl
 
 #include "m2l_gen.inc"
 
-constexpr int kTargets = 8;   // target nodes per wave
+// target nodes per wave: a target has 9 list entries on average (BASELINE ball, p = 6), so 6 targets fill one 64-lane batch; with 8
+// most waves ran a second, nearly empty batch (M2L 96 -> 78 us, and the near-field kernel it overlaps finishes earlier)
+constexpr int kTargets = 6;
 
 template <int P, typename T>
 __global__ __launch_bounds__(64) void m2l_lane_kernel(const float4 *__restrict__ csz, const T *__restrict__ mpole,
