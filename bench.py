@@ -68,6 +68,33 @@ def measured_traffic(kernel):
     return None, None
 
 
+# ---- synthetic workload: the initial condition of main3.cu:629-692 (Gaussian ball, centred, RMS-normalised) --------------
+SIGMA_X = (0.003, 0.001, 0.01)      # main3.cu:244
+OMEGA0 = (1.095, 1.0, 1.0)          # main3.cu:241
+XI = 2e-6                           # main3.cu:240
+
+
+def gaussian_ball(n, seed):
+    """[pos | vel | acc] of n particles: normal deviates with sigma_x / sigma_u = omega0 * sigma_x per axis, centred and
+    rescaled to exactly those RMS values (initGA, main3.cu:230-245); numpy's generator, not the reference's RNG stream"""
+    rng = np.random.default_rng(seed)
+    sx = np.array(SIGMA_X, dtype=np.float32)
+    su = np.array(OMEGA0, dtype=np.float32) * sx
+    buf = np.zeros((3, n, 3), dtype=np.float32)
+    for k, sig in ((0, sx), (1, su)):
+        v = rng.standard_normal((n, 3), dtype=np.float32) * sig
+        v -= v.mean(axis=0, dtype=np.float64).astype(np.float32)
+        v *= sig / np.sqrt((v.astype(np.float64) ** 2).mean(axis=0)).astype(np.float32)
+        buf[k] = v
+    return buf
+
+
+def coulomb_params(n_system):
+    """par[] of main3.cu:685-692: {xi / N, 0, 0, omega0^2}"""
+    om = np.array(OMEGA0, dtype=np.float32)
+    return np.array([np.float32(XI) / np.float32(n_system), 0, 0, om[0] * om[0], om[1] * om[1], om[2] * om[2]], dtype=np.float32)
+
+
 def cpu_baseline(args, n):
     """The oracle (a port of the reference's multithreaded CPU path) on a bounded sample of the same workload."""
     from oracle import pyoracle as po
@@ -77,8 +104,8 @@ def cpu_baseline(args, n):
         cores = min(cores, len(os.sched_getaffinity(0)))
     except Exception:
         pass
-    buf = o.init_reference(n)
-    par = o.params(n)
+    buf = gaussian_ball(n, 20240807)        # the same state the GPU run starts from (rank 0)
+    par = coulomb_params(n)
     if args.workload == "fmm_kd":
         kind, kw = po.KIND_FMM_KD, dict(p=args.order, unsort=False, threads=cores)
         steps = args.cpu_steps
@@ -106,7 +133,6 @@ def main():
     import torch.distributed as dist
     from coulomb_oscillators_amd import (Engine, EVAL_DIRECT, EVAL_FMM_KDTREE, EVAL_FMM_TRACELESS, INTEG_LEAPFROG, DomainRun,
                                          TorchComm)
-    from oracle import pyoracle as po          # initial conditions only (reference RNG stream) + cpu_baseline
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -124,11 +150,10 @@ def main():
     n = args.n
     sharded = world > 1 and args.workload == "fmm_kd"
     n_sys = world * n if sharded else n          # particles of ONE physical system
-    o = po.Oracle(np.float32)
-    # every rank draws n particles of the same Gaussian ball from its own segment of the reference's RNG stream;
-    # sharded run: their union is the N = world * n system, the kd-domains are cut by the first partition
-    buf = o.init_reference(n, discard=po.REF_DISCARD + 7919 * rank)
-    par = o.params(n_sys)
+    # every rank draws n particles of the same Gaussian ball with its own seed; sharded run: their union is the
+    # N = world * n system, the kd-domains are cut by the first partition
+    buf = gaussian_ball(n, 20240807 + rank)
+    par = coulomb_params(n_sys)
     d = torch.from_numpy(buf).cuda()
     prm = torch.from_numpy(par).cuda()
 
