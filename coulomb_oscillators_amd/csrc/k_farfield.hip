@@ -74,6 +74,13 @@ __device__ inline void centre_of(int m0, int m1, const float *c0, const float *c
 		c[a] = s / ft;
 	}
 }
+// centre + squared box diagonal (kd_size, fmm_cart3_kdtree.cuh:395-399), the record the traversal reads
+__device__ inline float4 node_csz(const float *__restrict__ lbound, const float *__restrict__ rbound, int i, float cx, float cy, float cz)
+{
+	const float dx = rbound[3 * i] - lbound[3 * i], dy = rbound[3 * i + 1] - lbound[3 * i + 1], dz = rbound[3 * i + 2] - lbound[3 * i + 2];
+	const float sz = dx * dx + dy * dy + dz * dz;
+	return make_float4(cx, cy, cz, sz);
+}
 #pragma clang fp contract(on)
 
 template <int P, bool AGENT>
@@ -124,7 +131,8 @@ __global__ __launch_bounds__(kBlock) void m2m_gen_kernel(float *center, float *m
 // ---- centres pass: centre of charge + multiplicity of every internal node (fmm_cart3_kdtree.cuh:339-348) -------------
 // One workgroup per subtree of <= kBlock leaves walks its levels in LDS; a second launch (one workgroup) does the levels
 // above the subtree roots.
-__global__ __launch_bounds__(kBlock) void kd_centres_kernel(float *center, int *mult, int L, int lr)
+__global__ __launch_bounds__(kBlock) void kd_centres_kernel(float *center, int *mult, int L, int lr, const float *__restrict__ lbound,
+                                                            const float *__restrict__ rbound, float4 *__restrict__ csz, int leaves_too)
 {
 	__shared__ float Cl[kBlock][3];
 	__shared__ int Nl[kBlock];
@@ -135,6 +143,7 @@ __global__ __launch_bounds__(kBlock) void kd_centres_kernel(float *center, int *
 		const int leaf = (1 << L) - 1 + b * nl + t;
 		Cl[t][0] = center[3 * leaf]; Cl[t][1] = center[3 * leaf + 1]; Cl[t][2] = center[3 * leaf + 2];
 		Nl[t] = mult[leaf];
+		if (leaves_too) csz[leaf] = node_csz(lbound, rbound, leaf, Cl[t][0], Cl[t][1], Cl[t][2]);
 	}
 	__syncthreads();
 	for (int l = L - 1; l >= lr; --l)
@@ -155,11 +164,13 @@ __global__ __launch_bounds__(kBlock) void kd_centres_kernel(float *center, int *
 			Nl[t] = m0 + m1;
 			center[3 * node] = c[0]; center[3 * node + 1] = c[1]; center[3 * node + 2] = c[2];
 			mult[node] = m0 + m1;
+			csz[node] = node_csz(lbound, rbound, node, c[0], c[1], c[2]);
 		}
 		__syncthreads();
 	}
 }
-__global__ __launch_bounds__(kBlock) void kd_centres_top_kernel(float *center, int *mult, int ltop)
+__global__ __launch_bounds__(kBlock) void kd_centres_top_kernel(float *center, int *mult, int ltop, const float *__restrict__ lbound,
+                                                                const float *__restrict__ rbound, float4 *__restrict__ csz)
 {
 	__shared__ float Cl[kBlock][3];
 	__shared__ int Nl[kBlock];
@@ -187,6 +198,7 @@ __global__ __launch_bounds__(kBlock) void kd_centres_top_kernel(float *center, i
 			Nl[t] = mlt;
 			center[3 * node] = c[0]; center[3 * node + 1] = c[1]; center[3 * node + 2] = c[2];
 			mult[node] = mlt;
+			csz[node] = node_csz(lbound, rbound, node, c[0], c[1], c[2]);
 		}
 		__syncthreads();
 	}
@@ -492,17 +504,25 @@ static int run_l2p(nbco_ctx *c, const float4 *pos, const float *center, const fl
 	}
 
 // centres + multiplicities of all internal nodes from the leaves' (2 launches up to 16 levels)
-int launch_kd_centres(nbco_ctx *c, float *center, int *mult, int L)
+int launch_kd_centres(nbco_ctx *c, float *center, int *mult, int L, const float *lbound, const float *rbound, float4 *csz)
 {
-	if (L == 0) return NBCO_OK;
+	if (L == 0)
+	{
+		// a one-node tree: only the traversal record of the root is missing
+		hipLaunchKernelGGL(kd_centres_kernel, dim3(1), dim3(kBlock), 0, c->stream, center, mult, 0, 0, lbound, rbound, csz, 1);
+		NBCO_HIP(hipGetLastError());
+		return NBCO_OK;
+	}
 	// a workgroup walks 8 levels (256 leaves of its subtree in LDS), the last launch (one workgroup) the <= 8 levels left:
-	// trees deeper than 16 levels (N > 2M at p = 6) take one more subtree stage per 8 levels
+	// trees deeper than 16 levels (N > 2M at p = 6) take one more subtree stage per 8 levels.  Every node's traversal
+	// record (centre + squared box diagonal) is written along the way.
 	int bottom = L;
 	for (; bottom > 16; bottom -= 8)
-		hipLaunchKernelGGL(kd_centres_kernel, dim3(1 << (bottom - 8)), dim3(kBlock), 0, c->stream, center, mult, bottom, bottom - 8);
+		hipLaunchKernelGGL(kd_centres_kernel, dim3(1 << (bottom - 8)), dim3(kBlock), 0, c->stream, center, mult, bottom, bottom - 8, lbound, rbound, csz,
+		                   bottom == L ? 1 : 0);
 	const int lr = bottom > 8 ? bottom - 8 : 0;
-	hipLaunchKernelGGL(kd_centres_kernel, dim3(1 << lr), dim3(kBlock), 0, c->stream, center, mult, bottom, lr);
-	if (lr > 0) hipLaunchKernelGGL(kd_centres_top_kernel, dim3(1), dim3(kBlock), 0, c->stream, center, mult, lr - 1);
+	hipLaunchKernelGGL(kd_centres_kernel, dim3(1 << lr), dim3(kBlock), 0, c->stream, center, mult, bottom, lr, lbound, rbound, csz, bottom == L ? 1 : 0);
+	if (lr > 0) hipLaunchKernelGGL(kd_centres_top_kernel, dim3(1), dim3(kBlock), 0, c->stream, center, mult, lr - 1, lbound, rbound, csz);
 	NBCO_HIP(hipGetLastError());
 	return NBCO_OK;
 }

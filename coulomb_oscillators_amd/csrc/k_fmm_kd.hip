@@ -266,17 +266,6 @@ __device__ inline void parent_centre(const TreeView &t, int k, float c[3], int &
 	}
 }
 
-// centre + squared box diagonal (kd_size, fmm_cart3_kdtree.cuh:395-399) packed for the traversal
-__global__ __launch_bounds__(kBlock) void kd_csz_kernel(TreeView t)
-{
-	for (int i = blockIdx.x * kBlock + threadIdx.x; i < t.ntot; i += gridDim.x * kBlock)
-	{
-		float dx = t.rbound[3 * i] - t.lbound[3 * i], dy = t.rbound[3 * i + 1] - t.lbound[3 * i + 1], dz = t.rbound[3 * i + 2] - t.lbound[3 * i + 2];
-		float sz = dx * dx + dy * dy + dz * dz;
-		t.csz[i] = make_float4(t.center[3 * i], t.center[3 * i + 1], t.center[3 * i + 2], sz);
-	}
-}
-
 struct AdmTab   // M = (max(mult1,mult2)/N)^(1/(3p+6)) evaluated on the host with libm powf per level
 {
 	int lo[32];
@@ -802,6 +791,24 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 		pos_out[s0 + i] = make_float4(px[i], py[i], pz[i], 0.f);
 		unsort_out[s0 + i] = orig[i];
 	}
+	// multiplicity and centre of charge of this slice's leaves, while their particles are still in LDS (what kd_leaf_kernel
+	// does from HBM: sequential sum in particle order, one division)
+	{
+		const int sl = t.L - l0;
+		const long long mL = 1LL << t.L, jb = j0 << sl;
+		for (int i = tid; i < (1 << sl); i += kSubT)
+		{
+			const long long jc = jb + i;
+			const long long st = (jc == 0) ? 0 : (n * jc - 1) / mL + 1, en = (n * (jc + 1) - 1) / mL + 1;
+			const int mlt = (int)(en - st);
+			float sx = 0.f, sy = 0.f, sz = 0.f;
+			for (int k = (int)(st - s0); k < (int)(en - s0); ++k) { sx = sx + px[k]; sy = sy + py[k]; sz = sz + pz[k]; }
+			if (mlt > 0) { const float d = (float)mlt; sx = sx / d; sy = sy / d; sz = sz / d; }
+			const int node = kd_beg(t.L) + (int)jc;
+			t.mult[node] = mlt;
+			t.center[3 * node] = sx; t.center[3 * node + 1] = sy; t.center[3 * node + 2] = sz;
+		}
+	}
 }
 
 #pragma clang fp contract(fast)
@@ -1009,10 +1016,15 @@ __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab
 	}
 }
 
-__global__ void traverse_init_kernel(int2 *frontier, int *counters, int nctr, int *tctr)
+// start state of a traversal: the root pair in the frontier, counters cleared, and (all workgroups) the per-target entry
+// counts of both lists cleared
+__global__ __launch_bounds__(kBlock) void traverse_init_kernel(int2 *frontier, int *counters, int nctr, int *tctr, unsigned *__restrict__ list_cnt,
+                                                               long long words)
 {
-	for (int i = threadIdx.x; i < nctr; i += blockDim.x) counters[i] = 0;
-	for (int i = threadIdx.x; i < kTcInts; i += blockDim.x) tctr[i] = 0;
+	for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < words; i += (long long)gridDim.x * kBlock) list_cnt[i] = 0u;
+	if (blockIdx.x != 0) return;
+	for (int i = threadIdx.x; i < nctr; i += kBlock) counters[i] = 0;
+	for (int i = threadIdx.x; i < kTcInts; i += kBlock) tctr[i] = 0;
 	__syncthreads();
 	if (threadIdx.x == 0) { frontier[0] = make_int2(0, 0); tctr[kTcFrontier] = 1; }
 }
@@ -1503,15 +1515,14 @@ static int kd_build_upward(nbco_ctx *c, const float *p, long long n, int L, cons
 			NBCO_TRY(launch_pack4(c, pos, p, n));
 			NBCO_HIP(hipMemsetAsync(c->counters.as<int>() + 110, 0, sizeof(int), st));
 		}
-		hipLaunchKernelGGL(kd_leaf_kernel, dim3(grid1d(nleaf)), dim3(kBlock), 0, st, tv, pos, n);
+		if (!rebuild) hipLaunchKernelGGL(kd_leaf_kernel, dim3(grid1d(nleaf)), dim3(kBlock), 0, st, tv, pos, n);   // (a rebuild's subtree kernel did it)
 		NBCO_HIP(hipGetLastError());
 	}
 	if (stage == 1) return NBCO_OK;
 	{
 		// centres of all nodes first (2 launches): that is all the traversal needs, so the multipole chain
 		// (P2M + M2M, generated register-resident bodies of k_farfield.hip) runs beside it on the second stream
-		NBCO_TRY(launch_kd_centres(c, tv.center, tv.mult, L));
-		hipLaunchKernelGGL(kd_csz_kernel, dim3(grid1d(ntot)), dim3(kBlock), 0, st, tv);
+		NBCO_TRY(launch_kd_centres(c, tv.center, tv.mult, L, tv.lbound, tv.rbound, tv.csz));
 		NBCO_TRY(c->fork_aux());
 		StreamScope on_aux(c, c->aux);
 		PhaseScope ph(c, NBCO_PH_P2M_M2M);
@@ -1568,12 +1579,13 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		// per-target entry counters / fill cursors of the two directed lists: [cnt_p2p | fill_p2p | cnt_m2l | fill_m2l]
 		const size_t np_ = (size_t)nleaf + 2, nm_ = (size_t)ntot + 2;
 		NBCO_TRY(c->reserve(c->list_cnt, sizeof(unsigned) * 2 * (np_ + nm_)));
-		NBCO_HIP(hipMemsetAsync(c->list_cnt.ptr, 0, sizeof(unsigned) * 2 * (np_ + nm_), st));
+
 		unsigned *cnt_p2p = c->list_cnt.as<unsigned>(), *cnt_m2l = cnt_p2p + 2 * np_;
 		NBCO_TRY(c->reserve(c->trav_ctr, sizeof(int) * 1024));
 		static_assert(kTcInts <= 1024, "traversal counter block");
 		int *tctr = c->trav_ctr.as<int>();
-		hipLaunchKernelGGL(traverse_init_kernel, dim3(1), dim3(128), 0, st, fa, ctr, 104, tctr);   // [110] is the selection-build flag
+		hipLaunchKernelGGL(traverse_init_kernel, dim3(grid1d((long long)(2 * (np_ + nm_)) / 8 + 1, 256)), dim3(kBlock), 0, st, fa, ctr, 104, tctr,
+		                   c->list_cnt.as<unsigned>(), (long long)(2 * (np_ + nm_)));   // counters[110] is the selection-build flag
 		const int iters = L + 2;   // every launch performs two traversal steps (2L + 1 are needed)
 		for (int it = 0; it < iters; ++it)
 		{

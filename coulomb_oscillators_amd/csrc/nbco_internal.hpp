@@ -216,7 +216,7 @@ int kd_select_level(nbco_ctx *c, int l, long long n, const float4 *pos_in, const
                     float *lbound, float *rbound, int *splitdim, int *index, int *flag);
 // k_farfield.hip
 int launch_upward_gen(nbco_ctx *c, int P, const float4 *pos, float *center, float *mpole, int *mult, const int *index, int L, int write_geom);
-int launch_kd_centres(nbco_ctx *c, float *center, int *mult, int L);
+int launch_kd_centres(nbco_ctx *c, float *center, int *mult, int L, const float *lbound, const float *rbound, float4 *csz);
 int launch_downward_gen(nbco_ctx *c, int P, const float *center, float *local, int L, int dom_d, int dom_g);
 int launch_m2m_top_gen(nbco_ctx *c, int P, float *center, float *mpole, int *mult, int ltop);
 int launch_l2p_gen(nbco_ctx *c, int P, const float4 *pos, const float *center, const float *local, const float4 *near, const int *chunk_off,
