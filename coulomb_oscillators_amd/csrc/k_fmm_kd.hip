@@ -1094,10 +1094,9 @@ __global__ __launch_bounds__(kBlock) void list_fill_kernel(const int2 *__restric
 	}
 }
 
-// one wave per target: rank sort of its source range (distinct keys) in registers up to 256 entries (the BASELINE ball
-// has 17 on average, 254 at most), a bitonic network in LDS up to kSegLds, and beyond that (not seen in practice) a
-// rank sort straight from global memory
-constexpr int kSegLds = 512;
+// one wave per target: rank sort of its source range (distinct keys) in registers up to 512 entries (the BASELINE ball
+// has 17 on average, 254..300 at most; a bitonic network in LDS for the 257..512 class cost 30 us of a 45 us kernel), and
+// beyond that (wide opening radii) a rank sort straight from global memory
 #ifndef NBCO_P2P_CHUNK
 #define NBCO_P2P_CHUNK 16
 #endif
@@ -1118,7 +1117,6 @@ __global__ __launch_bounds__(kBlock) void list_segsort_kernel(const int *__restr
 			desc[slot] = make_int2(leaf_index[src], leaf_mult[src]);
 		}
 	};
-	__shared__ uint64_t stage[kBlock / 64][kSegLds];
 	const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	// ranges of up to 64 * J entries: every lane keeps J entries in registers and ranks them against all entries of the
 	// range, which are broadcast one by one with v_readlane (an SGPR lane index: the loop is scalar, no LDS or memory
@@ -1157,31 +1155,7 @@ __global__ __launch_bounds__(kBlock) void list_segsort_kernel(const int *__restr
 		if (cnt <= 64) rank_in_registers(std::integral_constant<int, 1>{}, s, cnt);
 		else if (cnt <= 128) rank_in_registers(std::integral_constant<int, 2>{}, s, cnt);
 		else if (cnt <= 256) rank_in_registers(std::integral_constant<int, 4>{}, s, cnt);
-		else if (cnt <= kSegLds)
-		{
-			// bitonic network over the next power of two (padded with the largest key): ~45 wave-synchronous LDS steps at
-			// most, where ranking every key against every other would be cnt^2 / 64 dependent LDS reads per lane
-			int n2 = 128;
-			while (n2 < cnt) n2 <<= 1;
-			for (int i = lane; i < n2; i += 64) stage[wv][i] = i < cnt ? in[s + i] : ~0ull;
-			wave_lds_sync();
-			for (int k = 2; k <= n2; k <<= 1)
-				for (int j = k >> 1; j > 0; j >>= 1)
-				{
-					for (int i = lane; i < n2; i += 64)
-					{
-						const int x = i ^ j;
-						if (x > i)
-						{
-							const uint64_t ka = stage[wv][i], kb = stage[wv][x];
-							if ((ka > kb) == ((i & k) == 0)) { stage[wv][i] = kb; stage[wv][x] = ka; }
-						}
-					}
-					wave_lds_sync();
-				}
-			for (int i = lane; i < cnt; i += 64) emit(s + i, stage[wv][i]);
-			wave_lds_sync();
-		}
+		else if (cnt <= 512) rank_in_registers(std::integral_constant<int, 8>{}, s, cnt);
 		else
 		{
 			for (int i = lane; i < cnt; i += 64)
