@@ -437,12 +437,12 @@ static int run_upward(nbco_ctx *c, const float4 *pos, float *center, float *mpol
 
 // levels ltop .. 0 of a tree whose level ltop + 1 is already in place (the levels above the kd-domains)
 template <int P>
-static int run_m2m_top(nbco_ctx *c, float *center, float *mpole, int *mult, int ltop)
+static int run_m2m_top(nbco_ctx *c, float *center, float *mpole, int *mult, int ltop, int write_geom)
 {
 	constexpr int offM = P * (P + 1) * (P + 2) / 6, offS = offM > 0 ? offM : 1;
 	if ((1 << ltop) > kTopNodes || (size_t)(1 << ltop) * (offS + 4) * sizeof(float) > 60 * 1024)
 		return c->fail(NBCO_ERR_UNSUPPORTED, "launch_m2m_top_gen: too many top levels");
-	hipLaunchKernelGGL(m2m_top_kernel<P>, dim3(1), dim3(kTopNodes), (size_t)(1 << ltop) * (offS + 4) * sizeof(float), c->stream, center, mpole, mult, ltop, 1);
+	hipLaunchKernelGGL(m2m_top_kernel<P>, dim3(1), dim3(kTopNodes), (size_t)(1 << ltop) * (offS + 4) * sizeof(float), c->stream, center, mpole, mult, ltop, write_geom);
 	NBCO_HIP(hipGetLastError());
 	return NBCO_OK;
 }
@@ -534,9 +534,19 @@ int launch_upward_gen(nbco_ctx *c, int P, const float4 *pos, float *center, floa
 #undef CALL
 }
 
-int launch_m2m_top_gen(nbco_ctx *c, int P, float *center, float *mpole, int *mult, int ltop)
+// centres, multiplicities and traversal records of levels ltop .. 0 from level ltop + 1 (the levels above the kd-domains; the
+// boxes of those levels come from the partition step)
+int launch_kd_centres_top(nbco_ctx *c, float *center, int *mult, int ltop, const float *lbound, const float *rbound, float4 *csz)
 {
-#define CALL(PP) run_m2m_top<PP>(c, center, mpole, mult, ltop)
+	if ((1 << ltop) > kBlock) return c->fail(NBCO_ERR_UNSUPPORTED, "launch_kd_centres_top: too many top levels");
+	hipLaunchKernelGGL(kd_centres_top_kernel, dim3(1), dim3(kBlock), 0, c->stream, center, mult, ltop, lbound, rbound, csz);
+	NBCO_HIP(hipGetLastError());
+	return NBCO_OK;
+}
+
+int launch_m2m_top_gen(nbco_ctx *c, int P, float *center, float *mpole, int *mult, int ltop, int write_geom)
+{
+#define CALL(PP) run_m2m_top<PP>(c, center, mpole, mult, ltop, write_geom)
 	NBCO_DISPATCH_P(P, CALL)
 #undef CALL
 }

@@ -32,6 +32,7 @@
 #include "k_p2p.hpp"
 #include <rocprim/rocprim.hpp>
 #include <chrono>
+#include <functional>
 #include <cmath>
 #include <algorithm>
 
@@ -1490,13 +1491,13 @@ static int kd_build_upward(nbco_ctx *c, const float *p, long long n, int L, cons
 			NBCO_HIP(hipMemsetAsync(c->counters.as<int>() + 110, 0, sizeof(int), st));
 		}
 		if (!rebuild) hipLaunchKernelGGL(kd_leaf_kernel, dim3(grid1d(nleaf)), dim3(kBlock), 0, st, tv, pos, n);   // (a rebuild's subtree kernel did it)
+		// centres and traversal records of all nodes first (2 launches): that is all the traversal needs, so the multipole
+		// chain (P2M + M2M, generated register-resident bodies of k_farfield.hip) runs beside it on the second stream
+		NBCO_TRY(launch_kd_centres(c, tv.center, tv.mult, L, tv.lbound, tv.rbound, tv.csz));
 		NBCO_HIP(hipGetLastError());
 	}
 	if (stage == 1) return NBCO_OK;
 	{
-		// centres of all nodes first (2 launches): that is all the traversal needs, so the multipole chain
-		// (P2M + M2M, generated register-resident bodies of k_farfield.hip) runs beside it on the second stream
-		NBCO_TRY(launch_kd_centres(c, tv.center, tv.mult, L, tv.lbound, tv.rbound, tv.csz));
 		NBCO_TRY(c->fork_aux());
 		StreamScope on_aux(c, c->aux);
 		PhaseScope ph(c, NBCO_PH_P2M_M2M);
@@ -1515,8 +1516,11 @@ struct KdCounts
 	int sel_overflow = 0;
 };
 
+// phase 0: everything; 1: up to and including the traversal (its flags on their way to the host); 2: the rest, for a tree on
+// which phase 1 has run.  `pre_far` (phase 0 / 2) is called on the second stream ahead of the far-field chain: the sharded
+// evaluation unpacks the multipoles there, which arrive after the traversal has started.
 static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long long n, int mlt_max, const Dom dm, long long own0, long long own_n,
-                       const int *unsort, float *a, const float *param, KdCounts &out)
+                       const int *unsort, float *a, const float *param, KdCounts &out, int phase = 0, const std::function<int()> *pre_far = nullptr)
 {
 	const int P = c->o.fmm_order;
 	const int L = tv.L, ntot = tv.ntot, nleaf = 1 << L, beg = kd_beg(L);
@@ -1536,6 +1540,7 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 	c->list_cap = cap;
 
 	// ---- dual tree traversal ----------------------------------------------------------------------------
+	if (phase != 2)
 	{
 		PhaseScope ph(c, NBCO_PH_TRAVERSE);
 		AdmTab tab;
@@ -1579,6 +1584,7 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		NBCO_HIP(hipMemcpyAsync(c->h_flags + 3, ctr + 110, sizeof(int), hipMemcpyDeviceToHost, st));
 		NBCO_HIP(hipEventRecord(c->ev_flags, st));
 	}
+	if (phase == 1) return NBCO_OK;
 	const int *p2p_pref = c->trav_ctr.as<int>() + kTcP2PPref, *m2l_pref = c->trav_ctr.as<int>() + kTcM2LPref;
 	const int shift = L + 1;
 	// capacities (the traversal never writes more than `cap` pairs) and launch-size hints from the previous evaluation
@@ -1618,6 +1624,7 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		NBCO_TRY(c->fork_wait());
 		{
 			StreamScope on_aux(c, c->aux);
+			if (pre_far) NBCO_TRY((*pre_far)());
 			unsigned *cm = c->list_cnt.as<unsigned>() + 2 * ((size_t)nleaf + 2);
 			NBCO_TRY(build_directed_list(c, c->m2l_list.as<int2>(), c->m2l_list.as<int2>() + cap, m2l_pref, capR, nm2l_hint, 0, 0, 0, ntot, shift, cm,
 			                             c->m2l_start.as<int>(), c->m2l_keys.as<uint64_t>(), c->m2l_keys_alt.as<uint64_t>(), c->scan_tmp_aux));
@@ -1756,9 +1763,11 @@ __host__ __device__ inline int dist_global_id(int k, int r, int d)
 	return (1 << (l + d)) - 1 + (r << l) + (k - ((1 << l) - 1));
 }
 
-// gathered blocks [csz ntot_loc float4 | mpole ntot_loc * offM float] x G  ->  global node arrays (levels >= d)
+// gathered per-rank blocks -> global node arrays (levels >= d).  `blocks` points at rank 0's data, consecutive ranks are
+// block_bytes apart: the traversal records (float4 csz[ntot_loc]) and the multipoles (float mpole[ntot_loc][offM]) either
+// travel in one block per rank (nbco_dist_finish) or in two all-gathers (nbco_dist_finish_traverse / _rest)
 __global__ __launch_bounds__(kBlock) void dist_unpack_nodes_kernel(TreeView t, const char *__restrict__ blocks, size_t block_bytes, int ntot_loc, int G,
-                                                                   int d, int offM)
+                                                                   int d)
 {
 	const long long total = (long long)G * ntot_loc;
 	for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock)
@@ -1779,7 +1788,7 @@ __global__ __launch_bounds__(kBlock) void dist_unpack_mpole_kernel(TreeView t, c
 		const int r = (int)(i / per);
 		const long long e = i % per;
 		const int k = (int)(e / offM), comp = (int)(e % offM);
-		const float *src = reinterpret_cast<const float *>(blocks + (size_t)r * block_bytes + sizeof(float4) * (size_t)ntot_loc);
+		const float *src = reinterpret_cast<const float *>(blocks + (size_t)r * block_bytes);
 		t.mpole[(size_t)dist_global_id(k, r, d) * offM + comp] = src[e];
 	}
 }
@@ -1795,18 +1804,6 @@ __global__ __launch_bounds__(kBlock) void dist_ranges_kernel(TreeView t, long lo
 		t.mult[j] = (int)(end - start);
 	}
 }
-#pragma clang fp contract(off)
-// centre + squared box diagonal of the levels above the domains (boxes from the partition step)
-__global__ void dist_top_csz_kernel(TreeView t, const float *__restrict__ lb, const float *__restrict__ rb, int ntop)
-{
-	for (int i = threadIdx.x; i < ntop; i += blockDim.x)
-	{
-		float dx = rb[3 * i] - lb[3 * i], dy = rb[3 * i + 1] - lb[3 * i + 1], dz = rb[3 * i + 2] - lb[3 * i + 2];
-		float sz = dx * dx + dy * dy + dz * dz;
-		t.csz[i] = make_float4(t.center[3 * i], t.center[3 * i + 1], t.center[3 * i + 2], sz);
-	}
-}
-#pragma clang fp contract(on)
 __global__ void dist_root6_kernel(const float *__restrict__ lb, const float *__restrict__ rb, int node, float *__restrict__ out6)
 {
 	if (threadIdx.x < 3) { out6[threadIdx.x] = lb[3 * node + threadIdx.x]; out6[3 + threadIdx.x] = rb[3 * node + threadIdx.x]; }
@@ -1846,7 +1843,9 @@ int kd_dist_layout(nbco_ctx *c, long long n_global, int world, int rank, nbco_di
 	out->world = world; out->rank = rank; out->d = d; out->L = L; out->L_local = L - d; out->order = P;
 	out->ntot_local = (1 << (L - d + 1)) - 1;
 	out->n_global = n_global; out->n_local = n_global / world;
-	out->nodes_bytes = (long long)out->ntot_local * (long long)(sizeof(float4) + sizeof(float) * sym_off(P));
+	out->csz_bytes = (long long)out->ntot_local * (long long)sizeof(float4);
+	out->mpole_bytes = (long long)out->ntot_local * (long long)(sizeof(float) * sym_off(P));
+	out->nodes_bytes = out->csz_bytes + out->mpole_bytes;
 	out->pos_bytes = (long long)out->n_local * (long long)sizeof(float4);
 	return NBCO_OK;
 }
@@ -1897,7 +1896,9 @@ int kd_dist_partition(nbco_ctx *c, const float *state_all, long long n_global, i
 // stage 1 (pos_send != null): subtree build, tree-ordered positions into pos_send; stage 2 (nodes_send != null): upward
 // pass, node block into nodes_send.  Both pointers: the whole local stage.  The split lets the caller start the all-gather
 // of the positions while the multipoles are still being computed.
-int kd_dist_local(nbco_ctx *c, float *buf_local, long long n_local, void *nodes_send, void *pos_send)
+// csz_send / mpole_send: the two halves of the node block on their own (the traversal records are known after the build,
+// ahead of the multipoles)
+int kd_dist_local(nbco_ctx *c, float *buf_local, long long n_local, void *nodes_send, void *pos_send, void *csz_send, void *mpole_send)
 {
 	if (!c->dist.partitioned || n_local != c->dist.n_local)
 		return c->fail(NBCO_ERR_ARG, "nbco_dist_local: call nbco_dist_partition first (and pass its local particle count)");
@@ -1928,57 +1929,101 @@ int kd_dist_local(nbco_ctx *c, float *buf_local, long long n_local, void *nodes_
 		}
 		c->dist.rebuilt = rebuild;
 		NBCO_HIP(hipMemcpyAsync(pos_send, c->pos4.ptr, sizeof(float4) * (size_t)n_local, hipMemcpyDeviceToDevice, st));
+		if (csz_send) NBCO_HIP(hipMemcpyAsync(csz_send, c->kd.csz, sizeof(float4) * (size_t)lay.ntot_local, hipMemcpyDeviceToDevice, st));
 		c->dist.build_done = true;
 	}
-	if (nodes_send)
+	if (nodes_send || mpole_send)
 	{
 		if (!c->dist.build_done) return c->fail(NBCO_ERR_ARG, "nbco_dist_local_upward: the build stage has not run");
 		c->dist.build_done = false;
 		NBCO_TRY(kd_build_upward(c, buf_local, n_local, lay.L_local, nullptr, rebuild, 2));
 		NBCO_TRY(c->join_aux());   // the multipoles are about to leave the GPU
 		const int offM = sym_off(lay.order);
-		NBCO_HIP(hipMemcpyAsync(nodes_send, c->kd.csz, sizeof(float4) * (size_t)lay.ntot_local, hipMemcpyDeviceToDevice, st));
-		NBCO_HIP(hipMemcpyAsync((char *)nodes_send + sizeof(float4) * (size_t)lay.ntot_local, c->kd.mpole, sizeof(float) * (size_t)lay.ntot_local * offM,
-		                        hipMemcpyDeviceToDevice, st));
+		if (nodes_send)
+		{
+			NBCO_HIP(hipMemcpyAsync(nodes_send, c->kd.csz, sizeof(float4) * (size_t)lay.ntot_local, hipMemcpyDeviceToDevice, st));
+			mpole_send = (char *)nodes_send + sizeof(float4) * (size_t)lay.ntot_local;
+		}
+		NBCO_HIP(hipMemcpyAsync(mpole_send, c->kd.mpole, sizeof(float) * (size_t)lay.ntot_local * offM, hipMemcpyDeviceToDevice, st));
 		c->dist.local_done = true;
 	}
 	return NBCO_OK;
 }
 
-int kd_dist_finish(nbco_ctx *c, const void *nodes_all, const void *pos_all, float *buf_local, float *a_local, const float *param)
+// The global tree of a sharded evaluation: node arrays carved from dist_tree; ranges from evalBox's rule.
+static int dist_global_tree(nbco_ctx *c, const nbco_dist_layout &lay, KdTreeDev &g)
 {
-	if (!c->dist.local_done) return c->fail(NBCO_ERR_ARG, "nbco_dist_finish: call nbco_dist_local first");
-	c->dist.local_done = false;
+	const int L = lay.L, P = lay.order, ntot = (1 << (L + 1)) - 1;
+	NBCO_TRY(kd_carve(c, c->dist_tree, g, ntot, sym_off(P), tl_off(P + 1)));
+	g.L = L; g.ntot = ntot; g.order = P; g.n = lay.n_global; g.mlt_max = (int)((lay.n_global - 1) / (1LL << L) + 1);
+	return NBCO_OK;
+}
+
+// First half of the finish stage: needs the traversal records and the positions of all domains, not the multipoles.
+// csz_blocks points at rank 0's records, consecutive ranks are csz_stride bytes apart.
+static int dist_finish_traverse(nbco_ctx *c, const char *csz_blocks, size_t csz_stride, const void *pos_all)
+{
+	if (!c->dist.local_done && !c->dist.build_done) return c->fail(NBCO_ERR_ARG, "nbco_dist_finish: call nbco_dist_local first");
 	nbco_dist_layout lay;
 	NBCO_TRY(kd_dist_layout(c, c->dist.n_global, c->dist.world, c->dist.rank, &lay));
-	const int d = lay.d, G = lay.world, L = lay.L, P = lay.order;
-	const int ntot = (1 << (L + 1)) - 1, ntop = (1 << (d + 1)) - 1;
-	const int offM = sym_off(P), offL = tl_off(P + 1);
-	const long long N = lay.n_global, nl = lay.n_local;
+	const int d = lay.d, G = lay.world;
+	const int ntot = (1 << (lay.L + 1)) - 1, ntop = (1 << (d + 1)) - 1;
 	hipStream_t st = c->stream;
 	KdTreeDev g;
-	NBCO_TRY(kd_carve(c, c->dist_tree, g, ntot, offM, offL));
-	g.L = L; g.ntot = ntot; g.order = P; g.n = N; g.mlt_max = (int)((N - 1) / (1LL << L) + 1);
+	NBCO_TRY(dist_global_tree(c, lay, g));
 	TreeView tv = view_of(g);
 	{
 		PhaseScope ph(c, NBCO_PH_P2M_M2M);
-		hipLaunchKernelGGL(dist_ranges_kernel, dim3(grid1d(ntot)), dim3(kBlock), 0, st, tv, N);
-		hipLaunchKernelGGL(dist_unpack_nodes_kernel, dim3(grid1d((long long)G * lay.ntot_local)), dim3(kBlock), 0, st, tv, (const char *)nodes_all,
-		                   (size_t)lay.nodes_bytes, lay.ntot_local, G, d, offM);
-		if (offM > 0)
-			hipLaunchKernelGGL(dist_unpack_mpole_kernel, dim3(grid1d((long long)G * lay.ntot_local * offM)), dim3(kBlock), 0, st, tv,
-			                   (const char *)nodes_all, (size_t)lay.nodes_bytes, lay.ntot_local, G, d, offM);
+		hipLaunchKernelGGL(dist_ranges_kernel, dim3(grid1d(ntot)), dim3(kBlock), 0, st, tv, lay.n_global);
+		hipLaunchKernelGGL(dist_unpack_nodes_kernel, dim3(grid1d((long long)G * lay.ntot_local)), dim3(kBlock), 0, st, tv, csz_blocks, csz_stride,
+		                   lay.ntot_local, G, d);
 		if (d > 0)
 		{
-			NBCO_TRY(launch_m2m_top_gen(c, P, tv.center, tv.mpole, tv.mult, d - 1));
+			// centres, multiplicities and traversal records of the d levels above the domains (boxes from the partition step)
 			TopView top = top_view(c, ntop);
-			hipLaunchKernelGGL(dist_top_csz_kernel, dim3(1), dim3(64), 0, st, tv, (const float *)top.lbound, (const float *)top.rbound, (1 << d) - 1);
+			NBCO_TRY(launch_kd_centres_top(c, tv.center, tv.mult, d - 1, top.lbound, top.rbound, tv.csz));
 		}
 		NBCO_HIP(hipGetLastError());
 	}
 	KdCounts cnt;
 	const Dom dm{d, lay.rank};
-	NBCO_TRY(kd_interact(c, tv, (const float4 *)pos_all, N, g.mlt_max, dm, (long long)lay.rank * nl, nl, c->unsort.as<int>(), a_local, param, cnt));
+	NBCO_TRY(kd_interact(c, tv, (const float4 *)pos_all, lay.n_global, g.mlt_max, dm, (long long)lay.rank * lay.n_local, lay.n_local,
+	                     c->unsort.as<int>(), nullptr, nullptr, cnt, 1));
+	c->dist.pos_all = pos_all;
+	c->dist.traversed = true;
+	return NBCO_OK;
+}
+
+// Second half: multipoles of all domains (rank 0's at mp_blocks, consecutive ranks mp_stride bytes apart), lists, near and far
+// field, L2P for the own particles.
+static int dist_finish_rest(nbco_ctx *c, const char *mp_blocks, size_t mp_stride, float *buf_local, float *a_local, const float *param)
+{
+	if (!c->dist.traversed || !c->dist.local_done) return c->fail(NBCO_ERR_ARG, "nbco_dist_finish_rest: the traversal half or the multipoles are missing");
+	c->dist.traversed = false;
+	c->dist.local_done = false;
+	c->dist.build_done = false;
+	nbco_dist_layout lay;
+	NBCO_TRY(kd_dist_layout(c, c->dist.n_global, c->dist.world, c->dist.rank, &lay));
+	const int d = lay.d, G = lay.world, L = lay.L, P = lay.order;
+	const int offM = sym_off(P);
+	const long long nl = lay.n_local;
+	KdTreeDev g;
+	NBCO_TRY(dist_global_tree(c, lay, g));
+	TreeView tv = view_of(g);
+	// on the second stream, ahead of the M2L list: multipoles into the global arrays, M2M for the levels above the domains
+	const std::function<int()> pre_far = [&]() -> int {
+		PhaseScope ph(c, NBCO_PH_P2M_M2M);
+		if (offM > 0)
+			hipLaunchKernelGGL(dist_unpack_mpole_kernel, dim3(grid1d((long long)G * lay.ntot_local * offM)), dim3(kBlock), 0, c->stream, tv, mp_blocks, mp_stride,
+			                   lay.ntot_local, G, d, offM);
+		if (d > 0) NBCO_TRY(launch_m2m_top_gen(c, P, tv.center, tv.mpole, tv.mult, d - 1, 0));
+		NBCO_HIP(hipGetLastError());
+		return NBCO_OK;
+	};
+	KdCounts cnt;
+	const Dom dm{d, lay.rank};
+	NBCO_TRY(kd_interact(c, tv, (const float4 *)c->dist.pos_all, lay.n_global, g.mlt_max, dm, (long long)lay.rank * nl, nl, c->unsort.as<int>(), a_local, param,
+	                     cnt, 2, &pre_far));
 	if (cnt.sel_overflow) return c->fail(NBCO_ERR_UNSUPPORTED, "nbco_dist_finish: unresolved tie overflow of the selection build");
 	if (c->dist.rebuilt) NBCO_TRY(kd_finish_order(c, buf_local, nl));
 	c->tree_valid = true;
@@ -1986,10 +2031,32 @@ int kd_dist_finish(nbco_ctx *c, const void *nodes_all, const void *pos_all, floa
 	c->tree_order = P;
 	c->eval_counter += 1;
 	nbco_kd_info &info = c->info;
-	info.L = L; info.ntot = ntot; info.order = P; info.mlt_max = g.mlt_max; info.n = N;
+	info.L = L; info.ntot = g.ntot; info.order = P; info.mlt_max = g.mlt_max; info.n = lay.n_global;
 	info.p2p_pairs = cnt.np2p; info.m2l_pairs = cnt.nm2l; info.rebuilt = c->dist.rebuilt ? 1 : 0;
 	info.directed_p2p = -1;
 	return NBCO_OK;
+}
+
+int kd_dist_finish_traverse(nbco_ctx *c, const void *csz_all, const void *pos_all)
+{
+	nbco_dist_layout lay;
+	NBCO_TRY(kd_dist_layout(c, c->dist.n_global, c->dist.world, c->dist.rank, &lay));
+	return dist_finish_traverse(c, (const char *)csz_all, (size_t)lay.csz_bytes, pos_all);
+}
+int kd_dist_finish_rest(nbco_ctx *c, const void *mpole_all, float *buf_local, float *a_local, const float *param)
+{
+	nbco_dist_layout lay;
+	NBCO_TRY(kd_dist_layout(c, c->dist.n_global, c->dist.world, c->dist.rank, &lay));
+	return dist_finish_rest(c, (const char *)mpole_all, (size_t)lay.mpole_bytes, buf_local, a_local, param);
+}
+// both halves on node blocks gathered as a whole (per rank: records, then multipoles)
+int kd_dist_finish(nbco_ctx *c, const void *nodes_all, const void *pos_all, float *buf_local, float *a_local, const float *param)
+{
+	if (!c->dist.local_done) return c->fail(NBCO_ERR_ARG, "nbco_dist_finish: call nbco_dist_local first");
+	nbco_dist_layout lay;
+	NBCO_TRY(kd_dist_layout(c, c->dist.n_global, c->dist.world, c->dist.rank, &lay));
+	NBCO_TRY(dist_finish_traverse(c, (const char *)nodes_all, (size_t)lay.nodes_bytes, pos_all));
+	return dist_finish_rest(c, (const char *)nodes_all + lay.csz_bytes, (size_t)lay.nodes_bytes, buf_local, a_local, param);
 }
 
 // directed pair interactions of the last evaluation (nbco_kd_get_info): sum over the sorted P2P entries

@@ -325,6 +325,29 @@ int nbco_dist_local_upward(nbco_ctx *c, float *buf_local, long long n_local, voi
 	NBCO_TRY(kd_dist_local(c, buf_local, n_local, nodes_send, nullptr));
 	return maybe_sync(c);
 }
+int nbco_dist_local_geom(nbco_ctx *c, float *buf_local, long long n_local, void *pos_send, void *csz_send)
+{
+	if (!c || !buf_local || !pos_send || !csz_send) return c ? c->fail(NBCO_ERR_ARG, "nbco_dist_local_geom: null pointer") : NBCO_ERR_ARG;
+	NBCO_TRY(kd_dist_local(c, buf_local, n_local, nullptr, pos_send, csz_send, nullptr));
+	return maybe_sync(c);
+}
+int nbco_dist_local_mpole(nbco_ctx *c, float *buf_local, long long n_local, void *mpole_send)
+{
+	if (!c || !buf_local || !mpole_send) return c ? c->fail(NBCO_ERR_ARG, "nbco_dist_local_mpole: null pointer") : NBCO_ERR_ARG;
+	NBCO_TRY(kd_dist_local(c, buf_local, n_local, nullptr, nullptr, nullptr, mpole_send));
+	return maybe_sync(c);
+}
+int nbco_dist_finish_traverse(nbco_ctx *c, const void *csz_all, const void *pos_all)
+{
+	if (!c || !csz_all || !pos_all) return c ? c->fail(NBCO_ERR_ARG, "nbco_dist_finish_traverse: null pointer") : NBCO_ERR_ARG;
+	return kd_dist_finish_traverse(c, csz_all, pos_all);   // (never syncs: its point is to leave the stream busy)
+}
+int nbco_dist_finish_rest(nbco_ctx *c, const void *mpole_all, float *buf_local, float *a_local, const float *param)
+{
+	if (!c || !mpole_all || !buf_local || !a_local) return c ? c->fail(NBCO_ERR_ARG, "nbco_dist_finish_rest: null pointer") : NBCO_ERR_ARG;
+	NBCO_TRY(kd_dist_finish_rest(c, mpole_all, buf_local, a_local, param));
+	return maybe_sync(c);
+}
 int nbco_dist_finish(nbco_ctx *c, const void *nodes_all, const void *pos_all, float *buf_local, float *a_local, const float *param)
 {
 	if (!c || !nodes_all || !pos_all || !buf_local || !a_local) return c ? c->fail(NBCO_ERR_ARG, "nbco_dist_finish: null pointer") : NBCO_ERR_ARG;

@@ -125,7 +125,8 @@ struct nbco_ctx
 	{
 		int world = 0, rank = 0, d = 0, L = 0;
 		long long n_global = 0, n_local = 0;
-		bool partitioned = false, build_done = false, local_done = false, rebuilt = false;
+		bool partitioned = false, build_done = false, local_done = false, rebuilt = false, traversed = false;
+		const void *pos_all = nullptr;   // gathered positions, between the two halves of the finish stage
 	} dist;
 	bool sel_three_pass = false;            // set after the first tie / bucket overflow: three radix passes per select
 	bool force_sort_build = false;          // set after the second: use the sorting build from then on
@@ -208,8 +209,11 @@ int oct_copy_out(nbco_ctx *c, int which, void *host_dst, long long host_bytes);
 // multi-GPU kd-domain sharding (k_fmm_kd.hip)
 int kd_dist_layout(nbco_ctx *c, long long n_global, int world, int rank, nbco_dist_layout *out);
 int kd_dist_partition(nbco_ctx *c, const float *state_all, long long n_global, int world, int rank, float *state_local);
-int kd_dist_local(nbco_ctx *c, float *buf_local, long long n_local, void *nodes_send, void *pos_send);
+int kd_dist_local(nbco_ctx *c, float *buf_local, long long n_local, void *nodes_send, void *pos_send, void *csz_send = nullptr,
+                  void *mpole_send = nullptr);
 int kd_dist_finish(nbco_ctx *c, const void *nodes_all, const void *pos_all, float *buf_local, float *a_local, const float *param);
+int kd_dist_finish_traverse(nbco_ctx *c, const void *csz_all, const void *pos_all);
+int kd_dist_finish_rest(nbco_ctx *c, const void *mpole_all, float *buf_local, float *a_local, const float *param);
 // k_kdselect.hip
 int kd_select_begin(nbco_ctx *c, int l0, bool zero = true, long long *words_a = nullptr, long long *words_b = nullptr);
 int kd_select_level(nbco_ctx *c, int l, long long n, const float4 *pos_in, const int *unsort_in, float4 *pos_out, int *unsort_out,
@@ -218,7 +222,8 @@ int kd_select_level(nbco_ctx *c, int l, long long n, const float4 *pos_in, const
 int launch_upward_gen(nbco_ctx *c, int P, const float4 *pos, float *center, float *mpole, int *mult, const int *index, int L, int write_geom);
 int launch_kd_centres(nbco_ctx *c, float *center, int *mult, int L, const float *lbound, const float *rbound, float4 *csz);
 int launch_downward_gen(nbco_ctx *c, int P, const float *center, float *local, int L, int dom_d, int dom_g);
-int launch_m2m_top_gen(nbco_ctx *c, int P, float *center, float *mpole, int *mult, int ltop);
+int launch_m2m_top_gen(nbco_ctx *c, int P, float *center, float *mpole, int *mult, int ltop, int write_geom);
+int launch_kd_centres_top(nbco_ctx *c, float *center, int *mult, int ltop, const float *lbound, const float *rbound, float4 *csz);
 int launch_l2p_gen(nbco_ctx *c, int P, const float4 *pos, const float *center, const float *local, const float4 *near, const int *chunk_off,
                    const int *index, int mlt_max, const int *unsort, int scatter, const float *param, float *a, int have_near, long long n, int L,
                    long long own0, long long own_n);

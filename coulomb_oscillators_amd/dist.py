@@ -12,9 +12,10 @@ One process per GPU::
     run.partition(pos_mine, vel_mine)          # rebalance: every `rebalance` steps
     run.leapfrog(param, dt)                    # or run.force(param)
 
-The exchange per evaluation is one all-gather of the node block (csz + multipoles of the domain's subtree)
-and one of the tree-ordered positions; forces need no reduction because cross-domain pairs are evaluated
-one-directionally on the owner of the target.
+The exchange per evaluation is an all-gather of the tree-ordered positions and of the node block (csz + multipoles
+of the domain's subtree), the latter in two stages: the traversal records leave with the positions, the multipoles
+follow under the traversal.  Forces need no reduction because cross-domain pairs are evaluated one-directionally on
+the owner of the target.
 """
 import torch
 
@@ -106,6 +107,10 @@ class DomainRun:
         self.pos_send = torch.empty(int(self.lay.pos_bytes), dtype=u8, device=self.device)
         self.nodes_all = torch.empty(G * int(self.lay.nodes_bytes), dtype=u8, device=self.device)
         self.pos_all = torch.empty(G * int(self.lay.pos_bytes), dtype=u8, device=self.device)
+        # the node block in two parts (views of the same buffers): traversal records / multipoles
+        self.csz_bytes = int(getattr(self.lay, "csz_bytes", 0))
+        self.split = self.csz_bytes > 0 and all(hasattr(engine, m) for m in ("dist_local_geom", "dist_local_mpole", "dist_finish_traverse",
+                                                                             "dist_finish_rest")) and hasattr(comm, "all_gather_start")
         self.evals = 0
 
     # views of the local state
@@ -152,6 +157,27 @@ class DomainRun:
     def force(self, param=None, elastic=True):
         if self.rebalance > 0 and self.evals >= self.rebalance:
             self.partition()
+        if self.split:
+            # Three all-gathers, each started as soon as its data exists: positions + traversal records after the subtree
+            # build, multipoles after the upward pass.  The traversal (which needs no multipoles) is enqueued behind the
+            # first two; the multipoles -- 224 of the 240 bytes per node at order 6 -- travel under it.
+            cb, G = self.csz_bytes, self.world
+            csz_send, mp_send = self.nodes_send[:cb], self.nodes_send[cb:]
+            csz_all, mp_all = self.nodes_all[: G * cb], self.nodes_all[G * cb:]
+            self.eng.dist_local_geom(self.buf, self.n_local, self.pos_send, csz_send)
+            h_pos = self.comm.all_gather_start(self.pos_all, self.pos_send)
+            h_csz = self.comm.all_gather_start(csz_all, csz_send)
+            self.eng.dist_local_mpole(self.buf, self.n_local, mp_send)
+            h_mp = self.comm.all_gather_start(mp_all, mp_send)
+            h_pos.wait()
+            h_csz.wait()
+            self.eng.dist_finish_traverse(csz_all, self.pos_all)
+            h_mp.wait()
+            self.eng.dist_finish_rest(mp_all, self.buf, self.acc, param)
+            if elastic and param is not None:
+                self.eng.add_elastic(self.pos, self.acc, self.n_local, param[3:])
+            self.evals += 1
+            return
         if hasattr(self.eng, "dist_local_build") and hasattr(self.comm, "all_gather_start"):
             # the positions travel while the multipoles are still being computed
             self.eng.dist_local_build(self.buf, self.n_local, self.pos_send)
@@ -218,12 +244,36 @@ class LoopbackWorld:
             r.eng.dist_partition(r.state_all, r.n_global, r.world, r.rank, r.buf)
             r.evals = 0
 
-    def force(self, param=None, elastic=True):
-        for r in self.runs:
-            r.local()
-        nodes = torch.cat([r.nodes_send for r in self.runs])
-        pos = torch.cat([r.pos_send for r in self.runs])
-        for r in self.runs:
-            r.nodes_all.copy_(nodes)
+    def force(self, param=None, elastic=True, split=None):
+        """split=None: the two-stage exchange (records, then multipoles) when the engines offer it; False: one node block"""
+        runs = self.runs
+        if split is None:
+            split = all(hasattr(r.eng, "dist_finish_traverse") and r.csz_bytes > 0 for r in runs)
+        if not split:
+            for r in runs:
+                r.local()
+            nodes = torch.cat([r.nodes_send for r in runs])
+            pos = torch.cat([r.pos_send for r in runs])
+            for r in runs:
+                r.nodes_all.copy_(nodes)
+                r.pos_all.copy_(pos)
+                r.finish(param, elastic)
+            return
+        cb, G = runs[0].csz_bytes, self.G
+        for r in runs:
+            r.eng.dist_local_geom(r.buf, r.n_local, r.pos_send, r.nodes_send[:cb])
+        pos = torch.cat([r.pos_send for r in runs])
+        csz = torch.cat([r.nodes_send[:cb] for r in runs])
+        for r in runs:
+            r.eng.dist_local_mpole(r.buf, r.n_local, r.nodes_send[cb:])
+        mp = torch.cat([r.nodes_send[cb:] for r in runs])
+        for r in runs:
             r.pos_all.copy_(pos)
-            r.finish(param, elastic)
+            r.nodes_all[: G * cb].copy_(csz)
+            r.eng.dist_finish_traverse(r.nodes_all[: G * cb], r.pos_all)
+        for r in runs:
+            r.nodes_all[G * cb:].copy_(mp)
+            r.eng.dist_finish_rest(r.nodes_all[G * cb:], r.buf, r.acc, param)
+            if elastic and param is not None:
+                r.eng.add_elastic(r.pos, r.acc, r.n_local, param[3:])
+            r.evals += 1

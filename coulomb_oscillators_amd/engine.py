@@ -52,7 +52,8 @@ OCT_FIELDS = {"mult": 0, "index": 1, "center4": 2, "mpole": 3, "local": 4, "keys
 class DistLayout(C.Structure):
     _fields_ = [("world", C.c_int), ("rank", C.c_int), ("d", C.c_int), ("L", C.c_int), ("L_local", C.c_int),
                 ("ntot_local", C.c_int), ("order", C.c_int), ("n_global", C.c_longlong), ("n_local", C.c_longlong),
-                ("nodes_bytes", C.c_longlong), ("pos_bytes", C.c_longlong)]
+                ("nodes_bytes", C.c_longlong), ("pos_bytes", C.c_longlong), ("csz_bytes", C.c_longlong),
+                ("mpole_bytes", C.c_longlong)]
 
 
 def lib_path():
@@ -115,6 +116,10 @@ def _load():
         "nbco_dist_local_build": [P, P, LL, P],
         "nbco_dist_local_upward": [P, P, LL, P],
         "nbco_dist_finish": [P, P, P, P, P, P],
+        "nbco_dist_local_geom": [P, P, LL, P, P],
+        "nbco_dist_local_mpole": [P, P, LL, P],
+        "nbco_dist_finish_traverse": [P, P, P],
+        "nbco_dist_finish_rest": [P, P, P, P, P],
         "nbco_profile_enable": [P, I],
         "nbco_profile_reset": [P],
         "nbco_profile_get": [P, I, C.POINTER(D), C.POINTER(LL)],
@@ -269,6 +274,19 @@ class Engine:
 
     def dist_local_upward(self, buf_local, n_local, nodes_send):
         self._chk(self.lib.nbco_dist_local_upward(self.ctx, _ptr(buf_local), n_local, _ptr(nodes_send)))
+
+    # the same evaluation with the node block in two all-gathers (traversal records first, multipoles later)
+    def dist_local_geom(self, buf_local, n_local, pos_send, csz_send):
+        self._chk(self.lib.nbco_dist_local_geom(self.ctx, _ptr(buf_local), n_local, _ptr(pos_send), _ptr(csz_send)))
+
+    def dist_local_mpole(self, buf_local, n_local, mpole_send):
+        self._chk(self.lib.nbco_dist_local_mpole(self.ctx, _ptr(buf_local), n_local, _ptr(mpole_send)))
+
+    def dist_finish_traverse(self, csz_all, pos_all):
+        self._chk(self.lib.nbco_dist_finish_traverse(self.ctx, _ptr(csz_all), _ptr(pos_all)))
+
+    def dist_finish_rest(self, mpole_all, buf_local, a_local, param=None):
+        self._chk(self.lib.nbco_dist_finish_rest(self.ctx, _ptr(mpole_all), _ptr(buf_local), _ptr(a_local), _ptr(param)))
 
     def dist_finish(self, nodes_all, pos_all, buf_local, a_local, param=None):
         self._chk(self.lib.nbco_dist_finish(self.ctx, _ptr(nodes_all), _ptr(pos_all), _ptr(buf_local), _ptr(a_local), _ptr(param)))

@@ -200,6 +200,8 @@ typedef struct nbco_dist_layout {
 	long long n_global, n_local;
 	long long nodes_bytes; /* per-rank node block: float4 csz[ntot_local], float mpole[ntot_local][offM] */
 	long long pos_bytes;   /* per-rank position block: float4[n_local], tree order */
+	long long csz_bytes;   /* the two parts of the node block on their own: traversal records (centre + squared box */
+	long long mpole_bytes; /* diagonal) of the subtree's nodes, and their multipoles; csz_bytes + mpole_bytes = nodes_bytes */
 } nbco_dist_layout;
 int nbco_dist_layout_query(nbco_ctx *c, long long n_global, int world, int rank, nbco_dist_layout *out);
 int nbco_dist_partition(nbco_ctx *c, const float *state_all, long long n_global, int world, int rank, float *state_local);
@@ -210,6 +212,18 @@ int nbco_dist_local_build(nbco_ctx *c, float *buf_local, long long n_local, void
 int nbco_dist_local_upward(nbco_ctx *c, float *buf_local, long long n_local, void *nodes_send);
 int nbco_dist_finish(nbco_ctx *c, const void *nodes_all, const void *pos_all, float *buf_local, float *a_local,
                      const float *param);
+/* The same evaluation with the node block travelling in two all-gathers, so that the multipoles (224 of the 240 bytes per
+ * node at order 6) are on the wire while the GPUs traverse:
+ *   _local_geom        subtree build; fills pos_send (pos_bytes) and csz_send (csz_bytes)     -> all-gather both
+ *   _local_mpole       upward pass; fills mpole_send (mpole_bytes)                            -> all-gather
+ *   _finish_traverse   needs csz_all / pos_all (world x the blocks, rank order): global tree geometry + dual traversal;
+ *                      returns with the work enqueued, pos_all must stay valid until _finish_rest has run
+ *   _finish_rest       needs mpole_all: lists, near and far field, L2P -> a_local, buf_local as nbco_dist_finish
+ * Results are identical to nbco_dist_local + nbco_dist_finish. */
+int nbco_dist_local_geom(nbco_ctx *c, float *buf_local, long long n_local, void *pos_send, void *csz_send);
+int nbco_dist_local_mpole(nbco_ctx *c, float *buf_local, long long n_local, void *mpole_send);
+int nbco_dist_finish_traverse(nbco_ctx *c, const void *csz_all, const void *pos_all);
+int nbco_dist_finish_rest(nbco_ctx *c, const void *mpole_all, float *buf_local, float *a_local, const float *param);
 
 /* ---- per-phase device timing (HIP events on the context's stream) ---------------------------- */
 enum {

@@ -104,6 +104,52 @@ class NumpyDomainEngine:
         a.numpy().reshape(n, 3)[:] -= p.numpy().reshape(n, 3) * kk
 
 
+class NumpySplitEngine(NumpyDomainEngine):
+    """the same evaluation through the two-stage exchange of include/nbco.h (nbco_dist_local_geom / _local_mpole /
+    _finish_traverse / _finish_rest): the node block travels as [rank, n_local, 0, 0] first and [sum x, sum y, sum z, 0]
+    behind the traversal half"""
+
+    def dist_layout(self, n_global, world, rank):
+        lay = super().dist_layout(n_global, world, rank)
+        lay.csz_bytes, lay.mpole_bytes = 16, 16
+        assert lay.nodes_bytes == lay.csz_bytes + lay.mpole_bytes
+        return lay
+
+    def dist_local_geom(self, buf, n_local, pos_send, csz_send):
+        self.calls.append("geom")
+        p = buf.numpy()[:3 * n_local].reshape(n_local, 3)
+        csz_send.numpy().view(np.float32)[:] = (self.lay.rank, n_local, 0, 0)
+        p4 = pos_send.numpy().view(np.float32).reshape(n_local, 4)
+        p4[:, :3] = p
+        p4[:, 3] = 0
+
+    def dist_local_mpole(self, buf, n_local, mpole_send):
+        self.calls.append("mpole")
+        p = buf.numpy()[:3 * n_local].reshape(n_local, 3)
+        m = mpole_send.numpy().view(np.float32)
+        m[:3] = p.sum(0)
+        m[3] = 0
+
+    def dist_finish_traverse(self, csz_all, pos_all):
+        self.calls.append("traverse")
+        G, nl = self.lay.world, self.lay.n_local
+        hdr = csz_all.numpy().view(np.float32).reshape(G, 4)
+        for r in range(G):
+            assert hdr[r, 0] == r and hdr[r, 1] == nl
+        self._pos_all = pos_all
+
+    def dist_finish_rest(self, mpole_all, buf, a_local, param=None):
+        self.calls.append("rest")
+        G, nl = self.lay.world, self.lay.n_local
+        nodes = torch.zeros(G * 4 * self.HDR, dtype=torch.uint8)
+        hdr = nodes.numpy().view(np.float32).reshape(G, self.HDR)
+        hdr[:, 0] = np.arange(G)
+        hdr[:, 1] = nl
+        hdr[:, 2:6] = mpole_all.numpy().view(np.float32).reshape(G, 4)
+        super().dist_finish(nodes, self._pos_all, buf, a_local, param)
+        self.calls.pop()   # (the "finish" recorded by the base class)
+
+
 def _system(n, seed=11):
     rng = np.random.default_rng(seed)
     pos = rng.standard_normal((n, 3)).astype(np.float32)
@@ -119,7 +165,7 @@ def _drive(run, par, steps, dt):
     return torch.cat([run.pos.view(-1, 3), run.vel.view(-1, 3), run.acc.view(-1, 3)], dim=1).numpy()
 
 
-def _worker(rank, world, port, n, steps, dt, rebalance, outdir):
+def _worker(rank, world, port, n, steps, dt, rebalance, outdir, split=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -127,9 +173,9 @@ def _worker(rank, world, port, n, steps, dt, rebalance, outdir):
     try:
         pos, vel, par = _system(n)
         nl = n // world
-        eng = NumpyDomainEngine()
+        eng = NumpySplitEngine() if split else NumpyDomainEngine()
         run = DomainRun(eng, n, TorchComm(), device=torch.device("cpu"), rebalance=rebalance)
-        assert (run.world, run.rank, run.n_local) == (world, rank, nl)
+        assert (run.world, run.rank, run.n_local) == (world, rank, nl) and run.split == split
         run.partition(torch.from_numpy(pos[rank * nl:(rank + 1) * nl]).reshape(-1), torch.from_numpy(vel[rank * nl:(rank + 1) * nl]).reshape(-1))
         res = _drive(run, torch.from_numpy(par), steps, dt)
         np.save(os.path.join(outdir, "rank%d.npy" % rank), res)
@@ -152,8 +198,8 @@ def _free_port():
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world", [2, 4])
-def test_domain_run_over_gloo_matches_single_process(world):
+@pytest.mark.parametrize("world,split", [(2, False), (4, False), (2, True), (4, True)])
+def test_domain_run_over_gloo_matches_single_process(world, split):
     import torch.multiprocessing as mp
     n, steps, dt, rebalance = 512, 5, 1e-2, 2
     pos, vel, par = _system(n)
@@ -161,7 +207,7 @@ def test_domain_run_over_gloo_matches_single_process(world):
     one.partition(torch.from_numpy(pos).reshape(-1), torch.from_numpy(vel).reshape(-1))
     ref = _drive(one, torch.from_numpy(par), steps, dt)
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, _free_port(), n, steps, dt, rebalance, d), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), n, steps, dt, rebalance, d, split), nprocs=world, join=True)
         got = np.concatenate([np.load(os.path.join(d, "rank%d.npy" % r)) for r in range(world)])
         calls = [open(os.path.join(d, "calls%d.txt" % r)).read().split() for r in range(world)]
         scal = [np.load(os.path.join(d, "scal%d.npy" % r)) for r in range(world)]
@@ -181,7 +227,7 @@ def test_domain_run_over_gloo_matches_single_process(world):
         if ev >= rebalance:
             want.append("partition")
             ev = 0
-        want += ["local", "finish"]
+        want += ["geom", "mpole", "traverse", "rest"] if split else ["local", "finish"]
         ev += 1
     assert all(c == want for c in calls), calls
 

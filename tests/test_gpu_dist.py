@@ -31,6 +31,23 @@ def single_gpu(n, pos, vel, par, **opts):
     return e, buf
 
 
+@pytest.mark.parametrize("n,G,p", [(32768, 2, 6), (40000, 8, 5)])
+def test_single_block_exchange_gives_the_same(oracle32, n, G, p):
+    """nbco_dist_local + nbco_dist_finish (one node block per rank) and the two-stage exchange are the same evaluation"""
+    import torch
+    pos, vel = make_state(oracle32, n, "clumps")
+    par = torch.from_numpy(oracle32.params(n)).cuda()
+    opts = dict(fmm_order=p, unsort=0, tree_steps=1)
+    out = []
+    for split in (False, None):
+        world = loopback(n, G, pos, vel, **opts)
+        for _ in range(2):
+            world.force(par, elastic=False, split=split)
+        torch.cuda.synchronize()
+        out.append(torch.cat([torch.cat([r.pos, r.vel, r.acc]) for r in world.runs]))
+    assert torch.equal(out[0], out[1])
+
+
 def loopback(n, G, pos, vel, **opts):
     import torch
     from coulomb_oscillators_amd import Engine, LoopbackWorld
@@ -46,6 +63,7 @@ def loopback(n, G, pos, vel, **opts):
 @pytest.mark.parametrize("n,G,p,kind", [(32768, 2, 6, "reference"), (32768, 4, 4, "reference"), (32768, 8, 6, "clumps"),
                                         (40000, 8, 5, "uniform"), (24576, 2, 3, "clumps"), (1 << 20, 4, 6, "reference"), (32768, 4, 10, "uniform")])
 def test_sharded_equals_single_gpu(oracle32, n, G, p, kind):
+    """(the exchange runs in its two-stage form: traversal records + positions first, multipoles behind the traversal)"""
     import torch
     pos, vel = make_state(oracle32, n, kind)
     par = torch.from_numpy(oracle32.params(n)).cuda()
