@@ -348,6 +348,13 @@ int nbco_dist_finish_rest(nbco_ctx *c, const void *mpole_all, float *buf_local, 
 	NBCO_TRY(kd_dist_finish_rest(c, mpole_all, buf_local, a_local, param));
 	return maybe_sync(c);
 }
+int nbco_aux_stream(nbco_ctx *c, void **stream_out)
+{
+	if (!c || !stream_out) return c ? c->fail(NBCO_ERR_ARG, "nbco_aux_stream: null pointer") : NBCO_ERR_ARG;
+	NBCO_TRY(c->fork_mark());   // creates the stream on first use (the event it records is harmless)
+	*stream_out = (void *)c->aux;
+	return NBCO_OK;
+}
 int nbco_dist_finish(nbco_ctx *c, const void *nodes_all, const void *pos_all, float *buf_local, float *a_local, const float *param)
 {
 	if (!c || !nodes_all || !pos_all || !buf_local || !a_local) return c ? c->fail(NBCO_ERR_ARG, "nbco_dist_finish: null pointer") : NBCO_ERR_ARG;

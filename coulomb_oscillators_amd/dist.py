@@ -172,7 +172,7 @@ class DomainRun:
             h_pos.wait()
             h_csz.wait()
             self.eng.dist_finish_traverse(csz_all, self.pos_all)
-            h_mp.wait()
+            self._wait_far_field(h_mp)
             self.eng.dist_finish_rest(mp_all, self.buf, self.acc, param)
             if elastic and param is not None:
                 self.eng.add_elastic(self.pos, self.acc, self.n_local, param[3:])
@@ -190,6 +190,24 @@ class DomainRun:
             self.local()
             self.exchange()
         self.finish(param, elastic)
+
+    def _wait_far_field(self, handle):
+        """Order the consumers of the gathered multipoles behind `handle`.  Only the engine's second stream reads them
+        (nbco_aux_stream), so that stream waits and the compute stream goes on with the near-field lists; engines without
+        one (CPU test doubles) or a world of one wait on the current stream."""
+        ext = getattr(self, "_aux_ext", None)
+        if ext is None:
+            ext = False
+            if hasattr(self.eng, "aux_stream") and self.device.type == "cuda" and not isinstance(handle, _Done):
+                ptr = self.eng.aux_stream()
+                if ptr:
+                    ext = torch.cuda.ExternalStream(ptr, device=self.device)
+            self._aux_ext = ext
+        if ext:
+            with torch.cuda.stream(ext):
+                handle.wait()
+        else:
+            handle.wait()
 
     # ---- reductions over all domains: a handful of scalars through an all-reduce (SURVEY 8(e)) -----------------
     def minmax(self):

@@ -120,6 +120,7 @@ def _load():
         "nbco_dist_local_mpole": [P, P, LL, P],
         "nbco_dist_finish_traverse": [P, P, P],
         "nbco_dist_finish_rest": [P, P, P, P, P],
+        "nbco_aux_stream": [P, C.POINTER(C.c_void_p)],
         "nbco_profile_enable": [P, I],
         "nbco_profile_reset": [P],
         "nbco_profile_get": [P, I, C.POINTER(D), C.POINTER(LL)],
@@ -287,6 +288,12 @@ class Engine:
 
     def dist_finish_rest(self, mpole_all, buf_local, a_local, param=None):
         self._chk(self.lib.nbco_dist_finish_rest(self.ctx, _ptr(mpole_all), _ptr(buf_local), _ptr(a_local), _ptr(param)))
+
+    def aux_stream(self):
+        """raw hipStream_t of the context's second stream (see nbco_aux_stream)"""
+        out = C.c_void_p()
+        self._chk(self.lib.nbco_aux_stream(self.ctx, C.byref(out)))
+        return out.value or 0
 
     def dist_finish(self, nodes_all, pos_all, buf_local, a_local, param=None):
         self._chk(self.lib.nbco_dist_finish(self.ctx, _ptr(nodes_all), _ptr(pos_all), _ptr(buf_local), _ptr(a_local), _ptr(param)))

@@ -224,6 +224,11 @@ int nbco_dist_local_geom(nbco_ctx *c, float *buf_local, long long n_local, void 
 int nbco_dist_local_mpole(nbco_ctx *c, float *buf_local, long long n_local, void *mpole_send);
 int nbco_dist_finish_traverse(nbco_ctx *c, const void *csz_all, const void *pos_all);
 int nbco_dist_finish_rest(nbco_ctx *c, const void *mpole_all, float *buf_local, float *a_local, const float *param);
+/* The context's second stream (hipStream_t), on which the far-field chain runs and which alone reads mpole_all in
+ * nbco_dist_finish_rest: a caller whose collective runs on its own stream can make THIS stream wait for the multipole
+ * all-gather (hipStreamWaitEvent before calling _finish_rest) instead of the compute stream, so that the near-field
+ * lists and the pair kernel do not wait for the multipoles either. */
+int nbco_aux_stream(nbco_ctx *c, void **stream_out);
 
 /* ---- per-phase device timing (HIP events on the context's stream) ---------------------------- */
 enum {

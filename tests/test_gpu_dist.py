@@ -48,6 +48,51 @@ def test_single_block_exchange_gives_the_same(oracle32, n, G, p):
     assert torch.equal(out[0], out[1])
 
 
+def test_far_field_waits_on_the_second_stream(oracle32):
+    """the multipoles may arrive after nbco_dist_finish_traverse has been enqueued, and only the context's second stream
+    (nbco_aux_stream) has to wait for them: emulate a late all-gather with a slow copy on a side stream, make the
+    second stream wait for it the way DomainRun._wait_far_field does, and compare with the plain evaluation"""
+    import torch
+    n, G, p = 32768, 2, 6
+    pos, vel = make_state(oracle32, n, "clumps")
+    par = torch.from_numpy(oracle32.params(n)).cuda()
+    opts = dict(fmm_order=p, unsort=0, tree_steps=1)
+    ref = loopback(n, G, pos, vel, **opts)
+    ref.force(par, elastic=False)
+    torch.cuda.synchronize()
+    want = torch.cat([torch.cat([r.pos, r.vel, r.acc]) for r in ref.runs])
+
+    world = loopback(n, G, pos, vel, **opts)
+    runs = world.runs
+    cb = runs[0].csz_bytes
+    for r in runs:
+        r.eng.dist_local_geom(r.buf, r.n_local, r.pos_send, r.nodes_send[:cb])
+    pos_all = torch.cat([r.pos_send for r in runs])
+    csz_all = torch.cat([r.nodes_send[:cb] for r in runs])
+    for r in runs:
+        r.eng.dist_local_mpole(r.buf, r.n_local, r.nodes_send[cb:])
+    mp_all = torch.cat([r.nodes_send[cb:] for r in runs])
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    for r in runs:
+        r.pos_all.copy_(pos_all)
+        r.nodes_all[: G * cb].copy_(csz_all)
+        r.nodes_all[G * cb:].zero_()                       # stale contents until the "gather" lands
+        r.eng.dist_finish_traverse(r.nodes_all[: G * cb], r.pos_all)
+        with torch.cuda.stream(side):
+            torch.cuda._sleep(40_000_000)                  # ~20 ms: far longer than the traversal
+            r.nodes_all[G * cb:].copy_(mp_all)
+            landed = torch.cuda.Event()
+            landed.record(side)
+        aux = torch.cuda.ExternalStream(r.eng.aux_stream())
+        with torch.cuda.stream(aux):
+            landed.wait()                                  # what Work.wait() of an asynchronous all-gather does
+        r.eng.dist_finish_rest(r.nodes_all[G * cb:], r.buf, r.acc, par)
+    torch.cuda.synchronize()
+    got = torch.cat([torch.cat([r.pos, r.vel, r.acc]) for r in runs])
+    assert torch.equal(got, want)
+
+
 def loopback(n, G, pos, vel, **opts):
     import torch
     from coulomb_oscillators_amd import Engine, LoopbackWorld
