@@ -1155,7 +1155,10 @@ __global__ __launch_bounds__(kBlock) void list_segsort_kernel(const int *__restr
 		const int s = __builtin_amdgcn_readfirstlane(start[t]), cnt = __builtin_amdgcn_readfirstlane(start[t + 1]) - s;
 		if (cnt <= 64) rank_in_registers(std::integral_constant<int, 1>{}, s, cnt);
 		else if (cnt <= 128) rank_in_registers(std::integral_constant<int, 2>{}, s, cnt);
+		else if (cnt <= 192) rank_in_registers(std::integral_constant<int, 3>{}, s, cnt);
 		else if (cnt <= 256) rank_in_registers(std::integral_constant<int, 4>{}, s, cnt);
+		else if (cnt <= 320) rank_in_registers(std::integral_constant<int, 5>{}, s, cnt);
+		else if (cnt <= 384) rank_in_registers(std::integral_constant<int, 6>{}, s, cnt);
 		else if (cnt <= 512) rank_in_registers(std::integral_constant<int, 8>{}, s, cnt);
 		else
 		{
