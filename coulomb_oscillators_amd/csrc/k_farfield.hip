@@ -83,51 +83,6 @@ __device__ inline float4 node_csz(const float *__restrict__ lbound, const float 
 }
 #pragma clang fp contract(on)
 
-template <int P, bool AGENT>
-__device__ inline void m2m_node(float *center, float *mpole, int *mult, int k, int write_geom)
-{
-	constexpr int offM = P * (P + 1) * (P + 2) / 6;
-	float c[3];
-	int mlt;
-	parent_centre<AGENT>(center, mult, k, c, mlt);
-	float A[offM > 0 ? offM : 1];
-#pragma unroll
-	for (int q = 0; q < (offM > 0 ? offM : 1); ++q) A[q] = 0.f;
-	if (P >= 3)
-	{
-		for (int ch = 0; ch < 2; ++ch)
-		{
-			const int child = 2 * k + 1 + ch;
-			float Mc[offM > 0 ? offM : 1];
-#pragma unroll
-			for (int q = 0; q < offM; ++q) Mc[q] = AGENT ? ld_agent(&mpole[(size_t)child * offM + q]) : mpole[(size_t)child * offM + q];
-			const float ccx = AGENT ? ld_agent(&center[3 * child]) : center[3 * child];
-			const float ccy = AGENT ? ld_agent(&center[3 * child + 1]) : center[3 * child + 1];
-			const float ccz = AGENT ? ld_agent(&center[3 * child + 2]) : center[3 * child + 2];
-			m2m_accum<P>(Mc, c[0] - ccx, c[1] - ccy, c[2] - ccz, A);
-		}
-	}
-	float *M = mpole + (size_t)k * offM;
-	if (offM > 0) M[0] = (float)mlt;
-	if (offM > 1) { M[1] = 0.f; M[2] = 0.f; M[3] = 0.f; }
-	m2m_store<P>(A, M);
-	if (write_geom)
-	{
-		center[3 * k] = c[0]; center[3 * k + 1] = c[1]; center[3 * k + 2] = c[2];
-		mult[k] = mlt;
-	}
-}
-
-// write_geom = 0: centres and multiplicities were produced by the centres pass below (the same arithmetic), which lets
-// the traversal start while the multipoles are still being shifted on a second stream
-template <int P>
-__global__ __launch_bounds__(kBlock) void m2m_gen_kernel(float *center, float *mpole, int *mult, int l, int write_geom)
-{
-	const int i = blockIdx.x * kBlock + threadIdx.x;
-	if (i >= (1 << l)) return;
-	m2m_node<P, false>(center, mpole, mult, (1 << l) - 1 + i, write_geom);
-}
-
 // ---- centres pass: centre of charge + multiplicity of every internal node (fmm_cart3_kdtree.cuh:339-348) -------------
 // One workgroup per subtree of <= kBlock leaves walks its levels in LDS; a second launch (one workgroup) does the levels
 // above the subtree roots.
@@ -204,21 +159,23 @@ __global__ __launch_bounds__(kBlock) void kd_centres_top_kernel(float *center, i
 	}
 }
 
-// levels ltop .. 0 in one workgroup.  The expansions, centres and multiplicities of the level just built stay
-// in LDS (node i of a level sits in slot i), so a level costs LDS latency instead of HBM round trips.
+// Levels ltop .. lroot of the subtrees hanging off level lroot, one workgroup per subtree (lroot = 0: the top of the tree in
+// one workgroup).  The expansions, centres and multiplicities of the level just built stay in LDS (node i of a subtree's
+// level sits in slot i), so a level costs LDS latency instead of a launch and HBM round trips.
 template <int P>
-__global__ __launch_bounds__(kTopNodes) void m2m_top_kernel(float *center, float *mpole, int *mult, int ltop, int write_geom)
+__global__ __launch_bounds__(kTopNodes) void m2m_top_kernel(float *center, float *mpole, int *mult, int ltop, int lroot, int write_geom)
 {
 	constexpr int offM = P * (P + 1) * (P + 2) / 6, offS = offM > 0 ? offM : 1;
 	extern __shared__ float lds[];
-	float *Ml = lds;                                  // [2^ltop][offS]
-	float *Cl = Ml + (size_t)(1 << ltop) * offS;      // [2^ltop][3]
-	int *Nl = (int *)(Cl + (size_t)(1 << ltop) * 3);  // [2^ltop]
+	const int width = 1 << (ltop - lroot);            // nodes of this subtree at level ltop
+	float *Ml = lds;                                  // [width][offS]
+	float *Cl = Ml + (size_t)width * offS;            // [width][3]
+	int *Nl = (int *)(Cl + (size_t)width * 3);        // [width]
 	const int t = threadIdx.x;
-	for (int l = ltop; l >= 0; --l)
+	for (int l = ltop; l >= lroot; --l)
 	{
-		const bool on = t < (1 << l);
-		const int k = (1 << l) - 1 + t;
+		const bool on = t < (1 << (l - lroot));
+		const int k = (1 << l) - 1 + ((int)blockIdx.x << (l - lroot)) + t;
 		float A[offS], c[3] = {0.f, 0.f, 0.f};
 		int mlt = 0;
 		if (on)
@@ -423,14 +380,17 @@ static int run_upward(nbco_ctx *c, const float4 *pos, float *center, float *mpol
 	hipLaunchKernelGGL(p2m_gen_kernel<P>, dim3(grid_for(nleaf)), dim3(kBlock), 0, c->stream, pos, (const float *)center, (const int *)mult, index,
 	                   mpole, beg, nleaf);
 	constexpr int offM = P * (P + 1) * (P + 2) / 6, offS = offM > 0 ? offM : 1;
-	int top = kTopNodes;
-	while (top > 1 && (size_t)top * (offS + 4) * sizeof(float) > 60 * 1024) top >>= 1;   // LDS budget of the fused top kernel
-	int l = L - 1;
-	for (; l >= 0 && (1 << l) > top; --l)
-		hipLaunchKernelGGL(m2m_gen_kernel<P>, dim3(grid_for(1 << l)), dim3(kBlock), 0, c->stream, center, mpole, mult, l, write_geom);
-	if (l >= 0)
-		hipLaunchKernelGGL(m2m_top_kernel<P>, dim3(1), dim3(kTopNodes), (size_t)(1 << l) * (offS + 4) * sizeof(float), c->stream, center, mpole, mult, l,
-		                   write_geom);
+	// a workgroup walks as many levels of its subtree as fit its LDS (up to 256 nodes at the bottom level: 8 levels at
+	// p <= 5, 7 at p = 6): two or three launches for the whole upward shift instead of one per level
+	int depth = 8;
+	while (depth > 0 && (size_t)(1 << depth) * (offS + 4) * sizeof(float) > 60 * 1024) --depth;
+	for (int l = L - 1; l >= 0;)
+	{
+		const int lroot = std::max(l - depth, 0), width = 1 << (l - lroot);
+		hipLaunchKernelGGL(m2m_top_kernel<P>, dim3(1 << lroot), dim3(std::max(64, width)), (size_t)width * (offS + 4) * sizeof(float), c->stream, center, mpole,
+		                   mult, l, lroot, write_geom);
+		l = lroot - 1;
+	}
 	NBCO_HIP(hipGetLastError());
 	return NBCO_OK;
 }
@@ -442,7 +402,8 @@ static int run_m2m_top(nbco_ctx *c, float *center, float *mpole, int *mult, int 
 	constexpr int offM = P * (P + 1) * (P + 2) / 6, offS = offM > 0 ? offM : 1;
 	if ((1 << ltop) > kTopNodes || (size_t)(1 << ltop) * (offS + 4) * sizeof(float) > 60 * 1024)
 		return c->fail(NBCO_ERR_UNSUPPORTED, "launch_m2m_top_gen: too many top levels");
-	hipLaunchKernelGGL(m2m_top_kernel<P>, dim3(1), dim3(kTopNodes), (size_t)(1 << ltop) * (offS + 4) * sizeof(float), c->stream, center, mpole, mult, ltop, write_geom);
+	hipLaunchKernelGGL(m2m_top_kernel<P>, dim3(1), dim3(kTopNodes), (size_t)(1 << ltop) * (offS + 4) * sizeof(float), c->stream, center, mpole, mult, ltop, 0,
+	                   write_geom);
 	NBCO_HIP(hipGetLastError());
 	return NBCO_OK;
 }
