@@ -1019,10 +1019,13 @@ __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab
 
 // start state of a traversal: the root pair in the frontier, counters cleared, and (all workgroups) the per-target entry
 // counts of both lists cleared
+// One (leaf, leaf) self entry per own leaf of the P2P list (fmm_cart3_kdtree.cuh:1059-1071) is counted here: it owns slot 0
+// of its target's range, the slots handed out by the traversal's atomics start at 1.
 __global__ __launch_bounds__(kBlock) void traverse_init_kernel(int2 *frontier, int *counters, int nctr, int *tctr, unsigned *__restrict__ list_cnt,
-                                                               long long words)
+                                                               long long words, long long self0, long long nself)
 {
-	for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < words; i += (long long)gridDim.x * kBlock) list_cnt[i] = 0u;
+	for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < words; i += (long long)gridDim.x * kBlock)
+		list_cnt[i] = (i >= self0 && i < self0 + nself) ? 1u : 0u;
 	if (blockIdx.x != 0) return;
 	for (int i = threadIdx.x; i < nctr; i += kBlock) counters[i] = 0;
 	for (int i = threadIdx.x; i < kTcInts; i += kBlock) tctr[i] = 0;
@@ -1034,16 +1037,20 @@ __global__ __launch_bounds__(kBlock) void traverse_init_kernel(int2 *frontier, i
 // over its capacity (counters[2], reported to the caller as NBCO_ERR_CAPACITY once the host looks at the flags) the
 // lists are declared empty and the per-target counts cleared, so that everything already queued behind the traversal
 // runs on a consistent -- if useless -- state.
+// The counts and flags the host looks at after the evaluation go straight to pinned host memory (`host_flags`: P2P pairs, M2L
+// pairs, list overflow, tie flag of the build) -- two device-to-host copies less on the critical path.
 __global__ __launch_bounds__(1024) void traverse_finish_kernel(int *counters, int *tctr, long long capR, unsigned *cnt_all, long long ncnt,
-                                                               unsigned *cnt_self, int nself)
+                                                               unsigned *cnt_self, int nself, int *__restrict__ host_flags)
 {
 	const int lane = threadIdx.x;
 	const bool overflow = counters[2] != 0;
 	if (overflow)
+	{
+		// empty lists; the own leaves keep their self entries
 		for (long long i = threadIdx.x; i < ncnt; i += blockDim.x) cnt_all[i] = 0u;
-	__syncthreads();
-	// one (leaf, leaf) self entry per own leaf of the P2P list (fmm_cart3_kdtree.cuh:1059-1071)
-	for (int i = threadIdx.x; i < nself; i += blockDim.x) cnt_self[i] += 1u;
+		__syncthreads();
+		for (int i = threadIdx.x; i < nself; i += blockDim.x) cnt_self[i] = 1u;
+	}
 	if (lane >= 64) return;
 	for (int which = 0; which < 2; ++which)
 	{
@@ -1051,8 +1058,9 @@ __global__ __launch_bounds__(1024) void traverse_finish_kernel(int *counters, in
 		int v = (lane < kTravK && !overflow) ? tctr[src + lane] : 0, incl = v;
 		for (int o = 1; o < kTravK; o <<= 1) { const int y = __shfl_up(incl, o); if (lane >= o) incl += y; }
 		if (lane < kTravK) tctr[dst + lane] = incl - v;
-		if (lane == kTravK - 1) { tctr[dst + kTravK] = incl; counters[which] = incl; }
+		if (lane == kTravK - 1) { tctr[dst + kTravK] = incl; counters[which] = incl; host_flags[which] = incl; }
 	}
+	if (lane == 0) { host_flags[2] = overflow ? 1 : 0; host_flags[3] = counters[110]; }
 }
 
 // dense copy of a region-structured pair list (nbco_kd_copy)
@@ -1088,9 +1096,9 @@ __global__ __launch_bounds__(kBlock) void list_fill_kernel(const int2 *__restric
 		}
 		else
 		{
-			// self entries of the domain's own leaves: counted last (traverse_finish_kernel), so they own the last slot
+			// self entries of the domain's own leaves: counted first (traverse_init_kernel), so they own slot 0
 			const uint64_t t = (uint64_t)(self0 + (i - npairs));
-			keys[start[t + 1] - 1] = (t << shift) | t;
+			keys[start[t]] = (t << shift) | t;
 		}
 	}
 }
@@ -1566,8 +1574,10 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		NBCO_TRY(c->reserve(c->trav_ctr, sizeof(int) * 1024));
 		static_assert(kTcInts <= 1024, "traversal counter block");
 		int *tctr = c->trav_ctr.as<int>();
+		NBCO_TRY(c->flags_begin());
 		hipLaunchKernelGGL(traverse_init_kernel, dim3(grid1d((long long)(2 * (np_ + nm_)) / 8 + 1, 256)), dim3(kBlock), 0, st, fa, ctr, 104, tctr,
-		                   c->list_cnt.as<unsigned>(), (long long)(2 * (np_ + nm_)));   // counters[110] is the selection-build flag
+		                   c->list_cnt.as<unsigned>(), (long long)(2 * (np_ + nm_)), (long long)self0, (long long)(c->o.coll ? nself : 0));
+		// (counters[110] is the selection-build flag)
 		const int iters = L + 2;   // every launch performs two traversal steps (2L + 1 are needed)
 		for (int it = 0; it < iters; ++it)
 		{
@@ -1577,14 +1587,11 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 			std::swap(fa, fb);
 		}
 		hipLaunchKernelGGL(traverse_finish_kernel, dim3(1), dim3(1024), 0, st, ctr, tctr, capR, c->list_cnt.as<unsigned>(), (long long)(2 * (np_ + nm_)),
-		                   cnt_p2p + self0, c->o.coll ? nself : 0);
+		                   cnt_p2p + self0, c->o.coll ? nself : 0, c->h_flags);
 		NBCO_HIP(hipGetLastError());
-		// counts and flags go to pinned host memory behind the traversal; the host looks at them only after it has
+		// counts and flags are in pinned host memory once this event has passed; the host looks at them only after it has
 		// enqueued the rest of the evaluation (every later kernel takes its counts from the device), so the GPU never
 		// waits for a host round trip
-		NBCO_TRY(c->flags_begin());
-		NBCO_HIP(hipMemcpyAsync(c->h_flags, ctr, sizeof(int) * 3, hipMemcpyDeviceToHost, st));
-		NBCO_HIP(hipMemcpyAsync(c->h_flags + 3, ctr + 110, sizeof(int), hipMemcpyDeviceToHost, st));
 		NBCO_HIP(hipEventRecord(c->ev_flags, st));
 	}
 	if (phase == 1) return NBCO_OK;
