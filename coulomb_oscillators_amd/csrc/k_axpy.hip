@@ -119,7 +119,8 @@ __global__ __launch_bounds__(kBlock) void kick_drift_kernel(float *__restrict__ 
 }
 
 // fused tail of a force evaluation + kick: a = a*param[0] - k o x (rescale + add_elastic), v += a*ks
-__global__ __launch_bounds__(kBlock) void finish_kick_kernel(const float *__restrict__ x, float *__restrict__ v, float *__restrict__ a,
+// (v_in != v: the evaluator left the tree-ordered velocities in a scratch buffer and this kick brings them home)
+__global__ __launch_bounds__(kBlock) void finish_kick_kernel(const float *__restrict__ x, const float *v_in, float *v, float *__restrict__ a,
                                                              const float *__restrict__ param, float ks, long long n3, int elastic,
                                                              int rescale)
 {
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(kBlock) void finish_kick_kernel(const float *__rest
 		float ai = a[i] * s;
 		if (elastic) ai = fmaf(-kc, x[i], ai);
 		a[i] = ai;
-		v[i] = fmaf(ks, ai, v[i]);
+		v[i] = fmaf(ks, ai, v_in[i]);
 	}
 }
 
@@ -215,10 +216,10 @@ int launch_kick_drift(nbco_ctx *c, float *x, float *v, const float *a, float ks,
 	return NBCO_OK;
 }
 
-int launch_finish_kick(nbco_ctx *c, const float *x, float *v, float *a, const float *param, float ks, long long n, bool elastic)
+int launch_finish_kick(nbco_ctx *c, const float *x, const float *v_in, float *v, float *a, const float *param, float ks, long long n, bool elastic)
 {
 	if (n <= 0) return NBCO_OK;
-	hipLaunchKernelGGL(finish_kick_kernel, dim3(stream_grid(3 * n)), dim3(kBlock), 0, c->stream, x, v, a, param, ks, 3 * n, elastic ? 1 : 0, 0);
+	hipLaunchKernelGGL(finish_kick_kernel, dim3(stream_grid(3 * n)), dim3(kBlock), 0, c->stream, x, v_in, v, a, param, ks, 3 * n, elastic ? 1 : 0, 0);
 	NBCO_HIP(hipGetLastError());
 	return NBCO_OK;
 }

@@ -1701,7 +1701,8 @@ static int kd_finish_order(nbco_ctx *c, float *p, long long n)
 	NBCO_TRY(c->reserve(c->tmp3, sizeof(float) * 3 * (size_t)n));
 	hipLaunchKernelGGL(reorder_state_kernel, dim3(grid1d(n)), dim3(kBlock), 0, st, (const float4 *)c->pos4.as<float4>(), (const int *)c->unsort.as<int>(),
 	                   (const float *)(p + 3 * n), p, c->tmp3.as<float>(), n);
-	NBCO_HIP(hipMemcpyAsync(p + 3 * n, c->tmp3.ptr, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToDevice, st));
+	if (c->defer_v_copy) c->v_deferred = c->tmp3.as<float>();   // the caller's next pass over the velocities reads them from here
+	else NBCO_HIP(hipMemcpyAsync(p + 3 * n, c->tmp3.ptr, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToDevice, st));
 	NBCO_HIP(hipGetLastError());
 	return NBCO_OK;
 }

@@ -432,11 +432,22 @@ int nbco_integrate(nbco_ctx *c, int scheme, int kind, float *buf, long long n, c
 			PhaseScope ph(c, NBCO_PH_AXPY);
 			NBCO_TRY(launch_kick_drift(c, x, v, a, (float)ds, (float)dt, n3));
 		}
-		// F K(ds): the elastic term and the kick share one pass over x, v, a
-		NBCO_TRY(eval_kind(c, kind, x, a, n, param));
+		// F K(ds): the elastic term and the kick share one pass over x, v, a -- and when the evaluator has just re-ordered
+		// the particles, the kick reads the tree-ordered velocities straight from the evaluator's scratch copy
+		c->defer_v_copy = true;
+		c->v_deferred = nullptr;
+		const int rc = eval_kind(c, kind, x, a, n, param);
+		c->defer_v_copy = false;
+		const float *v_in = c->v_deferred ? c->v_deferred : v;
+		c->v_deferred = nullptr;
+		if (rc != NBCO_OK)
+		{
+			if (v_in != v) hipMemcpyAsync(v, v_in, sizeof(float) * (size_t)n3, hipMemcpyDeviceToDevice, c->stream);   // leave a whole state behind
+			return rc;
+		}
 		{
 			PhaseScope ph(c, NBCO_PH_AXPY);
-			NBCO_TRY(launch_finish_kick(c, x, v, a, param, (float)ds, n, elastic != 0));
+			NBCO_TRY(launch_finish_kick(c, x, v_in, v, a, param, (float)ds, n, elastic != 0));
 		}
 		break;
 	}

@@ -79,6 +79,10 @@ struct nbco_ctx
 	hipStream_t aux = nullptr;
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	bool aux_pending = false;
+	// the kd evaluator may leave the tree-ordered velocities in tmp3 for the caller's next pass over v (leapfrog's closing
+	// kick) instead of copying them back itself: requested with defer_v_copy, reported in v_deferred
+	bool defer_v_copy = false;
+	const float *v_deferred = nullptr;
 	long long perm_primed_n = -1;   // particle count for which both permutation buffers were last filled with valid indices
 	double host_wait_s = 0, host_call_s = 0;   // diagnostics (NBCO_HOST_TIMING): time blocked on the flags event / inside nbco_integrate
 	long long host_calls = 0;
@@ -189,8 +193,7 @@ int launch_copy(nbco_ctx *c, float *dst, const float *src, long long n3);
 int launch_pack4(nbco_ctx *c, float4 *dst, const float *src3, long long n);
 // fused integrator pieces
 int launch_kick_drift(nbco_ctx *c, float *x, float *v, const float *a, float ks, float ds, long long n3);
-int launch_finish_kick(nbco_ctx *c, const float *x, float *v, float *a, const float *param, float ks, long long n,
-                       bool elastic);
+int launch_finish_kick(nbco_ctx *c, const float *x, const float *v_in, float *v, float *a, const float *param, float ks, long long n, bool elastic);
 // k_direct.hip
 int launch_direct(nbco_ctx *c, const float *p, float *a, long long n, const float *param, bool kahan);
 // k_reduce.hip
