@@ -1541,7 +1541,7 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 
 	// capacity of the frontier and of the two pair lists, split into kTravK regions
 	// (regions fill unevenly: each gets twice its share of list_factor * ntot pairs)
-	const long long capR = 2 * (((long long)c->o.list_factor * ntot + 4096 + kTravK - 1) / kTravK), cap = capR * kTravK;
+	const long long capR = 2 * (((long long)c->o.list_factor * c->list_growth * ntot + 4096 + kTravK - 1) / kTravK), cap = capR * kTravK;
 	NBCO_TRY(c->reserve(c->frontier_a, sizeof(int2) * (size_t)cap));
 	NBCO_TRY(c->reserve(c->frontier_b, sizeof(int2) * (size_t)cap));
 	// pairs [0, cap) and, behind them, the slot of either direction inside its target's range [cap, 2 cap)
@@ -1687,7 +1687,7 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		out.sel_overflow = 1;
 		return NBCO_OK;
 	}
-	if (h[2] != 0) return c->fail(NBCO_ERR_CAPACITY, "dual tree traversal exceeded the list capacity (raise opts.list_factor)");
+	if (h[2] != 0) return c->fail(NBCO_ERR_CAPACITY, "dual tree traversal exceeded the list capacity (raise opts.list_factor or set opts.list_grow)");
 	out.np2p = h[0]; out.nm2l = h[1];
 	c->hint_np2p = h[0]; c->hint_nm2l = h[1];
 	return NBCO_OK;
@@ -1720,7 +1720,16 @@ int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 	NBCO_TRY(kd_build_upward(c, p, n, L, nullptr, rebuild));
 	KdCounts cnt;
 	const Dom whole{0, 0};
-	NBCO_TRY(kd_interact(c, view_of(c->kd), c->pos4.as<float4>(), n, c->kd.mlt_max, whole, 0, n, c->unsort.as<int>(), a, param, cnt));
+	{
+		const int rc = kd_interact(c, view_of(c->kd), c->pos4.as<float4>(), n, c->kd.mlt_max, whole, 0, n, c->unsort.as<int>(), a, param, cnt);
+		if (rc == NBCO_ERR_CAPACITY && c->grow_lists(c->kd.ntot))
+		{
+			// the lists have outgrown their buffers (the caller's arrays are untouched): twice the room, same evaluation
+			c->tree_valid = false;
+			return fmm_kdtree_eval(c, p, a, n, param);
+		}
+		if (rc != NBCO_OK) return rc;
+	}
 	if (cnt.sel_overflow)
 	{
 		// next more conservative build: three radix passes, then the sorting build
@@ -2033,8 +2042,13 @@ static int dist_finish_rest(nbco_ctx *c, const char *mp_blocks, size_t mp_stride
 	};
 	KdCounts cnt;
 	const Dom dm{d, lay.rank};
-	NBCO_TRY(kd_interact(c, tv, (const float4 *)c->dist.pos_all, lay.n_global, g.mlt_max, dm, (long long)lay.rank * nl, nl, c->unsort.as<int>(), a_local, param,
-	                     cnt, 2, &pre_far));
+	int rc = kd_interact(c, tv, (const float4 *)c->dist.pos_all, lay.n_global, g.mlt_max, dm, (long long)lay.rank * nl, nl, c->unsort.as<int>(), a_local, param,
+	                     cnt, 2, &pre_far);
+	while (rc == NBCO_ERR_CAPACITY && c->grow_lists(g.ntot))
+		// twice the room, traversal and the rest again (the global arrays, multipoles included, are in place; purely local)
+		rc = kd_interact(c, tv, (const float4 *)c->dist.pos_all, lay.n_global, g.mlt_max, dm, (long long)lay.rank * nl, nl, c->unsort.as<int>(), a_local, param,
+		                 cnt, 0, nullptr);
+	if (rc != NBCO_OK) return rc;
 	if (cnt.sel_overflow) return c->fail(NBCO_ERR_UNSUPPORTED, "nbco_dist_finish: unresolved tie overflow of the selection build");
 	if (c->dist.rebuilt) NBCO_TRY(kd_finish_order(c, buf_local, nl));
 	c->tree_valid = true;

@@ -119,6 +119,7 @@ int nbco_opts_default(nbco_opts *o)
 	o->m2l_first = 0;
 	o->sync = 1;
 	o->list_factor = 48;
+	o->list_grow = 1;
 	o->far_fp64 = 0;
 	o->stream = nullptr;
 	return NBCO_OK;
@@ -184,6 +185,7 @@ int nbco_set_opts(nbco_ctx *c, const nbco_opts *o)
 	if (!c || !o) return NBCO_ERR_ARG;
 	NBCO_TRY(check_opts(c, o));
 	if ((hipStream_t)o->stream != c->stream) NBCO_HIP(hipStreamSynchronize(c->stream));
+	if (o->list_factor != c->o.list_factor) c->list_growth = 1;
 	bool topo = o->fmm_order != c->o.fmm_order || o->dens_inhom != c->o.dens_inhom || o->tree_L != c->o.tree_L
 	            || o->unsort != c->o.unsort;
 	c->o = *o;

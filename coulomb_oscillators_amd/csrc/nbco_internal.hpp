@@ -81,6 +81,14 @@ struct nbco_ctx
 	bool aux_pending = false;
 	// the kd evaluator may leave the tree-ordered velocities in tmp3 for the caller's next pass over v (leapfrog's closing
 	// kick) instead of copying them back itself: requested with defer_v_copy, reported in v_deferred
+	int list_growth = 1;   // the lists hold list_growth * opts.list_factor * nodes pairs (doubled after an overflow, opts.list_grow)
+	bool grow_lists(int ntot)   // false: growth is off or exhausted
+	{
+		if (!o.list_grow || list_growth >= 64) return false;
+		if (4LL * list_growth * o.list_factor * (long long)ntot >= (1LL << 31)) return false;   // 32-bit list offsets
+		list_growth *= 2;
+		return true;
+	}
 	bool defer_v_copy = false;
 	const float *v_deferred = nullptr;
 	long long perm_primed_n = -1;   // particle count for which both permutation buffers were last filled with valid indices

@@ -73,8 +73,13 @@ typedef struct nbco_opts {
 	int   list_factor;  /* capacity of the P2P / M2L lists and of the traversal frontier, in units
 	                       of the node count (reference: 1000, fmm_cart3_kdtree.cuh:1584-1586).  The
 	                       lists are kept in 16 regions of list_factor * nodes / 8 pairs each; a region
-	                       that runs full makes the evaluation return NBCO_ERR_CAPACITY with the
-	                       caller's arrays untouched (default 48: ~10x the lists of the BASELINE runs) */
+	                       that runs full makes the evaluation grow the lists (list_grow) or return
+	                       NBCO_ERR_CAPACITY with the caller's arrays untouched (default 48: ~10x the lists of
+	                       the BASELINE runs at their start) */
+	int   list_grow;    /* != 0 (default): a traversal that overflows its lists doubles the capacity (up to 64 x
+	                       list_factor, and at most 2^31 pairs) and repeats the evaluation instead of failing:
+	                       long runs change shape -- a ball that starts with 2.7e5 leaf pairs at N = 1M holds 6e6
+	                       after 1200 steps, when a few ejected particles have stretched the outer leaves */
 	int   far_fp64;     /* != 0: nbco_fmm_traceless keeps multipole / local expansions in double and does
 	                       P2M, M2M, M2L, L2L and L2P in fp64 (BASELINE config 5: fp64 far field, fp32 P2P).
 	                       Positions, cell centres and the near field stay fp32.  The fp32 far field overflows

@@ -321,7 +321,7 @@ def test_list_capacity_overflow_is_reported_and_recoverable(oracle32):
     n, p = 65536, 6
     buf = o.init_reference(n)
     par = o.params(n)
-    e = Engine(fmm_order=p, unsort=0, list_factor=1)
+    e = Engine(fmm_order=p, unsort=0, list_factor=1, list_grow=0)
     d = dev(buf[:2])
     before = d.clone()
     a = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
@@ -329,8 +329,15 @@ def test_list_capacity_overflow_is_reported_and_recoverable(oracle32):
         e.fmm_cart3_kdtree(d, a, n, dev(par))
     torch.cuda.synchronize()
     assert torch.equal(d, before)
-    e.set(list_factor=48)
     _, want = o.fmm_kd(buf[:2], par, p=p, threads=4, unsort=False)
+    # with list_grow (the default) the same context doubles its lists until the evaluation fits
+    e.set(list_grow=1)
     e.fmm_cart3_kdtree(d, a, n, dev(par))
+    torch.cuda.synchronize()
+    assert force_err(a.cpu().numpy(), want) < 1e-5
+    # ... and a sufficient list_factor needs no growth
+    d2 = dev(buf[:2])
+    e.set(list_factor=48)
+    e.fmm_cart3_kdtree(d2, a, n, dev(par))
     torch.cuda.synchronize()
     assert force_err(a.cpu().numpy(), want) < 1e-5
