@@ -1105,7 +1105,7 @@ __global__ __launch_bounds__(kBlock) void list_fill_kernel(const int2 *__restric
 
 // one wave per target: rank sort of its source range (distinct keys) in registers up to 512 entries (the BASELINE ball
 // has 17 on average, 254..300 at most; a bitonic network in LDS for the 257..512 class cost 30 us of a 45 us kernel), and
-// beyond that (wide opening radii) a rank sort straight from global memory
+// beyond that (wide opening radii, outliers late in a long run) a radix sort of the range through global memory
 #ifndef NBCO_P2P_CHUNK
 #define NBCO_P2P_CHUNK 16
 #endif
@@ -1113,10 +1113,11 @@ constexpr int kP2PChunk = NBCO_P2P_CHUNK;   // source leaves per near-field work
 // DESC: the list is the P2P list -- also emit the source descriptor (first particle, multiplicity) of every sorted entry,
 // so the pair kernel does no dependent index -> mult -> position loads
 template <bool DESC>
-__global__ __launch_bounds__(kBlock) void list_segsort_kernel(const int *__restrict__ start, int ntargets, const uint64_t *__restrict__ in,
-                                                              uint64_t *__restrict__ out, int shift, const int *__restrict__ leaf_index,
-                                                              const int *__restrict__ leaf_mult, int2 *__restrict__ desc)
+__global__ __launch_bounds__(kBlock) void list_segsort_kernel(const int *__restrict__ start, int ntargets, uint64_t *in, uint64_t *out, int shift,
+                                                              const int *__restrict__ leaf_index, const int *__restrict__ leaf_mult,
+                                                              int2 *__restrict__ desc)
 {
+	__shared__ unsigned digit_off[kBlock / 64][256];   // long ranges only: per-wave digit offsets of the radix passes
 	const uint64_t smask = (1ull << shift) - 1;
 	auto emit = [&](int slot, uint64_t key) {
 		out[slot] = key;
@@ -1170,13 +1171,54 @@ __global__ __launch_bounds__(kBlock) void list_segsort_kernel(const int *__restr
 		else if (cnt <= 512) rank_in_registers(std::integral_constant<int, 8>{}, s, cnt);
 		else
 		{
-			for (int i = lane; i < cnt; i += 64)
+			// Long range (an outlier's leaf can be paired with most of the tree: tens of thousands of entries): the wave sorts
+			// it by source index with a stable LSD radix sort, 8 bits per pass, ping-ponging between its slices of the
+			// unsorted and the sorted key arrays.  O(cnt) per pass, where ranking would be O(cnt^2).
+			unsigned *off = digit_off[wv];
+			uint64_t *src = in + s, *dst = out + s;
+			const uint64_t below = (1ull << lane) - 1ull;
+			for (int bit = 0; bit < shift; bit += 8)
 			{
-				const uint64_t key = in[s + i];
-				int rank = 0;
-				for (int q = 0; q < cnt; ++q) rank += in[s + q] < key ? 1 : 0;
-				emit(s + rank, key);
+				for (int b = lane; b < 256; b += 64) off[b] = 0u;
+				wave_lds_sync();
+				for (int i = lane; i < cnt; i += 64) atomicAdd(&off[(unsigned)(src[i] >> bit) & 255u], 1u);
+				wave_lds_sync();
+				// exclusive scan of the 256 digit counts (four per lane)
+				unsigned v0 = off[4 * lane], v1 = off[4 * lane + 1], v2 = off[4 * lane + 2], v3 = off[4 * lane + 3];
+				const unsigned sum = v0 + v1 + v2 + v3;
+				unsigned incl = sum;
+				for (int o = 1; o < 64; o <<= 1) { const unsigned y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+				const unsigned base = incl - sum;
+				wave_lds_sync();
+				off[4 * lane] = base; off[4 * lane + 1] = base + v0; off[4 * lane + 2] = base + v0 + v1; off[4 * lane + 3] = base + v0 + v1 + v2;
+				wave_lds_sync();
+				// stable scatter, 64 entries at a time in range order
+				for (int i0 = 0; i0 < cnt; i0 += 64)
+				{
+					const int i = i0 + lane;
+					const bool valid = i < cnt;
+					const uint64_t key = valid ? src[i] : 0ull;
+					const unsigned dg = (unsigned)(key >> bit) & 255u;
+					uint64_t same = __ballot(valid);   // lanes holding the same digit
+#pragma unroll
+					for (int b = 0; b < 8; ++b)
+					{
+						const uint64_t bal = __ballot((dg >> b) & 1u);
+						same &= ((dg >> b) & 1u) ? bal : ~bal;
+					}
+					const unsigned before = (unsigned)__popcll(same & below);
+					const unsigned o = valid ? off[dg] : 0u;
+					if (valid) dst[o + before] = key;
+					wave_lds_sync();
+					if (valid && before == 0u) off[dg] = o + (unsigned)__popcll(same);
+					wave_lds_sync();
+				}
+				// the next pass reads what this one wrote (same wave, through memory)
+				__threadfence_block();
+				uint64_t *t2 = src; src = dst; dst = t2;
 			}
+			// `src` holds the sorted range now
+			for (int i = lane; i < cnt; i += 64) emit(s + i, src[i]);
 		}
 	}
 }
@@ -1359,10 +1401,10 @@ static int build_directed_list(nbco_ctx *c, const int2 *pairs, const int2 *ranks
 	                   (const int *)start, keys_tmp);
 	if (desc)
 		hipLaunchKernelGGL(list_segsort_kernel<true>, dim3((ntargets + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, (const int *)start, ntargets,
-		                   (const uint64_t *)keys_tmp, keys_out, shift, leaf_index, leaf_mult, desc);
+		                   keys_tmp, keys_out, shift, leaf_index, leaf_mult, desc);
 	else
 		hipLaunchKernelGGL(list_segsort_kernel<false>, dim3((ntargets + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, (const int *)start,
-		                   ntargets, (const uint64_t *)keys_tmp, keys_out, shift, (const int *)nullptr, (const int *)nullptr, (int2 *)nullptr);
+		                   ntargets, keys_tmp, keys_out, shift, (const int *)nullptr, (const int *)nullptr, (int2 *)nullptr);
 	NBCO_HIP(hipGetLastError());
 	return NBCO_OK;
 }
