@@ -1113,7 +1113,7 @@ constexpr int kP2PChunk = NBCO_P2P_CHUNK;   // source leaves per near-field work
 // DESC: the list is the P2P list -- also emit the source descriptor (first particle, multiplicity) of every sorted entry,
 // so the pair kernel does no dependent index -> mult -> position loads
 template <bool DESC>
-__global__ __launch_bounds__(kBlock) void list_segsort_kernel(const int *__restrict__ start, int ntargets, uint64_t *in, uint64_t *out, int shift,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void list_segsort_kernel(const int *__restrict__ start, int ntargets, uint64_t *in, uint64_t *out, int shift,
                                                               const int *__restrict__ leaf_index, const int *__restrict__ leaf_mult,
                                                               int2 *__restrict__ desc)
 {
