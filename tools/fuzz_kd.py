@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Randomised differential run of the kd-tree evaluator against the oracle (GPU box): python tools/fuzz_kd.py [seed] [cases]
+Tree arrays and interaction lists must be identical; forces are compared with the fp32 oracle (1e-5) and, when they differ
+more, with the fp64 oracle."""
+import sys, time, numpy as np, torch
+import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from coulomb_oscillators_amd import Engine
+from oracle.pyoracle import Oracle
+from nbutil import force_err, canon_pairs
+o = Oracle(np.float32)
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+bad = 0
+for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
+    n = int(rng.choice([rng.integers(1, 300), rng.integers(300, 9000), rng.integers(9000, 70000), rng.integers(70000, 300000)]))
+    p = int(rng.integers(1, 9))
+    kind = rng.choice(["gauss", "cube", "clumps", "quant", "dup"])
+    radius = float(rng.choice([1.0, 1.0, 1.5, 2.0]))
+    dens = float(rng.choice([1.0, 1.0, 0.5, 4.0]))
+    m2l_first = int(rng.integers(0, 2))
+    if kind == "gauss": buf = o.init_reference(n)
+    elif kind == "cube": buf = o.init_reference(n, test_mode=True)
+    else:
+        buf = np.zeros((3, n, 3), dtype=np.float32)
+        c = rng.standard_normal((8, 3)).astype(np.float32)
+        buf[0] = c[rng.integers(0, 8, n)] + 0.05 * rng.standard_normal((n, 3)).astype(np.float32)
+        if kind == "quant": buf[0] = (np.round(buf[0] / 2e-3) * 2e-3).astype(np.float32)
+        if kind == "dup" and n > 10: buf[0, : n // 3] = buf[0, n // 3: 2 * (n // 3)][: n // 3]
+    par = o.params(n)
+    try:
+        _, want = o.fmm_kd(buf[:2], par, p=p, threads=8, unsort=True, radius=radius, dens_inhom=dens, eps2=1e-10) if False else o.fmm_kd(buf[:2], par, p=p, threads=8, unsort=True, radius=radius, dens_inhom=dens)
+    except Exception as ex:
+        print("oracle failed", n, p, kind, ex); continue
+    tree = o.kd_tree()
+    e = Engine(fmm_order=p, unsort=1, tree_radius=radius, dens_inhom=dens, m2l_first=0)
+    d = torch.from_numpy(buf[:2].copy()).cuda(); a = torch.zeros((n, 3), device="cuda"); prm = torch.from_numpy(par).cuda()
+    try:
+        e.fmm_cart3_kdtree(d, a, n, prm); torch.cuda.synchronize()
+        got = a.cpu().numpy()
+        fin = np.isfinite(want).all()
+        err = force_err(got, want) if fin else float("nan")
+        info = e.kd_info()
+        same_lists = all(np.array_equal(canon_pairs(e.kd_array(k)), canon_pairs(tree[k])) for k in ("p2p", "m2l"))
+        same_tree = all(np.array_equal(e.kd_array(k), tree[k]) for k in ("index", "mult", "splitdim", "lbound", "rbound"))
+        ok = same_lists and same_tree and (not fin or err < 1e-5)
+        if not ok and same_lists and same_tree:
+            o64 = Oracle(np.float64)
+            _, w64 = o64.fmm_kd(buf[:2].astype(np.float64), par.astype(np.float64), p=p, threads=8, unsort=True, radius=radius, dens_inhom=dens)
+            print("   vs fp64 oracle: gpu", force_err(got, w64), "oracle32", force_err(want, w64), "same fp64 tree:", np.array_equal(o64.kd_tree()["index"], tree["index"]))
+        if not ok: bad += 1
+        print("OK " if ok else "BAD", f"n={n} p={p} {kind} r={radius} i={dens} L={info.L} mode={info.build_mode} err={err:.2e} lists={same_lists} tree={same_tree}", flush=True)
+    except Exception as ex:
+        bad += 1; print("EXC", n, p, kind, radius, dens, ex, flush=True)
+    e.close()
+print("bad:", bad)
