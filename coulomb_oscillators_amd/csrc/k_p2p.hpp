@@ -36,9 +36,9 @@ __device__ __forceinline__ void wave_lds_sync()
 		float r2 = fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, eps2)));         \
 		float ri = __builtin_amdgcn_rsqf(r2);                              \
 		float ri3 = ri * ri * ri;                                          \
-		ax = fmaf(dx, ri3, ax);                                            \
-		ay = fmaf(dy, ri3, ay);                                            \
-		az = fmaf(dz, ri3, az);                                            \
+		tx = fmaf(dx, ri3, tx);                                            \
+		ty = fmaf(dy, ri3, ty);                                            \
+		tz = fmaf(dz, ri3, tz);                                            \
 	}
 
 #ifndef NBCO_P2P_WAVES
@@ -119,6 +119,10 @@ __global__ __launch_bounds__(64 * kP2PWaves) NBCO_P2P_ATTR void p2p_kernel(const
 						}
 						wave_lds_sync();
 						const float4 *t4 = reinterpret_cast<const float4 *>(tile[b][g]);
+						// a tile's contributions are summed on their own and then added to the running total: the rounding error
+						// of a long fp32 sum grows with its length, and a lane sees thousands of sources per chunk when the leaves
+						// are large (the reference's CPU path also accumulates per leaf pair first)
+						float tx = 0.f, ty = 0.f, tz = 0.f;
 #pragma unroll 2
 						for (int q4 = 0; q4 < TPL / 4; ++q4)
 						{
@@ -128,6 +132,7 @@ __global__ __launch_bounds__(64 * kP2PWaves) NBCO_P2P_ATTR void p2p_kernel(const
 							P2P_PAIR(B.z, B.w, C.x)
 							P2P_PAIR(C.y, C.z, C.w)
 						}
+						ax += tx; ay += ty; az += tz;
 						wave_lds_sync();
 						b ^= 1;
 					}
