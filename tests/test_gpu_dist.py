@@ -48,6 +48,22 @@ def test_single_block_exchange_gives_the_same(oracle32, n, G, p):
     assert torch.equal(out[0], out[1])
 
 
+def test_sharded_lists_grow_on_demand(oracle32):
+    """a domain whose traversal overflows its lists doubles them and repeats its half of the evaluation on its own (no
+    collective involved); the result is still the single-GPU one"""
+    import torch
+    n, G, p = 65536, 2, 6
+    pos, vel = make_state(oracle32, n, "reference")
+    par = torch.from_numpy(oracle32.params(n)).cuda()
+    e1, ref = single_gpu(n, pos, vel, par, fmm_order=p, unsort=0, tree_steps=1)
+    for split in (None, False):
+        w = loopback(n, G, pos, vel, fmm_order=p, unsort=0, tree_steps=1, list_factor=1, list_grow=1)
+        w.force(par, elastic=False, split=split)
+        torch.cuda.synchronize()
+        got = torch.cat([torch.cat([r.pos for r in w.runs]), torch.cat([r.vel for r in w.runs]), torch.cat([r.acc for r in w.runs])])
+        assert torch.equal(got, ref)
+
+
 def test_far_field_waits_on_the_second_stream(oracle32):
     """the multipoles may arrive after nbco_dist_finish_traverse has been enqueued, and only the context's second stream
     (nbco_aux_stream) has to wait for them: emulate a late all-gather with a slow copy on a side stream, make the
