@@ -895,6 +895,11 @@ constexpr int kTcM2L = kTcP2P + kTravK;           // [kTravK]                   
 constexpr int kTcP2PPref = kTcM2L + kTravK;       // [kTravK + 1] exclusive prefix sums (traverse_finish_kernel)
 constexpr int kTcM2LPref = kTcP2PPref + kTravK + 1;
 constexpr int kTcInts = kTcM2LPref + kTravK + 1;
+// traversal launches beyond the tree depth: every launch performs two traversal steps, and L launches empty the frontier in
+// every case tried (edge sizes, deep trees, sharded trees); one spare, and traverse_finish_kernel checks the outcome
+#ifndef NBCO_TRAV_EXTRA
+#define NBCO_TRAV_EXTRA 1
+#endif
 
 // dense index -> slot of a region-structured list
 __device__ inline long long region_slot(const int *__restrict__ pref, long long capR, long long i)
@@ -1040,7 +1045,7 @@ __global__ __launch_bounds__(kBlock) void traverse_init_kernel(int2 *frontier, i
 // The counts and flags the host looks at after the evaluation go straight to pinned host memory (`host_flags`: P2P pairs, M2L
 // pairs, list overflow, tie flag of the build) -- two device-to-host copies less on the critical path.
 __global__ __launch_bounds__(1024) void traverse_finish_kernel(int *counters, int *tctr, long long capR, unsigned *cnt_all, long long ncnt,
-                                                               unsigned *cnt_self, int nself, int *__restrict__ host_flags)
+                                                               unsigned *cnt_self, int nself, int *__restrict__ host_flags, int iters)
 {
 	const int lane = threadIdx.x;
 	const bool overflow = counters[2] != 0;
@@ -1060,7 +1065,10 @@ __global__ __launch_bounds__(1024) void traverse_finish_kernel(int *counters, in
 		if (lane < kTravK) tctr[dst + lane] = incl - v;
 		if (lane == kTravK - 1) { tctr[dst + kTravK] = incl; counters[which] = incl; host_flags[which] = incl; }
 	}
-	if (lane == 0) { host_flags[2] = overflow ? 1 : 0; host_flags[3] = counters[110]; }
+	// the frontier the last launch wrote must be empty (it is after L + 1 launches of two levels each; checked, not assumed)
+	int left = lane < kTravK ? tctr[kTcFrontier + iters * kTravK + lane] : 0;
+	for (int o = 32; o > 0; o >>= 1) left += __shfl_xor(left, o);
+	if (lane == 0) { host_flags[2] = overflow ? 1 : (left != 0 ? 2 : 0); host_flags[3] = counters[110]; }
 }
 
 // dense copy of a region-structured pair list (nbco_kd_copy)
@@ -1620,7 +1628,7 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		hipLaunchKernelGGL(traverse_init_kernel, dim3(grid1d((long long)(2 * (np_ + nm_)) / 8 + 1, 256)), dim3(kBlock), 0, st, fa, ctr, 104, tctr,
 		                   c->list_cnt.as<unsigned>(), (long long)(2 * (np_ + nm_)), (long long)self0, (long long)(c->o.coll ? nself : 0));
 		// (counters[110] is the selection-build flag)
-		const int iters = L + 2;   // every launch performs two traversal steps (2L + 1 are needed)
+		const int iters = L + NBCO_TRAV_EXTRA;   // every launch performs two traversal steps; traverse_finish_kernel checks that none is left
 		for (int it = 0; it < iters; ++it)
 		{
 			hipLaunchKernelGGL(traverse_kernel, dim3(1024), dim3(kBlock), 0, st, tv, tab, (const int2 *)fa, fb, c->p2p_list.as<int2>(),
@@ -1629,7 +1637,7 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 			std::swap(fa, fb);
 		}
 		hipLaunchKernelGGL(traverse_finish_kernel, dim3(1), dim3(1024), 0, st, ctr, tctr, capR, c->list_cnt.as<unsigned>(), (long long)(2 * (np_ + nm_)),
-		                   cnt_p2p + self0, c->o.coll ? nself : 0, c->h_flags);
+		                   cnt_p2p + self0, c->o.coll ? nself : 0, c->h_flags, iters);
 		NBCO_HIP(hipGetLastError());
 		// counts and flags are in pinned host memory once this event has passed; the host looks at them only after it has
 		// enqueued the rest of the evaluation (every later kernel takes its counts from the device), so the GPU never
@@ -1729,6 +1737,7 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		out.sel_overflow = 1;
 		return NBCO_OK;
 	}
+	if (h[2] == 2) return c->fail(NBCO_ERR_HIP, "internal error: the dual tree traversal did not finish in its launches");
 	if (h[2] != 0) return c->fail(NBCO_ERR_CAPACITY, "dual tree traversal exceeded the list capacity (raise opts.list_factor or set opts.list_grow)");
 	out.np2p = h[0]; out.nm2l = h[1];
 	c->hint_np2p = h[0]; c->hint_nm2l = h[1];
