@@ -1088,8 +1088,22 @@ __global__ __launch_bounds__(kBlock) void list_compact_kernel(const int2 *__rest
 
 __global__ __launch_bounds__(kBlock) void list_fill_kernel(const int2 *__restrict__ pairs, const int2 *__restrict__ ranks, const int *__restrict__ pref,
                                                            long long capR, int sub, int self0, int nself, int shift, const int *__restrict__ start,
-                                                           uint64_t *__restrict__ keys)
+                                                           uint64_t *__restrict__ keys, const int *__restrict__ chunk_off, int ntargets,
+                                                           const int *__restrict__ leaf_index, const int *__restrict__ leaf_mult,
+                                                           int4 *__restrict__ chunk)
 {
+	// P2P list: the work-unit table of the pair kernel only needs the two prefix sums, like the fill: same launch.
+	// chunk record: {first particle of the target leaf, first entry, end entry, particles of the target leaf}
+	if (chunk)
+		for (int i = blockIdx.x * kBlock + threadIdx.x; i < ntargets; i += gridDim.x * kBlock)
+		{
+			const int b = start[i], e = start[i + 1], o = chunk_off[i], n = chunk_off[i + 1] - o;
+			const int ind = leaf_index[i], mlt = leaf_mult[i];
+			// equal shares (a list of 17 becomes 9 + 8, not 16 + 1: a wave that only gets one source leaf spends its life
+			// in the chain of dependent loads at the head of a chunk)
+			const int per = n > 0 ? (e - b + n - 1) / n : 0;
+			for (int k = 0; k < n; ++k) chunk[o + k] = make_int4(ind, min(b + k * per, e), min(b + (k + 1) * per, e), mlt);
+		}
 	const long long npairs = pref[kTravK];   // the pair count never leaves the device (regions are clamped to their capacity)
 	const long long total = npairs + nself;
 	for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock)
@@ -1252,22 +1266,6 @@ __global__ __launch_bounds__(kBlock) void pair_count_kernel(const int *__restric
 // evaluates one chunk and stores the partial sums of its 32 targets, and the L2P kernel adds a leaf's
 // chunks in list order (fixed order: still bit-reproducible, still no atomics).  Source descriptors and chunk
 // counts come out of the per-target sort (list_segsort_kernel<true>).
-// chunk record: {first particle of the target leaf, first entry, end entry, particles of the target leaf}
-__global__ __launch_bounds__(kBlock) void p2p_chunk_fill_kernel(const int *__restrict__ start, const int *__restrict__ off, int nleaf,
-                                                                const int *__restrict__ leaf_index, const int *__restrict__ leaf_mult,
-                                                                int4 *__restrict__ chunk)
-{
-	for (int i = blockIdx.x * kBlock + threadIdx.x; i < nleaf; i += gridDim.x * kBlock)
-	{
-		const int b = start[i], e = start[i + 1], o = off[i], n = off[i + 1] - o;
-		const int ind = leaf_index[i], mlt = leaf_mult[i];
-		// equal shares (a list of 17 becomes 9 + 8, not 16 + 1: a wave that only gets one source leaf spends its life
-		// in the chain of dependent loads at the head of a chunk)
-		const int per = n > 0 ? (e - b + n - 1) / n : 0;
-		for (int k = 0; k < n; ++k) chunk[o + k] = make_int4(ind, min(b + k * per, e), min(b + (k + 1) * per, e), mlt);
-	}
-}
-
 // tree order for the caller's state in one pass: positions unpacked to xyz triplets, velocities gathered into a scratch
 // copy (the gather cannot run in place)
 __global__ __launch_bounds__(kBlock) void reorder_state_kernel(const float4 *__restrict__ pos, const int *__restrict__ unsort,
@@ -1398,15 +1396,13 @@ static int build_directed_list(nbco_ctx *c, const int2 *pairs, const int2 *ranks
 	hipStream_t st = c->stream;   // (the self entries were added to cnt by traverse_finish_kernel)
 	if (desc)
 	{
-		// P2P list: entry offsets and chunk offsets from one scan, then the work-unit table (it only needs the offsets)
+		// P2P list: entry offsets and chunk offsets from one scan (the work-unit table is written by the fill kernel)
 		NBCO_TRY(exclusive_scan_counts_and_chunks(c, cnt, start, chunk_off, (size_t)(ntargets + 1), scan_tmp));
-		hipLaunchKernelGGL(p2p_chunk_fill_kernel, dim3(grid1d(ntargets)), dim3(kBlock), 0, st, (const int *)start, (const int *)chunk_off, ntargets, leaf_index,
-		                   leaf_mult, chunks);
 	}
 	else
 		NBCO_TRY(exclusive_scan_ints(c, (int *)cnt, start, (size_t)(ntargets + 1), scan_tmp));
 	hipLaunchKernelGGL(list_fill_kernel, dim3(grid1d(npairs_hint + nself)), dim3(kBlock), 0, st, pairs, ranks, pref_dev, capR, sub, self0, nself, shift,
-	                   (const int *)start, keys_tmp);
+	                   (const int *)start, keys_tmp, (const int *)chunk_off, ntargets, leaf_index, leaf_mult, desc ? chunks : (int4 *)nullptr);
 	if (desc)
 		hipLaunchKernelGGL(list_segsort_kernel<true>, dim3((ntargets + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, (const int *)start, ntargets,
 		                   keys_tmp, keys_out, shift, leaf_index, leaf_mult, desc);
