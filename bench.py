@@ -1,22 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X N-body Coulomb-oscillator engine.
 
-Metric (BASELINE.json): particle-steps/sec (+ Gpair-interactions/sec), N = 1M FMM-3D p = 6.
+Metric (BASELINE.json): particle-steps/sec (+ Gpair-interactions/sec), N = 1M FMM-3D p = 6, at 1/2/4/8 GPUs.
 
 A "step" is one leapfrog step (integrator.cuh:68-96) of the whole particle set with the kd-tree FMM
 evaluator + elastic term (coulombOscillatorFMMKD3, main3.cu:59-63), i.e. K(dt/2) D(dt) F K(dt/2),
 with the tree rebuilt on every evaluation (the reference CPU driver's behaviour) unless --tree-steps
-says otherwise.  Inputs are the reference's synthetic Gaussian ball (main3.cu:662-664) resident in
-HBM before the timed region.
+says otherwise.  Inputs are the reference's synthetic Gaussian ball (main3.cu:113-137 over the stream of
+:662-664, produced by the library's host-only nbco_init_gaussian) resident in HBM before the timed region.
 
-    python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0.
+With N > 1 and no WORLD_SIZE in the environment the parent starts N fresh rank processes itself (before it
+touches torch or the GPU) and relays rank 0's JSON line; under torchrun (WORLD_SIZE set) every process is one
+rank.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,7 +33,7 @@ FP32_VECTOR_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (vector)"
 FLOP_PER_PAIR = 20                   # one directed pair interaction = 20 flop
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -48,9 +51,64 @@ def parse():
     ap.add_argument("--dens-inhom", type=float, default=1.0, help="the reference's -i option (deeper trees for clustered inputs)")
     ap.add_argument("--dt", type=float, default=5e-4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the tree-reuse, strong-scaling, octree and nbco3 CLI legs after the timed region")
     ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--profile-all", action="store_true", help="record HIP events around every phase (perturbs value)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+# ---- N > 1 without a launcher: start the ranks ourselves --------------------------------------------------------------
+def spawn_ranks(args):
+    """One fresh python process per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment), started before this
+    process has imported torch or made any GPU call.  Rank 0's stdout is captured and its JSON line relayed; a failing rank
+    fails the run (the others are terminated by PID, nothing is restarted)."""
+    world = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    import tempfile
+    procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")
+    for r in range(world):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    failed = None
+    pending = set(range(world))
+    while pending and failed is None:      # poll: a crashed rank must not leave the others hanging in a collective
+        for r in sorted(pending):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            pending.discard(r)
+            if rc != 0:
+                failed = (r, rc)
+                break
+        if pending and failed is None:
+            time.sleep(0.2)
+    if failed is not None:
+        for r in pending:
+            procs[r].terminate()
+        for r in pending:
+            try:
+                procs[r].wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+        sys.stderr.write("bench.py: rank %d exited with status %d\n" % failed)
+        return 1
+    out0.seek(0)
+    line = None
+    for l in out0.read().splitlines():
+        if l.startswith("{"):
+            line = l
+    if line is None:
+        sys.stderr.write("bench.py: rank 0 printed no JSON line\n")
+        return 1
+    print(line)
+    return 0
 
 
 def measured_traffic(kernel):
@@ -68,24 +126,42 @@ def measured_traffic(kernel):
     return None, None
 
 
+def measured_ceiling():
+    """fraction of the nominal fp32 peak that the bare 13-instruction pair body reaches on register operands
+    (tools/pair_ceiling.hip, summary committed under profiles/): the issue ceiling of any non-mutual pair kernel"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pair_ceiling.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        res = json.load(f)["results"]
+    best = max((r["frac_of_157.3"] for r in res if r["variant"] in ("pair", "pair4")), default=None)
+    return best, os.path.relpath(files[-1], ROOT)
+
+
 # ---- synthetic workload: the initial condition of main3.cu:629-692 (Gaussian ball, centred, RMS-normalised) --------------
 SIGMA_X = (0.003, 0.001, 0.01)      # main3.cu:244
 OMEGA0 = (1.095, 1.0, 1.0)          # main3.cu:241
 XI = 2e-6                           # main3.cu:240
+REF_SEED = 5351550349027530206      # main3.cu:662
+REF_DISCARD = 1248                  # main3.cu:664
 
 
-def gaussian_ball(n, seed):
-    """[pos | vel | acc] of n particles: normal deviates with sigma_x / sigma_u = omega0 * sigma_x per axis, centred and
-    rescaled to exactly those RMS values (initGA, main3.cu:230-245); numpy's generator, not the reference's RNG stream"""
-    rng = np.random.default_rng(seed)
+def gaussian_ball(n, rank=0):
+    """[pos | vel | acc] of n particles from the library's host-only nbco_init_gaussian: the reference's initGA over
+    mt19937_64(REF_SEED + rank) after discard(1248).  Rank 0 therefore starts from exactly the state `nbco3 -n <n>` starts
+    from; further ranks draw further samples of the same ball from their own streams."""
+    import ctypes as C
+    from coulomb_oscillators_amd import lib_path
+    lib = C.CDLL(lib_path())
+    lib.nbco_init_gaussian.argtypes = [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_ulonglong, C.c_ulonglong, C.c_int]
+    lib.nbco_init_gaussian.restype = C.c_int
     sx = np.array(SIGMA_X, dtype=np.float32)
     su = np.array(OMEGA0, dtype=np.float32) * sx
     buf = np.zeros((3, n, 3), dtype=np.float32)
-    for k, sig in ((0, sx), (1, su)):
-        v = rng.standard_normal((n, 3), dtype=np.float32) * sig
-        v -= v.mean(axis=0, dtype=np.float64).astype(np.float32)
-        v *= sig / np.sqrt((v.astype(np.float64) ** 2).mean(axis=0)).astype(np.float32)
-        buf[k] = v
+    rc = lib.nbco_init_gaussian(buf.ctypes.data, n, sx.ctypes.data, su.ctypes.data, REF_SEED + rank, REF_DISCARD, 0)
+    if rc != 0:
+        raise RuntimeError("nbco_init_gaussian failed with status %d" % rc)
     return buf
 
 
@@ -95,16 +171,39 @@ def coulomb_params(n_system):
     return np.array([np.float32(XI) / np.float32(n_system), 0, 0, om[0] * om[0], om[1] * om[1], om[2] * om[2]], dtype=np.float32)
 
 
+def host_cpu():
+    """(physical cores this process may run on, CPU model string) from /proc/cpuinfo and the affinity mask"""
+    model, cores, cur = "unknown", set(), {}
+    try:
+        allowed = os.sched_getaffinity(0)
+    except Exception:
+        allowed = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f.read().split("\n") + [""]:
+                if ":" in line:
+                    k, v = [t.strip() for t in line.split(":", 1)]
+                    cur[k] = v
+                elif cur:
+                    if "model name" in cur:
+                        model = cur["model name"]
+                    cpu = int(cur.get("processor", -1))
+                    if allowed is None or cpu in allowed:
+                        cores.add((cur.get("physical id", "0"), cur.get("core id", str(cpu))))
+                    cur = {}
+    except OSError:
+        pass
+    n = len(cores) or (len(allowed) if allowed else (os.cpu_count() or 1))
+    return n, model
+
+
 def cpu_baseline(args, n):
-    """The oracle (a port of the reference's multithreaded CPU path) on a bounded sample of the same workload."""
+    """The oracle (a port of the reference's multithreaded CPU path) on a bounded sample of the same workload: one
+    std::thread per physical host core."""
     from oracle import pyoracle as po
     o = po.Oracle(np.float32)
-    cores = min(os.cpu_count() or 1, 16)
-    try:
-        cores = min(cores, len(os.sched_getaffinity(0)))
-    except Exception:
-        pass
-    buf = gaussian_ball(n, 20240807)        # the same state the GPU run starts from (rank 0)
+    cores, model = host_cpu()
+    buf = gaussian_ball(n)                  # the same state the GPU run starts from (rank 0)
     par = coulomb_params(n)
     if args.workload == "fmm_kd":
         kind, kw = po.KIND_FMM_KD, dict(p=args.order, unsort=False, threads=cores)
@@ -115,7 +214,7 @@ def cpu_baseline(args, n):
         for _ in range(steps):
             o.integrate(po.SCHEME_LEAPFROG, kind, buf, par, args.dt, **kw)
         dt = time.perf_counter() - t0
-        return {"value": n * steps / dt, "unit": "particle-steps/s", "cores": cores, "kind": "port", "sample": sample}
+        return {"value": n * steps / dt, "unit": "particle-steps/s", "cores": cores, "cpu": model, "kind": "port", "sample": sample}
     # direct: rows are independent, time a slice of the targets against all sources
     ns = min(n, 32768)
     sub = buf[:, :ns].copy()
@@ -123,12 +222,37 @@ def cpu_baseline(args, n):
     o.direct3(sub[0], par, threads=cores)
     dt = time.perf_counter() - t0
     rate = ns * ns / dt                     # pair interactions / s
-    return {"value": rate / n, "unit": "particle-steps/s", "cores": cores, "kind": "port",
+    return {"value": rate / n, "unit": "particle-steps/s", "cores": cores, "cpu": model, "kind": "port",
             "sample": "direct3 on N=%d (pair rate %.3g/s scaled to N=%d), %d std::threads" % (ns, rate, n, cores)}
+
+
+def cli_leg(n, order):
+    """Throughput of the drop-in binary itself: wall time of `nbco3 -n N -p P -iters K` for two K (one snapshot each, at
+    iteration 0), differenced so that process start-up, the host-side init and the snapshot drop out."""
+    import tempfile
+    exe = os.path.join(ROOT, "coulomb_oscillators_amd", "host", "nbco3")
+    if not os.path.exists(exe):
+        return None
+    k1, k2 = 50, 350
+    walls = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for k in (k1, k2):
+            t0 = time.perf_counter()
+            r = subprocess.run([exe, "-n", str(n), "-p", str(order), "-iters", str(k), "-steps", "100000", "-o", tmp],
+                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=900)
+            walls.append(time.perf_counter() - t0)
+            if r.returncode != 0:
+                return {"error": r.stderr[-300:]}
+    per_iter = (walls[1] - walls[0]) / (k2 - k1)
+    return {"command": "nbco3 -n %d -p %d -iters {%d,%d} -steps 100000 (tree_steps 8, m2l_first: the reference GPU driver's defaults)" % (n, order, k1, k2),
+            "wall_s": walls, "ms_per_step": 1e3 * per_iter, "cli_particle_steps_per_s": n / per_iter}
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))        # nothing below has run: no torch import, no GPU call in this process
+
     import torch
     import torch.distributed as dist
     from coulomb_oscillators_amd import (Engine, EVAL_DIRECT, EVAL_FMM_KDTREE, EVAL_FMM_TRACELESS, INTEG_LEAPFROG, DomainRun,
@@ -149,48 +273,16 @@ def main():
         torch.cuda.set_device(0)
     n = args.n
     sharded = world > 1 and args.workload == "fmm_kd"
-    n_sys = world * n if sharded else n          # particles of ONE physical system
-    # every rank draws n particles of the same Gaussian ball with its own seed; sharded run: their union is the
-    # N = world * n system, the kd-domains are cut by the first partition
-    buf = gaussian_ball(n, 20240807 + rank)
-    par = coulomb_params(n_sys)
-    d = torch.from_numpy(buf).cuda()
-    prm = torch.from_numpy(par).cuda()
-
     kind = {"fmm_kd": EVAL_FMM_KDTREE, "fmm_oct": EVAL_FMM_TRACELESS, "direct": EVAL_DIRECT}[args.workload]
     if args.far_fp64 and args.workload != "fmm_oct":
         raise SystemExit("--far-fp64 needs --workload fmm_oct")
-    eng = Engine(fmm_order=args.order, unsort=0, tree_steps=args.tree_steps, sync=0, far_fp64=int(args.far_fp64), dens_inhom=args.dens_inhom)
     dom = "direct" if args.workload == "direct" else "p2p"
-    run = None
-    if sharded:
-        run = DomainRun(eng, n_sys, TorchComm(), rebalance=args.rebalance)
-        run.partition(d[0].reshape(-1), d[1].reshape(-1))
 
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-
-    if sharded:
-        run.force(prm)                          # precompute accelerations (main3.cu:836-839)
-        step = lambda: run.leapfrog(prm, args.dt)
-    else:
-        eng.compute_force(kind, d, n, prm)
-        step = lambda: eng.integrate(INTEG_LEAPFROG, kind, d, n, prm, args.dt)
-    for _ in range(args.warmup):
-        step()
-    eng.profile(True if args.profile_all else [dom])
-    eng.profile_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof = eng.profile_get()
-    eng.profile(False)
 
     def reduce(x, op):
         if world == 1:
@@ -199,7 +291,42 @@ def main():
         dist.all_reduce(t, op=op)
         return float(t.item())
 
-    elapsed = reduce(elapsed, dist.ReduceOp.MAX)
+    def timed_run(n_local, steps, warmup, profile):
+        """warm-up, then `steps` leapfrog steps between two barriers; (elapsed max over ranks, engine, run, state, profile)"""
+        n_sys = world * n_local if sharded else n_local      # particles of ONE physical system
+        # every rank draws n_local particles of the same Gaussian ball from its own stream; sharded run: their union is the
+        # N = world * n_local system, the kd-domains are cut by the first partition
+        buf = gaussian_ball(n_local, rank)
+        d = torch.from_numpy(buf).cuda()
+        prm = torch.from_numpy(coulomb_params(n_sys)).cuda()
+        eng = Engine(fmm_order=args.order, unsort=0, tree_steps=args.tree_steps, sync=0, far_fp64=int(args.far_fp64), dens_inhom=args.dens_inhom)
+        run = None
+        if sharded:
+            run = DomainRun(eng, n_sys, TorchComm(), rebalance=args.rebalance)
+            run.partition(d[0].reshape(-1), d[1].reshape(-1))
+            run.force(prm)                          # precompute accelerations (main3.cu:836-839)
+            step = lambda: run.leapfrog(prm, args.dt)
+        else:
+            eng.compute_force(kind, d, n_local, prm)
+            step = lambda: eng.integrate(INTEG_LEAPFROG, kind, d, n_local, prm, args.dt)
+        for _ in range(warmup):
+            step()
+        if profile:
+            eng.profile(True if args.profile_all else [dom])
+            eng.profile_reset()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        elapsed = reduce(time.perf_counter() - t0, dist.ReduceOp.MAX)
+        prof = eng.profile_get() if profile else None
+        eng.profile(False)
+        state = run.buf if sharded else d
+        assert torch.isfinite(state).all(), "non-finite state after the timed steps"
+        return elapsed, eng, run, step, prof, n_sys
+
+    elapsed, eng, run, step, prof, n_sys = timed_run(n, args.steps, args.warmup, True)
 
     if args.workload == "fmm_kd":
         info = eng.kd_info()
@@ -216,10 +343,13 @@ def main():
     else:
         pairs_per_eval = n * n
         extra = {}
+    pairs_all = reduce(float(pairs_per_eval), dist.ReduceOp.SUM)
+    legs = not args.no_extra_legs
+
     # the reference's GPU driver rebuilds the kd-tree every tree_steps = 8 evaluations (fmm_cart3_kdtree.cuh:1619); the
     # headline value above rebuilds every step (CPU-driver semantics), this is the amortised figure beside it
     reuse = None
-    if world == 1 and args.workload == "fmm_kd" and args.tree_steps == 1:
+    if legs and world == 1 and args.workload == "fmm_kd" and args.tree_steps == 1:
         eng.set(tree_steps=8)
         for _ in range(8):
             step()
@@ -233,13 +363,30 @@ def main():
         reuse = {"tree_steps": 8, "steps": k8, "ms_per_step": 1e3 * e8 / k8, "value": n * k8 / e8, "unit": "particle-steps/s"}
         eng.set(tree_steps=1)
 
-    state = run.buf if sharded else d
-    assert torch.isfinite(state).all(), "non-finite state after the timed steps"
-    pairs_all = reduce(float(pairs_per_eval), dist.ReduceOp.SUM)
+    # the metric reads "N = 1M ... at 1/2/4/8 GPUs": ONE system of --particles cut into `world` kd-domains (strong scaling),
+    # next to the headline value, which keeps --particles per GPU (weak scaling)
+    strong = None
+    if legs and sharded and n % world == 0 and n // world >= 4096:
+        eng.close()
+        e_s, eng_s, run_s, _, _, nsys_s = timed_run(n // world, args.steps, args.warmup, False)
+        strong = {"scaling": "strong", "n_system": nsys_s, "n_per_gpu": n // world, "ms_per_step": 1e3 * e_s / args.steps,
+                  "value": nsys_s * args.steps / e_s, "unit": "particle-steps/s",
+                  "allgather_bytes_per_eval_per_gpu": run_s.exchange_bytes()}
+        eng_s.close()
 
     value = world * n * args.steps / elapsed
+    if args.workload == "fmm_kd":
+        wl = ("FMM-3D kd-tree p=%d, N=%d per GPU (one system of %d), leapfrog, Gaussian ball, tree rebuilt every %d step(s)"
+              % (args.order, n, n_sys, args.tree_steps))
+        metric = "particle-steps/sec (+ Gpair-interactions/sec), N=%d FMM-3D kd-tree p=%d, %d GPU(s)" % (n_sys, args.order, world)
+    elif args.workload == "fmm_oct":
+        wl = "FMM-3D uniform octree, traceless multipoles p=%d, N=%d per GPU, leapfrog, Gaussian ball" % (args.order, n)
+        metric = "particle-steps/sec, N=%d FMM-3D cartesian traceless (octree) p=%d, %d replica(s)" % (n, args.order, world)
+    else:
+        wl = "direct O(N^2) 3D, N=%d per GPU, leapfrog" % n
+        metric = "particle-steps/sec (+ Gpair-interactions/sec), N=%d direct O(N^2), %d replica(s)" % (n, world)
     out = {
-        "metric": "particle-steps/sec (+ Gpair-interactions/sec), N=1M FMM-3D p=6",
+        "metric": metric,
         "value": value,
         "unit": "particle-steps/s",
         "n_gpus": world,
@@ -253,11 +400,9 @@ def main():
         "data": "synthetic",
         "gpair_per_s": pairs_all * args.steps / elapsed / 1e9,
         "tree_reuse": reuse,
-        "config": {"workload": ("FMM-3D kd-tree p=%d, N=%d per GPU (one system of %d), leapfrog, Gaussian ball, tree rebuilt every %d step(s)"
-                                % (args.order, n, n_sys, args.tree_steps)) if args.workload == "fmm_kd"
-                   else ("FMM-3D uniform octree, traceless multipoles p=%d, N=%d per GPU, leapfrog, Gaussian ball" % (args.order, n))
-                   if args.workload == "fmm_oct" else "direct O(N^2) 3D, N=%d per GPU, leapfrog" % n,
-                   "n_per_gpu": n, "order": args.order, "dt": args.dt,
+        "strong": strong,
+        "config": {"workload": wl, "n_per_gpu": n, "order": args.order, "dt": args.dt,
+                   "init": "reference stream mt19937_64(%d + rank), discard %d (main3.cu:662-664)" % (REF_SEED, REF_DISCARD),
                    "parallelism": ("kd-domain sharding x%d, one all-gather of nodes + positions per evaluation" % world) if sharded
                    else ("single GPU" if world == 1 else "independent replicas x%d" % world), **extra},
     }
@@ -269,13 +414,45 @@ def main():
             kname = "p2p_kernel" if dom == "p2p" else "direct_tiles"
             default_cfg = world == 1 and n == 1048576 and args.order == 6
             traffic, src = measured_traffic(kname) if default_cfg else (None, None)
+            ceil_frac, ceil_src = measured_ceiling()
             out["roofline"] = {"bound": "valu_fp32", "kernel": kname,
                                "achieved": ach, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "B/launch",
-                               "traffic_source": src,
+                               "frac": ach / FP32_VECTOR_PEAK_TFLOPS,
+                               "frac_of_measured_ceiling": (ach / FP32_VECTOR_PEAK_TFLOPS / ceil_frac) if ceil_frac else None,
+                               "measured_ceiling_frac": ceil_frac, "measured_ceiling_source": ceil_src,
+                               "traffic": traffic, "traffic_unit": "B/launch", "traffic_source": src,
                                "pairs_per_launch": pairs_per_eval, "avg_launch_ms": avg_s * 1e3, "flop_per_pair": FLOP_PER_PAIR}
         if args.profile_all:
             out["phase_ms_per_step"] = {k: v[0] / args.steps for k, v in prof.items() if v[1]}
+    # further single-GPU legs, outside the timed region (rank 0 of a one-GPU run only)
+    if rank == 0 and world == 1 and legs and args.workload == "fmm_kd":
+        eng.close()
+        # BASELINE configs[2] by name: the uniform-octree evaluator with traceless multipoles on the same ball.  The cubic
+        # grid over the anisotropic ball leaves 625 of 32 768 cells occupied: an almost all-pairs P2P run.
+        try:
+            eo = Engine(fmm_order=args.order, unsort=0, sync=0)
+            bo = torch.from_numpy(gaussian_ball(n)).cuda()
+            po = torch.from_numpy(coulomb_params(n)).cuda()
+            eo.compute_force(EVAL_FMM_TRACELESS, bo, n, po)
+            torch.cuda.synchronize()
+            ko = 3
+            t2 = time.perf_counter()
+            for _ in range(ko):
+                eo.integrate(INTEG_LEAPFROG, EVAL_FMM_TRACELESS, bo, n, po, args.dt)
+            torch.cuda.synchronize()
+            eo_s = (time.perf_counter() - t2) / ko
+            oi = eo.oct_info()
+            out["octree_traceless"] = {"workload": "FMM-3D cartesian traceless (uniform octree) p=%d, N=%d, leapfrog, same ball" % (args.order, n),
+                                       "steps": ko, "ms_per_step": 1e3 * eo_s, "value": n / eo_s, "unit": "particle-steps/s", "L": oi.L}
+            eo.close()
+            del bo
+        except Exception as e:   # an extra leg must not take the headline down with it
+            out["octree_traceless"] = {"error": str(e)[:200]}
+        try:
+            out["cli"] = cli_leg(n, args.order)
+        except Exception as e:
+            out["cli"] = {"error": str(e)[:200]}
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline and args.workload != "fmm_oct":
             out["cpu_baseline"] = cpu_baseline(args, n)
         print(json.dumps(out))

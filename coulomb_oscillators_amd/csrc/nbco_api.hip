@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cmath>
 #include <new>
+#include <random>
 #include "fmm_tables.hpp"
 
 int nbco_ctx::reserve(DevBuf &b, size_t bytes)
@@ -557,6 +558,49 @@ int nbco_profile_get(nbco_ctx *c, int phase, double *total_ms, long long *launch
 	NBCO_TRY(drain_timers(c));
 	if (total_ms) *total_ms = c->timers[phase].total_ms;
 	if (launches) *launches = c->timers[phase].launches;
+	return NBCO_OK;
+}
+
+// ---- initial condition: initGA / initU of main3.cu:71-137 over the reference's generator (host only) --------------------------
+namespace {
+struct V3 { float x, y, z; };
+void centre_dist(V3 *d, long long n)   // main3.cu:71-80 (fp32 running sums, as there)
+{
+	V3 c{0, 0, 0};
+	for (long long i = 0; i < n; ++i) { c.x += d[i].x; c.y += d[i].y; c.z += d[i].z; }
+	c.x /= (float)n; c.y /= (float)n; c.z /= (float)n;
+	for (long long i = 0; i < n; ++i) { d[i].x -= c.x; d[i].y -= c.y; d[i].z -= c.z; }
+}
+void adjust_rms(V3 *d, long long n, V3 adj)   // main3.cu:82-92
+{
+	V3 s{0, 0, 0};
+	for (long long i = 0; i < n; ++i) { s.x += d[i].x * d[i].x; s.y += d[i].y * d[i].y; s.z += d[i].z * d[i].z; }
+	s.x = std::sqrt(s.x / (float)n); s.y = std::sqrt(s.y / (float)n); s.z = std::sqrt(s.z / (float)n);
+	const V3 f{adj.x / s.x, adj.y / s.y, adj.z / s.z};   // `data[i] *= adj / d`: the quotient first, then one product
+	for (long long i = 0; i < n; ++i) { d[i].x *= f.x; d[i].y *= f.y; d[i].z *= f.z; }
+}
+} // namespace
+
+int nbco_init_gaussian(float *host_state, long long n, const float *sx, const float *su, unsigned long long seed, unsigned long long discard,
+                       int uniform_positions)
+{
+	if (!host_state || !sx || !su || n <= 0) return NBCO_ERR_ARG;
+	std::mt19937_64 gen(seed);
+	gen.discard(discard);
+	std::normal_distribution<float> dist(0.f, 1.f);
+	for (long long i = 0; i < 6 * n; ++i) host_state[i] = dist(gen);   // all position deviates, then all velocity deviates (:121-123)
+	V3 *pos = reinterpret_cast<V3 *>(host_state), *vel = pos + n;
+	const V3 x{sx[0], sx[1], sx[2]}, u{su[0], su[1], su[2]};
+	for (long long i = 0; i < n; ++i) { pos[i].x *= x.x; pos[i].y *= x.y; pos[i].z *= x.z; }
+	for (long long i = 0; i < n; ++i) { vel[i].x *= u.x; vel[i].y *= u.y; vel[i].z *= u.z; }
+	centre_dist(pos, n); adjust_rms(pos, n, x);
+	centre_dist(vel, n); adjust_rms(vel, n, u);
+	if (uniform_positions)   // initU with a = -1, b = 1 (main3.cu:94-111)
+	{
+		std::uniform_real_distribution<float> dx(-1, 1), dy(-1, 1), dz(-1, 1);
+		for (long long i = 0; i < n; ++i) { pos[i].x = dx(gen); pos[i].y = dy(gen); pos[i].z = dz(gen); }
+		centre_dist(pos, n);
+	}
 	return NBCO_OK;
 }
 

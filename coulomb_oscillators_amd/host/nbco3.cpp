@@ -13,7 +13,6 @@
 #include <fstream>
 #include <iostream>
 #include <limits>
-#include <random>
 #include <string>
 #include <string_view>
 #include <vector>
@@ -32,40 +31,6 @@ namespace {
 	} while (0)
 
 struct V3 { SCAL x, y, z; };
-
-void centerDist(V3 *d, int n)   // main3.cu:71-80
-{
-	V3 c{0, 0, 0};
-	for (int i = 0; i < n; ++i) { c.x += d[i].x; c.y += d[i].y; c.z += d[i].z; }
-	c.x /= (SCAL)n; c.y /= (SCAL)n; c.z /= (SCAL)n;
-	for (int i = 0; i < n; ++i) { d[i].x -= c.x; d[i].y -= c.y; d[i].z -= c.z; }
-}
-
-void adjustRMS(V3 *d, int n, V3 adj)   // main3.cu:82-92
-{
-	V3 s{0, 0, 0};
-	for (int i = 0; i < n; ++i) { s.x += d[i].x * d[i].x; s.y += d[i].y * d[i].y; s.z += d[i].z * d[i].z; }
-	s.x = std::sqrt(s.x / (SCAL)n); s.y = std::sqrt(s.y / (SCAL)n); s.z = std::sqrt(s.z / (SCAL)n);
-	for (int i = 0; i < n; ++i) { d[i].x = d[i].x * adj.x / s.x; d[i].y = d[i].y * adj.y / s.y; d[i].z = d[i].z * adj.z / s.z; }
-}
-
-void initGA(V3 *data, int nBodies, V3 x, V3 u, std::mt19937_64 &gen)   // main3.cu:113-137
-{
-	std::normal_distribution<SCAL> dist((SCAL)0, (SCAL)1);
-	SCAL *s = reinterpret_cast<SCAL *>(data);
-	for (long long i = 0; i < 6LL * nBodies; ++i) s[i] = dist(gen);
-	for (int i = 0; i < nBodies; ++i) { data[i].x *= x.x; data[i].y *= x.y; data[i].z *= x.z; }
-	for (int i = nBodies; i < 2 * nBodies; ++i) { data[i].x *= u.x; data[i].y *= u.y; data[i].z *= u.z; }
-	centerDist(data, nBodies); adjustRMS(data, nBodies, x);
-	centerDist(data + nBodies, nBodies); adjustRMS(data + nBodies, nBodies, u);
-}
-
-void initU(V3 *data, int nBodies, std::mt19937_64 &gen)   // main3.cu:94-111 with a = -1, b = 1
-{
-	std::uniform_real_distribution<SCAL> dx(-1, 1), dy(-1, 1), dz(-1, 1);
-	for (int i = 0; i < nBodies; ++i) { data[i].x = dx(gen); data[i].y = dy(gen); data[i].z = dz(gen); }
-	centerDist(data, nBodies);
-}
 
 const char *kHelp =
     "This program comes with ABSOLUTELY NO WARRANTY.\n\n"
@@ -92,6 +57,156 @@ const char *kHelp =
     "  -xi <v>, -omega0 <wx> <wy>, -x <sx> <sy> <sz>, -u <ux> <uy> <uz>   physical parameters.\n"
     "  -cpu, -cpu-threads <n>, -cacheline <n>   not available: this build is GPU (MI355X) only.\n";
 
+// device allocation that frees itself
+template <class T> struct DeviceArray
+{
+	T *ptr = nullptr;
+	explicit DeviceArray(size_t count) { HIPCHK(hipMalloc((void **)&ptr, count * sizeof(T))); }
+	~DeviceArray() { if (ptr) (void)hipFree(ptr); }
+	DeviceArray(const DeviceArray &) = delete;
+	DeviceArray &operator=(const DeviceArray &) = delete;
+};
+
+// One run of the program: the device state [pos | vel | acc], the parameter pack and the engine context, with the three
+// modes of main3.cu:707-874 as member functions.
+struct Session
+{
+	int n;
+	DeviceArray<SCAL> state, par, ref_acc;
+	bool have_ref = false;
+
+	Session(const nbco_opts &o, int n_, const std::vector<float> &host, const SCAL (&p)[6]) : n(n_), state(9 * (size_t)n_), par(6), ref_acc(3 * (size_t)n_)
+	{
+		upload(host);
+		HIPCHK(hipMemcpy(par.ptr, p, sizeof p, hipMemcpyHostToDevice));
+		init(o);
+	}
+	~Session() { nbco_destroy(ctx()); ctx() = nullptr; }
+
+	void upload(const std::vector<float> &host) { HIPCHK(hipMemcpy(state.ptr, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice)); }   // acc not copied
+	SCAL *acc() { return state.ptr + 6 * (size_t)n; }
+	nbco_opts opts() const { nbco_opts cur; nbco_get_opts(ctx(), &cur); return cur; }
+	template <class F> void change(F &&f) { nbco_opts cur = opts(); f(cur); init(cur); }
+
+	// seconds per evaluation: one untimed call, then batches of 1, 2, 4, ... calls until min_seconds have passed (main3.cu:707-735)
+	SCAL seconds_per_evaluation(SCAL min_seconds)
+	{
+		compute_force(fmm_cart3_kdtree, state.ptr, n, par.ptr);
+		long long calls = 0;
+		SCAL elapsed = 0;
+		const auto t0 = steady_clock::now();
+		for (long long batch = 1; calls == 0 || elapsed < min_seconds; batch *= 2)
+		{
+			for (long long i = 0; i < batch; ++i) compute_force(fmm_cart3_kdtree, state.ptr, n, par.ptr);
+			calls += batch;
+			elapsed = duration_cast<microseconds>(steady_clock::now() - t0).count() * (SCAL)1.e-6;
+		}
+		return elapsed / (SCAL)calls;
+	}
+
+	// mean relative error of the FMM accelerations against the compensated direct sum (main3.cu:139-181).  With the caller's
+	// order kept (unsort) the direct sum is cached until `refresh`; otherwise the FMM runs first because it permutes the state.
+	SCAL mean_error(bool refresh)
+	{
+		float err = 0;
+		if (opts().unsort)
+		{
+			if (refresh || !have_ref)
+			{
+				compute_force(direct3, state.ptr, n, par.ptr);
+				check(nbco_copy(ctx(), ref_acc.ptr, acc(), n), "copy");
+				have_ref = true;
+			}
+			compute_force(fmm_cart3_kdtree, state.ptr, n, par.ptr);
+			check(nbco_mean_relerr(ctx(), acc(), ref_acc.ptr, n, &err), "mean_relerr");
+		}
+		else
+		{
+			compute_force(fmm_cart3_kdtree, state.ptr, n, par.ptr);
+			check(nbco_copy(ctx(), ref_acc.ptr, acc(), n), "copy");
+			compute_force(direct3, state.ptr, n, par.ptr);
+			check(nbco_mean_relerr(ctx(), ref_acc.ptr, acc(), n, &err), "mean_relerr");
+		}
+		return (SCAL)err;
+	}
+
+	// -accuracy: fastest (r, p) of the grid of main3.cu:739-740 whose error stays below the bound (main3.cu:737-788)
+	int search_parameters(SCAL bound)
+	{
+		struct Candidate { SCAL r; int p; SCAL seconds, error; };
+		static constexpr SCAL radii[] = {1.11f, 1.25f, 1.43f, 1.67f, 2.f, 2.5f, 3.f};
+		std::vector<Candidate> admissible;
+		std::cout << "Parameter optimization in progress, please wait" << std::flush;
+		for (SCAL r : radii)
+			for (int p = 1; p <= 6; ++p)
+			{
+				change([&](nbco_opts &c) { c.coll = 1; c.unsort = 1; c.tree_radius = r; c.fmm_order = p; });
+				const SCAL e = mean_error(false);
+				if (e < bound) admissible.push_back({r, p, seconds_per_evaluation(0), e});
+				std::cout << '.' << std::flush;
+			}
+		if (admissible.empty()) { std::cout << "\nOptimization failed!" << std::endl; return -1; }
+		const Candidate *best = &admissible.front();
+		for (const Candidate &c : admissible)
+			if (c.seconds < best->seconds) best = &c;
+		change([&](nbco_opts &c) { c.tree_radius = best->r; c.fmm_order = best->p; });
+		std::cout << "\nBest parameters: r = " << best->r << ", p = " << best->p << ", time = " << best->seconds << ", error = " << best->error << std::endl;
+		return 0;
+	}
+
+	// -test: time of one evaluation at the chosen order, then the error table for orders 1..10 (main3.cu:790-811)
+	void print_error_table(const std::vector<float> &host)
+	{
+		change([](nbco_opts &c) { c.unsort = 0; });
+		std::cout << opts().fmm_order << ": Average time: " << seconds_per_evaluation(1) << " [s]" << std::endl;
+		upload(host);   // the timing loop permuted the state: the table is quoted in the caller's order
+		for (int p = 1; p <= 10; ++p)
+		{
+			change([&](nbco_opts &c) { c.unsort = 1; c.fmm_order = p; });
+			std::cout << p << ": Relative error: " << mean_error(p == 1) << std::endl;
+		}
+	}
+
+	// -test2: error of successive evaluations while the particles move in the trap and the tree is reused (main3.cu:812-831)
+	void print_reuse_errors(SCAL dt)
+	{
+		change([](nbco_opts &c) { c.unsort = 0; });
+		const int evaluations = opts().tree_steps + 1;
+		for (int i = 0; i < evaluations; ++i)
+		{
+			const SCAL e = mean_error(false);
+			pre_symplectic_euler(add_elastic, state.ptr, n, par.ptr + 3, dt, step);
+			std::cout << "Relative error after " << i << " steps: " << e << std::endl;
+		}
+	}
+
+	// simulation: accelerations first, then nIters fused integrator steps; a snapshot [pos | vel] every nSteps iterations
+	// (main3.cu:832-874).  Evaluations are enqueued without a drain; the copy of a snapshot is what waits for the device.
+	int simulate(int scheme, SCAL dt, int nIters, int nSteps, const std::string &folder, std::vector<float> &host, size_t state_bytes)
+	{
+		change([](nbco_opts &c) { c.unsort = 0; c.sync = 0; });
+		check(nbco_force(ctx(), NBCO_EVAL_FMM_KDTREE, state.ptr, n, par.ptr, 1), "compute_force");
+		for (int iter = 0; iter < nIters; ++iter)
+		{
+			check(nbco_integrate(ctx(), scheme, NBCO_EVAL_FMM_KDTREE, state.ptr, n, par.ptr, (double)dt, 1.0, 1), "integrate");
+			if (iter % nSteps != 0) continue;
+			std::cout << iter << ' ' << std::flush;
+			check(nbco_sync(ctx()), "sync");
+			HIPCHK(hipMemcpy(host.data(), state.ptr, state_bytes, hipMemcpyDeviceToHost));   // acc not copied
+			std::ofstream fout(folder + "/out" + std::to_string(iter) + '_' + std::to_string(dt) + ".bin", std::ios::out | std::ios::binary);
+			if (!fout)
+			{
+				std::cerr << "Error: cannot write on output location. Check that \"" << folder << "\" folder exists. Create it if not." << std::endl;
+				return -1;
+			}
+			fout.write(reinterpret_cast<const char *>(host.data()), (std::streamsize)state_bytes);
+		}
+		check(nbco_sync(ctx()), "sync");
+		std::cout << std::endl;
+		return 0;
+	}
+};
+
 } // namespace
 
 int main(int argc, const char **argv)
@@ -105,7 +220,7 @@ int main(int argc, const char **argv)
 	std::string strout("out"), strin;
 	bool in = false, test = false, test2 = false, b_accuracy = false;
 	SCAL accuracy = (SCAL)0.001;
-	integrator_t symp_integ = leapfrog;
+	int scheme = NBCO_INTEG_LEAPFROG;   // main3.cu:238
 	SCAL xi = (SCAL)2.e-6;
 	V3 omega0{(SCAL)1.095, (SCAL)1.0, (SCAL)1.0}, x{(SCAL)0.003, (SCAL)0.001, (SCAL)0.01};
 	V3 u{omega0.x * x.x, omega0.y * x.y, omega0.z * x.z};
@@ -159,9 +274,9 @@ int main(int argc, const char **argv)
 			// the documented bare names are accepted as well
 			std::string_view v(argv[i + 1]);
 			std::string_view tail = v.size() > 1 ? v.substr(1) : std::string_view{};
-			if (v == "eu" || tail == "eu") symp_integ = symplectic_euler;
-			else if (v == "fr" || tail == "fr") symp_integ = forestruth;
-			else if (v == "pefrl" || tail == "pefrl") symp_integ = pefrl;
+			if (v == "eu" || tail == "eu") scheme = NBCO_INTEG_EULER;
+			else if (v == "fr" || tail == "fr") scheme = NBCO_INTEG_FORESTRUTH;
+			else if (v == "pefrl" || tail == "pefrl") scheme = NBCO_INTEG_PEFRL;
 			else { std::cerr << "Error: invalid argument to '-integ': " << argv[i + 1] << '\n'; return -1; }
 			++i;
 		}
@@ -244,32 +359,30 @@ int main(int argc, const char **argv)
 	}
 
 	// ---- state ---------------------------------------------------------------------------------------
-	std::vector<char> c_buf;
-	size_t cpyBytes = 0;
+	std::vector<float> host;   // [pos | vel] as the state files hold them; the accelerations never leave the device
 	if (in)
 	{
-		std::ifstream fin(strin, std::ios::in | std::ios::binary);
+		std::ifstream fin(strin, std::ios::in | std::ios::binary | std::ios::ate);
 		if (!fin) { std::cerr << "Error: cannot read from input location." << std::endl; return -1; }
-		fin.ignore(std::numeric_limits<std::streamsize>::max());
-		cpyBytes = (size_t)fin.gcount();
-		nBodies = (int)(cpyBytes / 2 / sizeof(V3));       // main3.cu:636
-		cpyBytes = 2 * (size_t)nBodies * sizeof(V3);
-		c_buf.resize(3 * (size_t)nBodies * sizeof(V3));
-		fin.clear();
+		const std::streamoff len = fin.tellg();
+		nBodies = (int)((size_t)len / 2 / sizeof(V3));       // main3.cu:636
+		host.resize(6 * (size_t)nBodies);
 		fin.seekg(0, std::ios::beg);
-		fin.read(c_buf.data(), (std::streamsize)cpyBytes);
+		fin.read(reinterpret_cast<char *>(host.data()), (std::streamsize)(host.size() * sizeof(float)));
 	}
 	else
 	{
-		cpyBytes = 2 * (size_t)nBodies * sizeof(V3);
-		c_buf.resize(3 * (size_t)nBodies * sizeof(V3));
-		std::mt19937_64 gen(5351550349027530206ULL);      // main3.cu:662-666
-		gen.discard(624 * 2);
-		initGA(reinterpret_cast<V3 *>(c_buf.data()), nBodies, x, u, gen);
-		if (test) initU(reinterpret_cast<V3 *>(c_buf.data()), nBodies, gen);
+		host.resize(6 * (size_t)nBodies);
+		const float sx[3]{x.x, x.y, x.z}, su[3]{u.x, u.y, u.z};
+		// main3.cu:662-666: mt19937_64(5351550349027530206), discard(624 * 2), initGA, and initU over the same stream for -test
+		if (nbco_init_gaussian(host.data(), nBodies, sx, su, NBCO_REF_SEED, NBCO_REF_DISCARD, test ? 1 : 0) != NBCO_OK)
+		{
+			std::cerr << "Error: cannot sample the initial state." << std::endl;
+			return -1;
+		}
 	}
 	if (nBodies <= 0) { std::cerr << "Error: no particles." << std::endl; return -1; }
-	SCAL *buf = reinterpret_cast<SCAL *>(c_buf.data());
+	const size_t state_bytes = host.size() * sizeof(float);
 
 	if (!test && !test2)
 	{
@@ -282,135 +395,16 @@ int main(int argc, const char **argv)
 		for (int i = 0; i < argc; ++i) farg << argv[i] << ' ';
 	}
 
-	SCAL par[6]{xi / (SCAL)nBodies, 0, 0, omega0.x * omega0.x, omega0.y * omega0.y, omega0.z * omega0.z};   // main3.cu:685-692
+	const SCAL par[6]{xi / (SCAL)nBodies, 0, 0, omega0.x * omega0.x, omega0.y * omega0.y, omega0.z * omega0.z};   // main3.cu:685-692
 
-	SCAL *d_buf = nullptr, *d_par = nullptr, *d_tmp = nullptr;
-	HIPCHK(hipMalloc((void **)&d_buf, c_buf.size()));
-	HIPCHK(hipMalloc((void **)&d_par, sizeof par));
-	HIPCHK(hipMemcpy(d_buf, buf, cpyBytes, hipMemcpyHostToDevice));   // acc not copied
-	HIPCHK(hipMemcpy(d_par, par, sizeof par, hipMemcpyHostToDevice));
-	init(o);
-
-	auto set_opts = [&](auto &&mod) { nbco_opts cur; nbco_get_opts(ctx(), &cur); mod(cur); init(cur); };
-
-	auto test_time = [&](SCAL min_loop = 0, int loop_n = 1) {   // main3.cu:707-735
-		compute_force(fmm_cart3_kdtree, d_buf, nBodies, d_par);
-		SCAL duration;
-		int loop_counter = 0;
-		auto begin = steady_clock::now();
-		do
-		{
-			for (int i = 0; i < loop_n; ++i) compute_force(fmm_cart3_kdtree, d_buf, nBodies, d_par);
-			auto end = steady_clock::now();
-			loop_counter += loop_n;
-			loop_n *= 2;
-			duration = duration_cast<microseconds>(end - begin).count() * (SCAL)1.e-6;
-		} while (duration < min_loop);
-		return duration / loop_counter;
-	};
-	// mean relative error of the FMM against the compensated direct sum (main3.cu:139-181, b_unsort case)
-	auto test_accuracy = [&](bool b_update) {
-		static bool have_ref = false;
-		VEC *acc = reinterpret_cast<VEC *>(d_buf) + 2 * (size_t)nBodies;
-		if (!d_tmp) HIPCHK(hipMalloc((void **)&d_tmp, sizeof(V3) * (size_t)nBodies));
-		nbco_opts cur;
-		nbco_get_opts(ctx(), &cur);
-		if (cur.unsort)
-		{
-			if (b_update || !have_ref)
-			{
-				compute_force(direct3, d_buf, nBodies, d_par);
-				check(nbco_copy(ctx(), d_tmp, &acc->x, nBodies), "copy");
-				have_ref = true;
-			}
-			compute_force(fmm_cart3_kdtree, d_buf, nBodies, d_par);
-			float err = 0;
-			check(nbco_mean_relerr(ctx(), &acc->x, d_tmp, nBodies, &err), "mean_relerr");
-			return (SCAL)err;
-		}
-		compute_force(fmm_cart3_kdtree, d_buf, nBodies, d_par);
-		check(nbco_copy(ctx(), d_tmp, &acc->x, nBodies), "copy");
-		compute_force(direct3, d_buf, nBodies, d_par);
-		float err = 0;
-		check(nbco_mean_relerr(ctx(), d_tmp, &acc->x, nBodies, &err), "mean_relerr");
-		return (SCAL)err;
-	};
-
-	if (b_accuracy)   // main3.cu:737-788
+	Session s(o, nBodies, host, par);
+	int rc = 0;
+	if (b_accuracy) rc = s.search_parameters(accuracy);
+	if (rc == 0)
 	{
-		const int search_p[] = {1, 2, 3, 4, 5, 6};
-		const SCAL search_r[] = {1.11f, 1.25f, 1.43f, 1.67f, 2.f, 2.5f, 3.f};
-		SCAL best_r = 0, best_time = FLT_MAX, best_accuracy = 0;
-		int best_p = 0;
-		std::cout << "Parameter optimization in progress, please wait" << std::flush;
-		for (SCAL r : search_r)
-			for (int p : search_p)
-			{
-				set_opts([&](nbco_opts &c) { c.coll = 1; c.unsort = 1; c.tree_radius = r; c.fmm_order = p; });
-				SCAL curr = test_accuracy(false);
-				if (curr < accuracy)
-				{
-					SCAL t = test_time();
-					if (t < best_time) { best_r = r; best_p = p; best_accuracy = curr; best_time = t; }
-				}
-				std::cout << '.' << std::flush;
-			}
-		if (best_time == FLT_MAX) { std::cout << "\nOptimization failed!" << std::endl; return -1; }
-		set_opts([&](nbco_opts &c) { c.tree_radius = best_r; c.fmm_order = best_p; });
-		std::cout << "\nBest parameters: r = " << best_r << ", p = " << best_p << ", time = " << best_time << ", error = " << best_accuracy << std::endl;
+		if (test) s.print_error_table(host);
+		else if (test2) s.print_reuse_errors(dt);
+		else rc = s.simulate(scheme, dt, nIters, nSteps, strout, host, state_bytes);
 	}
-
-	if (test)   // main3.cu:790-811
-	{
-		set_opts([](nbco_opts &c) { c.unsort = 0; });
-		nbco_opts cur;
-		nbco_get_opts(ctx(), &cur);
-		std::cout << cur.fmm_order << ": Average time: " << test_time(1) << " [s]" << std::endl;
-		HIPCHK(hipMemcpy(d_buf, buf, cpyBytes, hipMemcpyHostToDevice));   // restore the caller's order for the error table
-		for (int p = 1; p <= 10; ++p)
-		{
-			set_opts([&](nbco_opts &c) { c.unsort = 1; c.fmm_order = p; });
-			std::cout << p << ": Relative error: " << test_accuracy(p == 1) << std::endl;
-		}
-	}
-	else if (test2)   // main3.cu:812-831
-	{
-		set_opts([](nbco_opts &c) { c.unsort = 0; });
-		nbco_opts cur;
-		nbco_get_opts(ctx(), &cur);
-		for (int i = 0; i < cur.tree_steps + 1; ++i)
-		{
-			SCAL relerr = test_accuracy(false);
-			pre_symplectic_euler(add_elastic, d_buf, nBodies, d_par + 3, dt, step);
-			std::cout << "Relative error after " << i << " steps: " << relerr << std::endl;
-		}
-	}
-	else   // main3.cu:832-874
-	{
-		set_opts([](nbco_opts &c) { c.unsort = 0; });
-		compute_force(coulombOscillatorFMMKD3, d_buf, nBodies, d_par);
-		for (int iter = 0; iter < nIters; ++iter)
-		{
-			symp_integ(coulombOscillatorFMMKD3, d_buf, nBodies, d_par, dt, step, 1);
-			if (iter % nSteps == 0)
-			{
-				std::cout << iter << ' ' << std::flush;
-				HIPCHK(hipMemcpy(buf, d_buf, cpyBytes, hipMemcpyDeviceToHost));   // acc not copied
-				std::ofstream fout(strout + "/out" + std::to_string(iter) + '_' + std::to_string(dt) + ".bin", std::ios::out | std::ios::binary);
-				if (!fout)
-				{
-					std::cerr << "Error: cannot write on output location. Check that \"" << strout << "\" folder exists. Create it if not." << std::endl;
-					return -1;
-				}
-				fout.write(c_buf.data(), (std::streamsize)cpyBytes);
-			}
-		}
-		std::cout << std::endl;
-	}
-
-	nbco_destroy(ctx());
-	if (d_tmp) HIPCHK(hipFree(d_tmp));
-	HIPCHK(hipFree(d_buf));
-	HIPCHK(hipFree(d_par));
-	return 0;
+	return rc;
 }

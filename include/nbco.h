@@ -245,6 +245,17 @@ int nbco_profile_enable(nbco_ctx *c, int mask);     /* bit i: record a pair of e
 int nbco_profile_reset(nbco_ctx *c);
 int nbco_profile_get(nbco_ctx *c, int phase, double *total_ms, long long *launches);  /* syncs */
 
+/* ---- initial condition (host only, no GPU needed) ----------------------------------------------
+ * The reference's synthetic state: initGA (main3.cu:113-137) over std::mt19937_64(seed) after discard(discard)
+ * (main3.cu:662-664: seed 5351550349027530206, discard 1248) -- 3n position deviates then 3n velocity deviates
+ * from std::normal_distribution<float>, scaled by sigma_x / sigma_u per axis, centred and rescaled to exactly those
+ * RMS values; with uniform_positions != 0 the positions are then redrawn uniformly in [-1, 1)^3 and centred, as
+ * the -test mode does (initU, main3.cu:94-111,666).  host_state = [pos n x 3 | vel n x 3] floats in HOST memory. */
+#define NBCO_REF_SEED 5351550349027530206ULL
+#define NBCO_REF_DISCARD 1248ULL
+int nbco_init_gaussian(float *host_state, long long n, const float *sigma_x3, const float *sigma_u3,
+                       unsigned long long seed, unsigned long long discard, int uniform_positions);
+
 /* ---- operator tables (host only, no GPU needed) ------------------------------------------------
  * Copies the flattened coefficient / index table `name` for expansion order `order` into `out`
  * (int32 or float32 elements, at most `cap` of them) and stores the element count in *count.

@@ -1232,7 +1232,8 @@ void oracle_init_reference(real* buf, int n, const real* sx, const real* su, int
 		for (int i = 0; i < m; ++i) s = s + vec3{d[i].x * d[i].x, d[i].y * d[i].y, d[i].z * d[i].z};
 		s = s / (real)m;
 		s = {std::sqrt(s.x), std::sqrt(s.y), std::sqrt(s.z)};
-		for (int i = 0; i < m; ++i) { vec3 q{d[i].x * adj.x, d[i].y * adj.y, d[i].z * adj.z}; d[i] = {q.x / s.x, q.y / s.y, q.z / s.z}; }
+		const vec3 f{adj.x / s.x, adj.y / s.y, adj.z / s.z};   // main3.cu:91 `data[i] *= adj / d`: quotient first, then one product per element
+		for (int i = 0; i < m; ++i) d[i] = {d[i].x * f.x, d[i].y * f.y, d[i].z * f.z};
 	};
 	scale(data, n, X);
 	scale(data + n, n, U);

@@ -47,3 +47,23 @@ def test_engine_fails_loudly_without_gpu(engine_lib):
     lib = ctypes.CDLL(engine_lib)
     ctx = ctypes.c_void_p()
     assert lib.nbco_create(ctypes.byref(ctx), None) != 0
+
+
+def test_init_gaussian_is_the_reference_stream(engine_lib, oracle32):
+    """nbco_init_gaussian (host only): initGA / initU of main3.cu:94-137 over mt19937_64(5351550349027530206), discard 1248 --
+    bit-identical to the oracle's restatement, centred, RMS exactly sigma."""
+    import numpy as np
+    lib = ctypes.CDLL(engine_lib)
+    lib.nbco_init_gaussian.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulonglong,
+                                       ctypes.c_ulonglong, ctypes.c_int]
+    sx = np.array([0.003, 0.001, 0.01], dtype=np.float32)
+    su = np.array([1.095, 1.0, 1.0], dtype=np.float32) * sx
+    for n, uniform in ((4096, 0), (30001, 0), (4096, 1)):
+        got = np.zeros((2, n, 3), dtype=np.float32)
+        assert lib.nbco_init_gaussian(got.ctypes.data, n, sx.ctypes.data, su.ctypes.data, 5351550349027530206, 1248, uniform) == 0
+        want = oracle32.init_reference(n, test_mode=bool(uniform))
+        assert np.array_equal(got, want[:2])
+        if not uniform:
+            assert np.allclose(np.sqrt((got[0].astype(np.float64) ** 2).mean(0)), sx, rtol=1e-5)
+            assert np.abs(got[0].mean(0)).max() < 1e-6 * sx.max() * 10
+    assert lib.nbco_init_gaussian(None, 10, sx.ctypes.data, su.ctypes.data, 1, 0, 0) != 0

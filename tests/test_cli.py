@@ -85,3 +85,37 @@ def test_cli_test_mode_reproduces_reference_table(nbco3):
     for g, w in zip(got, want):
         assert 0.5 * w < g < 1.6 * w, (got, want)
     assert "Average time:" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cli_reuse_mode_errors_stay_at_truncation_level(nbco3):
+    """`nbco3 -n 8192 -p 4 -test2` (main3.cu:812-831): tree_steps + 1 evaluations while the particles move in the trap and the
+    tree is reused; every printed error stays at the order-4 truncation level."""
+    r = run(nbco3, "-n", "8192", "-p", "4", "-test2")
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("Relative error after")]
+    assert [int(l.split()[3]) for l in lines] == list(range(9))          # tree_steps = 8 (constants.cuh:45) -> 9 evaluations
+    errs = [float(l.split(":")[1]) for l in lines]
+    assert all(0 < e < 5e-2 for e in errs), errs
+    assert max(errs) < 3 * errs[0], errs                                   # reuse does not degrade the first evaluation's error much
+
+
+@pytest.mark.gpu
+def test_cli_accuracy_search_stays_inside_the_grid(nbco3, tmp_path):
+    """`nbco3 -n 4096 -accuracy 1e-2 -iters 0` (main3.cu:737-788): prints the best (r, p) of the search grid :739-740 and an
+    error below the bound, then runs the simulation with them."""
+    out = tmp_path / "out"
+    out.mkdir()
+    r = run(nbco3, "-n", "4096", "-accuracy", "1e-2", "-iters", "0", "-steps", "1", "-o", str(out))
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.count(".") >= 42                                        # one dot per grid point (7 radii x 6 orders)
+    best = [l for l in r.stdout.splitlines() if l.startswith("Best parameters:")]
+    assert len(best) == 1, r.stdout
+    f = dict(kv.split(" = ") for kv in best[0][len("Best parameters: "):].split(", "))
+    assert float(f["r"]) in [pytest.approx(v) for v in (1.11, 1.25, 1.43, 1.67, 2, 2.5, 3)]
+    assert int(f["p"]) in range(1, 7)
+    assert 0 < float(f["error"]) < 1e-2 and float(f["time"]) > 0
+    assert os.path.getsize(out / "out0_0.000500.bin") == 2 * 4096 * 12
+    # an impossible bound fails the way the reference does
+    r = run(nbco3, "-n", "4096", "-accuracy", "1e-12", "-o", str(out))
+    assert r.returncode != 0 and "Optimization failed!" in r.stdout
