@@ -1090,8 +1090,10 @@ __global__ __launch_bounds__(kBlock) void list_fill_kernel(const int2 *__restric
                                                            long long capR, int sub, int self0, int nself, int shift, const int *__restrict__ start,
                                                            uint64_t *__restrict__ keys, const int *__restrict__ chunk_off, int ntargets,
                                                            const int *__restrict__ leaf_index, const int *__restrict__ leaf_mult,
-                                                           int4 *__restrict__ chunk)
+                                                           int4 *__restrict__ chunk, int pidmode)
 {
+	// pidmode (mutual near field): an entry is (source << 32 | index of its unordered pair), so that after the per-target sort the
+	// two directions of a pair still know each other; self entries carry 0xFFFFFFFF
 	// P2P list: the work-unit table of the pair kernel only needs the two prefix sums, like the fill: same launch.
 	// chunk record: {first particle of the target leaf, first entry, end entry, particles of the target leaf}
 	if (chunk)
@@ -1113,14 +1115,22 @@ __global__ __launch_bounds__(kBlock) void list_fill_kernel(const int2 *__restric
 			const long long slot = region_slot(pref, capR, i);
 			const int2 p = pairs[slot], r = ranks[slot];
 			const uint64_t a = (uint64_t)(p.x - sub), b = (uint64_t)(p.y - sub);
-			if (r.x >= 0) keys[start[a] + r.x] = (a << shift) | b;
-			if (r.y >= 0) keys[start[b] + r.y] = (b << shift) | a;
+			if (pidmode)
+			{
+				if (r.x >= 0) keys[start[a] + r.x] = (b << 32) | (uint64_t)(uint32_t)i;
+				if (r.y >= 0) keys[start[b] + r.y] = (a << 32) | (uint64_t)(uint32_t)i;
+			}
+			else
+			{
+				if (r.x >= 0) keys[start[a] + r.x] = (a << shift) | b;
+				if (r.y >= 0) keys[start[b] + r.y] = (b << shift) | a;
+			}
 		}
 		else
 		{
 			// self entries of the domain's own leaves: counted first (traverse_init_kernel), so they own slot 0
 			const uint64_t t = (uint64_t)(self0 + (i - npairs));
-			keys[start[t]] = (t << shift) | t;
+			keys[start[t]] = pidmode ? ((t << 32) | 0xFFFFFFFFull) : ((t << shift) | t);
 		}
 	}
 }
@@ -1134,26 +1144,58 @@ __global__ __launch_bounds__(kBlock) void list_fill_kernel(const int2 *__restric
 constexpr int kP2PChunk = NBCO_P2P_CHUNK;   // source leaves per near-field work unit (see the P2P section)
 // DESC: the list is the P2P list -- also emit the source descriptor (first particle, multiplicity) of every sorted entry,
 // so the pair kernel does no dependent index -> mult -> position loads
+// what the per-target sort of the P2P list also produces for the mutual near-field kernel (k_p2p.hpp); desc4 == nullptr: off
+struct MutualLists
+{
+	int4 *desc4 = nullptr;            // per sorted entry: {first particle of the source leaf, its multiplicity, pair index, code}
+	int4 *chunk = nullptr;            // work units {first particle of the target leaf, first entry, end entry, multiplicity}
+	const int *chunk_off = nullptr;   // chunk slots of target t: [chunk_off[t], chunk_off[t + 1])
+	int2 *sec_range = nullptr;        // per target: its entries whose sums other waves deliver (code 2)
+	int self0 = 0, nself = 0;         // leaves of the own kd-domain
+};
 template <bool DESC>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void list_segsort_kernel(const int *__restrict__ start, int ntargets, uint64_t *in, uint64_t *out, int shift,
                                                               const int *__restrict__ leaf_index, const int *__restrict__ leaf_mult,
-                                                              int2 *__restrict__ desc)
+                                                              int2 *__restrict__ desc, MutualLists mu)
 {
 	__shared__ unsigned digit_off[kBlock / 64][256];   // long ranges only: per-wave digit offsets of the radix passes
 	const uint64_t smask = (1ull << shift) - 1;
-	auto emit = [&](int slot, uint64_t key) {
-		out[slot] = key;
-		if (DESC)
+	// mutual near field (mu.desc4 set): entries are (source << 32 | pair index); the sorted list is written in the usual
+	// (target << shift | source) form, and every entry gets a descriptor {first particle, multiplicity, pair index, code}
+	// with code 1 = this target's wave evaluates the pair for both leaves (source after target), 2 = the source's wave does
+	// (source before target), 0 = one direction only (the leaf itself, or a source outside the kd-domain [self0, self0 + nself))
+	const int lowbit = (DESC && mu.desc4) ? 32 : 0;
+	auto emit = [&](int t, int slot, uint64_t key) {
+		const int src = (int)((key >> lowbit) & smask);
+		if (DESC && mu.desc4)
 		{
-			const int src = (int)(key & smask);
-			desc[slot] = make_int2(leaf_index[src], leaf_mult[src]);
+			out[slot] = ((uint64_t)t << shift) | (uint64_t)src;
+			const int code = (src == t || src < mu.self0 || src >= mu.self0 + mu.nself) ? 0 : (src > t ? 1 : 2);
+			mu.desc4[slot] = make_int4(leaf_index[src], leaf_mult[src], (int)(uint32_t)key, code);
+			return;
 		}
+		out[slot] = key;
+		if (DESC) desc[slot] = make_int2(leaf_index[src], leaf_mult[src]);
+	};
+	// mutual near field: work units of target t once its list is sorted.  Sorted order = [sources of lower kd-domains: nf
+	// entries][own sources before t: delivered by their waves][t itself][sources after t]; the work entries (all but the
+	// second group) are dealt to the target's chunk slots in equal shares; a unit that spans the gap skips it by code.
+	auto finish_target = [&](int t, int s, int cnt, int nf, int nq, int lane) {
+		const int o = mu.chunk_off[t], n = mu.chunk_off[t + 1] - o;
+		const int w = nf + (cnt - nq), per = n > 0 ? (w + n - 1) / n : 0;
+		const int ind = leaf_index[t], mlt = leaf_mult[t];
+		for (int i = lane; i < n; i += 64)
+		{
+			const int jb = min(i * per, w), je = min((i + 1) * per, w);
+			mu.chunk[o + i] = make_int4(ind, s + (jb < nf ? jb : jb - nf + nq), s + (je <= nf ? je : je - nf + nq), mlt);
+		}
+		if (lane == 0) mu.sec_range[t] = make_int2(s + nf, s + nq);
 	};
 	const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	// ranges of up to 64 * J entries: every lane keeps J entries in registers and ranks them against all entries of the
 	// range, which are broadcast one by one with v_readlane (an SGPR lane index: the loop is scalar, no LDS or memory
 	// latency inside).  All entries of a range share the target, so comparing the 32-bit source indices orders the keys.
-	auto rank_in_registers = [&](auto jtag, int s, int cnt) {
+	auto rank_in_registers = [&](auto jtag, int t, int s, int cnt) {
 		constexpr int J = decltype(jtag)::value;
 		uint64_t key[J];
 		unsigned src[J];
@@ -1162,7 +1204,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 		for (int j = 0; j < J; ++j)
 		{
 			key[j] = lane + 64 * j < cnt ? in[s + lane + 64 * j] : ~0ull;
-			src[j] = (unsigned)(key[j] & smask);
+			src[j] = (unsigned)((key[j] >> lowbit) & smask);
 			rank[j] = 0;
 		}
 #pragma unroll
@@ -1176,21 +1218,33 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 				for (int j = 0; j < J; ++j) rank[j] += other < src[j] ? 1 : 0;
 			}
 		}
+		int nf = 0, nq = 0;
+		if (DESC && mu.desc4)
+		{
+#pragma unroll
+			for (int j = 0; j < J; ++j)
+			{
+				const bool valid = lane + 64 * j < cnt;
+				nf += __popcll(__ballot(valid && (int)src[j] < mu.self0));
+				nq += __popcll(__ballot(valid && (int)src[j] < t));
+			}
+		}
 #pragma unroll
 		for (int j = 0; j < J; ++j)
-			if (lane + 64 * j < cnt) emit(s + rank[j], key[j]);
+			if (lane + 64 * j < cnt) emit(t, s + rank[j], key[j]);
+		if (DESC && mu.desc4) finish_target(t, s, cnt, nf, nq, lane);
 	};
 	for (int t = blockIdx.x * (kBlock / 64) + wv; t < ntargets; t += gridDim.x * (kBlock / 64))
 	{
 		// wave-uniform by construction; telling the compiler so keeps the loops scalar
 		const int s = __builtin_amdgcn_readfirstlane(start[t]), cnt = __builtin_amdgcn_readfirstlane(start[t + 1]) - s;
-		if (cnt <= 64) rank_in_registers(std::integral_constant<int, 1>{}, s, cnt);
-		else if (cnt <= 128) rank_in_registers(std::integral_constant<int, 2>{}, s, cnt);
-		else if (cnt <= 192) rank_in_registers(std::integral_constant<int, 3>{}, s, cnt);
-		else if (cnt <= 256) rank_in_registers(std::integral_constant<int, 4>{}, s, cnt);
-		else if (cnt <= 320) rank_in_registers(std::integral_constant<int, 5>{}, s, cnt);
-		else if (cnt <= 384) rank_in_registers(std::integral_constant<int, 6>{}, s, cnt);
-		else if (cnt <= 512) rank_in_registers(std::integral_constant<int, 8>{}, s, cnt);
+		if (cnt <= 64) rank_in_registers(std::integral_constant<int, 1>{}, t, s, cnt);
+		else if (cnt <= 128) rank_in_registers(std::integral_constant<int, 2>{}, t, s, cnt);
+		else if (cnt <= 192) rank_in_registers(std::integral_constant<int, 3>{}, t, s, cnt);
+		else if (cnt <= 256) rank_in_registers(std::integral_constant<int, 4>{}, t, s, cnt);
+		else if (cnt <= 320) rank_in_registers(std::integral_constant<int, 5>{}, t, s, cnt);
+		else if (cnt <= 384) rank_in_registers(std::integral_constant<int, 6>{}, t, s, cnt);
+		else if (cnt <= 512) rank_in_registers(std::integral_constant<int, 8>{}, t, s, cnt);
 		else
 		{
 			// Long range (an outlier's leaf can be paired with most of the tree: tens of thousands of entries): the wave sorts
@@ -1199,7 +1253,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 			unsigned *off = digit_off[wv];
 			uint64_t *src = in + s, *dst = out + s;
 			const uint64_t below = (1ull << lane) - 1ull;
-			for (int bit = 0; bit < shift; bit += 8)
+			for (int bit = lowbit; bit < lowbit + shift; bit += 8)
 			{
 				for (int b = lane; b < 256; b += 64) off[b] = 0u;
 				wave_lds_sync();
@@ -1240,7 +1294,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 				uint64_t *t2 = src; src = dst; dst = t2;
 			}
 			// `src` holds the sorted range now
-			for (int i = lane; i < cnt; i += 64) emit(s + i, src[i]);
+			int nf = 0, nq = 0;
+			for (int i0 = 0; i0 < cnt; i0 += 64)
+			{
+				const int i = i0 + lane;
+				const uint64_t key = i < cnt ? src[i] : 0ull;
+				if (i < cnt) emit(t, s + i, key);
+				const int sv = (int)((key >> lowbit) & smask);
+				nf += __popcll(__ballot(i < cnt && sv < mu.self0));
+				nq += __popcll(__ballot(i < cnt && sv < t));
+			}
+			if (DESC && mu.desc4) finish_target(t, s, cnt, nf, nq, lane);
 		}
 	}
 }
@@ -1391,7 +1455,7 @@ static int exclusive_scan_counts_and_chunks(nbco_ctx *c, const unsigned *cnt, in
 static int build_directed_list(nbco_ctx *c, const int2 *pairs, const int2 *ranks, const int *pref_dev, long long capR, long long npairs_hint, int sub,
                                int self0, int nself, int ntargets, int shift, unsigned *cnt, int *start, uint64_t *keys_tmp, uint64_t *keys_out,
                                DevBuf &scan_tmp, const int *leaf_index = nullptr, const int *leaf_mult = nullptr, int2 *desc = nullptr,
-                               int *chunk_off = nullptr, int4 *chunks = nullptr)
+                               int *chunk_off = nullptr, int4 *chunks = nullptr, const MutualLists *mutual = nullptr)
 {
 	hipStream_t st = c->stream;   // (the self entries were added to cnt by traverse_finish_kernel)
 	if (desc)
@@ -1402,13 +1466,18 @@ static int build_directed_list(nbco_ctx *c, const int2 *pairs, const int2 *ranks
 	else
 		NBCO_TRY(exclusive_scan_ints(c, (int *)cnt, start, (size_t)(ntargets + 1), scan_tmp));
 	hipLaunchKernelGGL(list_fill_kernel, dim3(grid1d(npairs_hint + nself)), dim3(kBlock), 0, st, pairs, ranks, pref_dev, capR, sub, self0, nself, shift,
-	                   (const int *)start, keys_tmp, (const int *)chunk_off, ntargets, leaf_index, leaf_mult, desc ? chunks : (int4 *)nullptr);
+	                   (const int *)start, keys_tmp, (const int *)chunk_off, ntargets, leaf_index, leaf_mult,
+	                   (desc && !mutual) ? chunks : (int4 *)nullptr, mutual ? 1 : 0);
 	if (desc)
+	{
+		MutualLists mu;
+		if (mutual) { mu = *mutual; mu.chunk = chunks; mu.chunk_off = chunk_off; mu.self0 = self0; mu.nself = nself; }
 		hipLaunchKernelGGL(list_segsort_kernel<true>, dim3((ntargets + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, (const int *)start, ntargets,
-		                   keys_tmp, keys_out, shift, leaf_index, leaf_mult, desc);
+		                   keys_tmp, keys_out, shift, leaf_index, leaf_mult, desc, mu);
+	}
 	else
 		hipLaunchKernelGGL(list_segsort_kernel<false>, dim3((ntargets + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, (const int *)start,
-		                   ntargets, keys_tmp, keys_out, shift, (const int *)nullptr, (const int *)nullptr, (int2 *)nullptr);
+		                   ntargets, keys_tmp, keys_out, shift, (const int *)nullptr, (const int *)nullptr, (int2 *)nullptr, MutualLists{});
 	NBCO_HIP(hipGetLastError());
 	return NBCO_OK;
 }
@@ -1570,7 +1639,7 @@ static int kd_build_upward(nbco_ctx *c, const float *p, long long n, int L, cons
 struct KdCounts
 {
 	long long np2p = 0, nm2l = 0;
-	int sel_overflow = 0;
+	int sel_overflow = 0, react_overflow = 0;
 };
 
 // phase 0: everything; 1: up to and including the traversal (its flags on their way to the host); 2: the rest, for a tree on
@@ -1582,6 +1651,7 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 	const int P = c->o.fmm_order;
 	const int L = tv.L, ntot = tv.ntot, nleaf = 1 << L, beg = kd_beg(L);
 	const int offL = tl_off(P + 1);
+	out = KdCounts{};
 	const int self0 = dm.g << (L - dm.d), nself = 1 << (L - dm.d);   // the domain's own leaves
 	hipStream_t st = c->stream;
 
@@ -1649,6 +1719,23 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 	const long long nm2l_hint = c->hint_nm2l > 0 ? std::min(cap, c->hint_nm2l + c->hint_nm2l / 4 + 1024) : cap;
 	const long long dp2p_hint = 2 * np2p_hint + nself;
 	const long long max_chunks = c->o.coll ? dp2p_cap / kP2PChunk + nself : 0, chunks_hint = dp2p_hint / kP2PChunk + nself;
+	// Near field in the mutual (Newton III) form when the leaves fill two 16-lane rows (k_p2p.hpp).  Its reaction records are
+	// indexed by the unordered pair: one per pair of the P2P list, sized from the previous evaluation's count -- the first
+	// evaluation of a context waits for the traversal's count instead (once), and an evaluation whose list outgrew the buffer
+	// is repeated by the caller (the kernels never write beyond it).
+	const bool mutual = c->o.coll && c->o.p2p_mutual && mlt_max > 16 && mlt_max <= 32;
+	long long react_cap = 0;
+	if (mutual)
+	{
+		if (c->hint_np2p <= 0)
+		{
+			NBCO_HIP(hipEventSynchronize(c->ev_flags));
+			c->hint_np2p = c->h_flags[0];
+			c->hint_nm2l = c->h_flags[1];
+		}
+		react_cap = std::min(cap, c->hint_np2p + c->hint_np2p / 4 + 1024);
+		NBCO_TRY(c->reserve(c->p2p_react, sizeof(float4) * kReactStride * (size_t)react_cap));
+	}
 	// ---- directed sorted lists --------------------------------------------------------------------------
 	{
 		PhaseScope ph(c, NBCO_PH_LISTS);
@@ -1664,12 +1751,20 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		if (c->o.coll)
 		{
 			unsigned *cp = c->list_cnt.as<unsigned>();
-			NBCO_TRY(c->reserve(c->p2p_desc, sizeof(int2) * (size_t)(dp2p_cap + 1)));
+			NBCO_TRY(c->reserve(c->p2p_desc, (mutual ? sizeof(int4) : sizeof(int2)) * (size_t)(dp2p_cap + 1)));
+			MutualLists mu;
+			if (mutual)
+			{
+				NBCO_TRY(c->reserve(c->p2p_sec, sizeof(int2) * (size_t)(nleaf + 2)));
+				mu.desc4 = c->p2p_desc.as<int4>();
+				mu.sec_range = c->p2p_sec.as<int2>();
+			}
 			NBCO_TRY(c->reserve(c->p2p_chunk_off, sizeof(int) * (size_t)(nleaf + 2)));
 			NBCO_TRY(c->reserve(c->p2p_chunks, sizeof(int4) * (size_t)max_chunks));
 			NBCO_TRY(build_directed_list(c, c->p2p_list.as<int2>(), c->p2p_list.as<int2>() + cap, p2p_pref, capR, np2p_hint, beg, self0, nself, nleaf, shift, cp,
 			                             c->p2p_start.as<int>(), c->p2p_keys.as<uint64_t>(), c->p2p_keys_alt.as<uint64_t>(), c->sort_tmp,
-			                             tv.index + beg, tv.mult + beg, c->p2p_desc.as<int2>(), c->p2p_chunk_off.as<int>(), c->p2p_chunks.as<int4>()));
+			                             tv.index + beg, tv.mult + beg, c->p2p_desc.as<int2>(), c->p2p_chunk_off.as<int>(), c->p2p_chunks.as<int4>(),
+			                             mutual ? &mu : nullptr));
 			// remembered for nbco_kd_get_info (the directed pair count is evaluated on demand)
 			c->pc_mult = tv.mult + beg; c->pc_shift = shift; c->pc_total = c->p2p_start.as<int>() + nleaf;
 		}
@@ -1705,7 +1800,8 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		const int2 *pd = c->p2p_desc.as<int2>();
 		const int4 *pc = c->p2p_chunks.as<int4>();
 		const int *pt = c->p2p_chunk_off.as<int>() + nleaf;   // total number of chunks
-		if (mlt_max <= 8) launch_p2p<8>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near);
+		if (mutual) launch_p2p_mutual(c, pos, c->p2p_desc.as<int4>(), pc, pt, chunks_hint, mlt_max, near, c->p2p_react.as<float4>(), react_cap);
+		else if (mlt_max <= 8) launch_p2p<8>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near);
 		else if (mlt_max <= 16) launch_p2p<16>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near);
 		else if (mlt_max <= 32) launch_p2p<32>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near);
 		else launch_p2p<64>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near);
@@ -1716,7 +1812,8 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 	{
 		PhaseScope ph(c, NBCO_PH_L2P);
 		NBCO_TRY(launch_l2p_gen(c, P, pos, tv.center, tv.local, near, c->p2p_chunk_off.as<int>(), tv.index, mlt_max, unsort, c->o.unsort ? 1 : 0,
-		                        param, a, c->o.coll ? 1 : 0, n, L, own0, own_n));
+		                        param, a, c->o.coll ? 1 : 0, n, L, own0, own_n, mutual ? c->p2p_sec.as<int2>() : nullptr,
+		                        mutual ? c->p2p_desc.as<int4>() : nullptr, mutual ? c->p2p_react.as<float4>() : nullptr, react_cap));
 	}
 	// ---- now look at what the traversal reported (long finished: the GPU is busy with the work queued above) ----------
 	{
@@ -1737,6 +1834,7 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 	if (h[2] != 0) return c->fail(NBCO_ERR_CAPACITY, "dual tree traversal exceeded the list capacity (raise opts.list_factor or set opts.list_grow)");
 	out.np2p = h[0]; out.nm2l = h[1];
 	c->hint_np2p = h[0]; c->hint_nm2l = h[1];
+	if (mutual && h[0] > react_cap) out.react_overflow = 1;   // the pair list outgrew the reaction records: same evaluation again, sized from h[0]
 	return NBCO_OK;
 }
 
@@ -1776,6 +1874,11 @@ int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 			return fmm_kdtree_eval(c, p, a, n, param);
 		}
 		if (rc != NBCO_OK) return rc;
+	}
+	if (cnt.react_overflow && !cnt.sel_overflow)
+	{
+		c->tree_valid = false;
+		return fmm_kdtree_eval(c, p, a, n, param);
 	}
 	if (cnt.sel_overflow)
 	{
@@ -2091,8 +2194,9 @@ static int dist_finish_rest(nbco_ctx *c, const char *mp_blocks, size_t mp_stride
 	const Dom dm{d, lay.rank};
 	int rc = kd_interact(c, tv, (const float4 *)c->dist.pos_all, lay.n_global, g.mlt_max, dm, (long long)lay.rank * nl, nl, c->unsort.as<int>(), a_local, param,
 	                     cnt, 2, &pre_far);
-	while (rc == NBCO_ERR_CAPACITY && c->grow_lists(g.ntot))
-		// twice the room, traversal and the rest again (the global arrays, multipoles included, are in place; purely local)
+	while ((rc == NBCO_ERR_CAPACITY && c->grow_lists(g.ntot)) || (rc == NBCO_OK && cnt.react_overflow && !cnt.sel_overflow))
+		// twice the room (or reaction records sized from the count just seen), traversal and the rest again (the global arrays,
+		// multipoles included, are in place; purely local)
 		rc = kd_interact(c, tv, (const float4 *)c->dist.pos_all, lay.n_global, g.mlt_max, dm, (long long)lay.rank * nl, nl, c->unsort.as<int>(), a_local, param,
 		                 cnt, 0, nullptr);
 	if (rc != NBCO_OK) return rc;

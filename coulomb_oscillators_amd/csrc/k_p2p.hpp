@@ -166,4 +166,106 @@ static void launch_p2p(nbco_ctx *c, const float4 *pos, const int2 *desc, const i
 	hipLaunchKernelGGL(p2p_kernel<TPL>, dim3(grid), dim3(64 * kP2PWaves), 0, c->stream, pos, desc, chunk, ntotal, c->o.eps2, src_max, stride, partial);
 }
 
+
+// ---- mutual (Newton III) form for leaves of 17..32 particles ----------------------------------------------------------------
+// The reference's GPU pair kernel evaluates each unordered leaf pair once and applies +-d (fmm_cart3_kdtree.cuh:874-959, smem
+// partner accumulators + global atomics).  Here one wave takes a leaf pair (A, B) as four 16 x 16 blocks, one per 16-lane row:
+// row r holds targets A[16 (r >> 1) ..] and sources B[16 (r & 1) ..], one of each per lane, in registers.  At step s a lane
+// meets the source held by the lane s places away in its row -- the rotation is a DPP modifier (row_ror) on the subtraction's
+// operand, no instruction moves data -- and the contribution u = d r^-3 goes to the lane's own target (a -= u) and, rotated
+// back by the same modifier on the addition, to the owner of the source (b += u): 18 vector instructions for two directed
+// pairs instead of 26, one v_rsq_f32 instead of two, and no LDS traffic at all.  Sums stay in a fixed order (bit-reproducible,
+// no atomics): the wave keeps the target sums of a work unit in registers and stores them as the unit's partial sums, and it
+// stores the source sums of every (A, B) as a 32-particle "reaction" record that the L2P kernel adds to B's particles in
+// list order.  Entry codes (desc.w): 0 = one direction only (the leaf with itself; a source leaf of another kd-domain),
+// 1 = both directions, reaction stored at react[desc.z], 2 = the other leaf's wave delivers this entry's sum (skipped here).
+template <int S> __device__ __forceinline__ float row_ror16(float v)
+{
+	if constexpr (S == 0) return v;
+	else return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + S, 0xF, 0xF, false));
+}
+template <int S, bool REACT>
+__device__ __forceinline__ void mutual_steps(float px, float py, float pz, float sx, float sy, float sz, float eps2, float &ax, float &ay, float &az,
+                                             float &bx, float &by, float &bz)
+{
+	const float dx = row_ror16<S>(sx) - px, dy = row_ror16<S>(sy) - py, dz = row_ror16<S>(sz) - pz;   // source - target
+	const float r2 = fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, eps2)));
+	const float ri = __builtin_amdgcn_rsqf(r2);
+	const float w = ri * ri * ri;
+	if constexpr (REACT)
+	{
+		const float ux = dx * w, uy = dy * w, uz = dz * w;
+		ax -= ux; ay -= uy; az -= uz;
+		bx += row_ror16<(16 - S) % 16>(ux); by += row_ror16<(16 - S) % 16>(uy); bz += row_ror16<(16 - S) % 16>(uz);
+	}
+	else
+	{
+		ax = fmaf(-dx, w, ax); ay = fmaf(-dy, w, ay); az = fmaf(-dz, w, az);
+	}
+	if constexpr (S + 1 < 16) mutual_steps<S + 1, REACT>(px, py, pz, sx, sy, sz, eps2, ax, ay, az, bx, by, bz);
+}
+
+constexpr int kReactStride = 32;   // particles per reaction record
+
+__global__ __launch_bounds__(256) void p2p_mutual_kernel(const float4 *__restrict__ pos, const int4 *__restrict__ desc, const int4 *__restrict__ chunk,
+                                                         const int *__restrict__ nchunks_total, float eps2, int stride, float4 *__restrict__ partial,
+                                                         float4 *__restrict__ react, int react_cap)
+{
+	const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, row = lane >> 4, k = lane & 15;
+	const int tsub = 16 * (row >> 1) + k, ssub = 16 * (row & 1) + k;   // this lane's particle inside the target / source leaf
+	const int total = *nchunks_total;
+	const int cstride = gridDim.x * 4;
+	const float4 far = make_float4(1.e18f, 1.e18f, 1.e18f, 0.f);
+	for (int cid = blockIdx.x * 4 + wv; cid < total; cid += cstride)
+	{
+		const int4 ck = chunk[cid];
+		const int it = __builtin_amdgcn_readfirstlane(ck.x), e0 = __builtin_amdgcn_readfirstlane(ck.y), e1 = __builtin_amdgcn_readfirstlane(ck.z),
+		          mt = __builtin_amdgcn_readfirstlane(ck.w);
+		// (loads always go to a valid particle and the value is replaced afterwards: a select between a load and a constant makes
+		// the compiler select between ADDRESSES, with the constant parked in scratch and a flat load in the loop)
+		float4 pt = pos[it + min(tsub, mt - 1)];
+		if (tsub >= mt) pt = far;
+		float ax = 0.f, ay = 0.f, az = 0.f;
+		// the source of the first entry; every later one is fetched while its predecessor is being evaluated
+		int4 d = e0 < e1 ? desc[e0] : make_int4(0, 0, 0, 2);
+		float4 ps = pos[d.x + min(ssub, max(d.y - 1, 0))];
+		if (ssub >= d.y) ps = far;
+		for (int e = e0; e < e1; ++e)
+		{
+			const int4 dn = e + 1 < e1 ? desc[e + 1] : make_int4(0, 0, 0, 2);
+			float4 pn = pos[dn.x + min(ssub, max(dn.y - 1, 0))];
+			if (ssub >= dn.y) pn = far;
+			const int code = __builtin_amdgcn_readfirstlane(d.w);
+			if (code == 1)
+			{
+				float tx = 0.f, ty = 0.f, tz = 0.f, bx = 0.f, by = 0.f, bz = 0.f;
+				mutual_steps<0, true>(pt.x, pt.y, pt.z, ps.x, ps.y, ps.z, eps2, tx, ty, tz, bx, by, bz);
+				ax += tx; ay += ty; az += tz;
+				// rows 0 and 2 (1 and 3) hold the two halves of the sums of B's lower (upper) 16 particles
+				bx += __shfl_xor(bx, 32); by += __shfl_xor(by, 32); bz += __shfl_xor(bz, 32);
+				const int pid = __builtin_amdgcn_readfirstlane(d.z);
+				if (lane < 32 && pid < react_cap) react[(size_t)pid * kReactStride + lane] = make_float4(bx, by, bz, 0.f);
+			}
+			else if (code == 0)
+			{
+				float tx = 0.f, ty = 0.f, tz = 0.f, bx, by, bz;
+				mutual_steps<0, false>(pt.x, pt.y, pt.z, ps.x, ps.y, ps.z, eps2, tx, ty, tz, bx, by, bz);
+				ax += tx; ay += ty; az += tz;
+			}
+			d = dn; ps = pn;
+		}
+		// rows 0 and 1 (2 and 3) hold the two halves of the sums of A's lower (upper) 16 particles
+		ax += __shfl_xor(ax, 16); ay += __shfl_xor(ay, 16); az += __shfl_xor(az, 16);
+		if ((row & 1) == 0 && tsub < mt) partial[(size_t)cid * stride + tsub] = make_float4(ax, ay, az, 0.f);
+	}
+}
+
+static void launch_p2p_mutual(nbco_ctx *c, const float4 *pos, const int4 *desc, const int4 *chunk, const int *ntotal, long long chunks_hint, int stride,
+                              float4 *partial, float4 *react, long long react_cap)
+{
+	const int grid = (int)std::max<long long>(1, (chunks_hint + 3) / 4);
+	hipLaunchKernelGGL(p2p_mutual_kernel, dim3(grid), dim3(256), 0, c->stream, pos, desc, chunk, ntotal, c->o.eps2, stride, partial, react,
+	                   (int)std::min<long long>(react_cap, 0x7fffffff));
+}
+
 } // namespace

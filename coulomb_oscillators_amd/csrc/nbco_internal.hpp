@@ -123,6 +123,7 @@ struct nbco_ctx
 	DevBuf frontier_a, frontier_b, p2p_list, m2l_list, counters;
 	DevBuf p2p_keys, p2p_keys_alt, m2l_keys, m2l_keys_alt, p2p_start, m2l_start;
 	DevBuf p2p_chunk_off, p2p_chunks, p2p_desc;
+	DevBuf p2p_sec, p2p_react;   // mutual near field: per-target range of entries delivered by other waves, reaction records
 	const int *pc_mult = nullptr, *pc_total = nullptr;   // inputs of the on-demand directed pair count
 	int pc_shift = 0;
 	DevBuf list_cnt, trav_ctr;
@@ -237,7 +238,8 @@ int launch_m2m_top_gen(nbco_ctx *c, int P, float *center, float *mpole, int *mul
 int launch_kd_centres_top(nbco_ctx *c, float *center, int *mult, int ltop, const float *lbound, const float *rbound, float4 *csz);
 int launch_l2p_gen(nbco_ctx *c, int P, const float4 *pos, const float *center, const float *local, const float4 *near, const int *chunk_off,
                    const int *index, int mlt_max, const int *unsort, int scatter, const float *param, float *a, int have_near, long long n, int L,
-                   long long own0, long long own_n);
+                   long long own0, long long own_n, const int2 *sec_range = nullptr, const int4 *desc4 = nullptr, const float4 *react = nullptr,
+                   long long react_cap = 0);
 // k_m2l.hip
 int launch_m2l_lanes(nbco_ctx *c, int P, const float4 *csz, const float *mpole, float *local, const uint64_t *keys, const int *start,
                      int shift, int ntot);

@@ -31,7 +31,7 @@ class Opts(C.Structure):
     _fields_ = [("fmm_order", C.c_int), ("tree_radius", C.c_float), ("eps2", C.c_float), ("coll", C.c_int),
                 ("unsort", C.c_int), ("dens_inhom", C.c_float), ("tree_L", C.c_int), ("tree_steps", C.c_int),
                 ("m2l_first", C.c_int), ("sync", C.c_int), ("list_factor", C.c_int), ("list_grow", C.c_int), ("far_fp64", C.c_int),
-                ("stream", C.c_void_p)]
+                ("p2p_mutual", C.c_int), ("stream", C.c_void_p)]
 
 
 class KdInfo(C.Structure):

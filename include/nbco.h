@@ -86,6 +86,11 @@ typedef struct nbco_opts {
 	                       beyond N ~ 1e5 at orders 9-10 (r^-11 19!! ~ 1e40); this mode does not.
 	                       No reference counterpart other than the -DSCAL=double build.  nbco_fmm_kdtree
 	                       rejects it (NBCO_ERR_UNSUPPORTED). */
+	int   p2p_mutual;   /* != 0 (default): nbco_fmm_kdtree evaluates every leaf pair of its near field once and applies the
+	                       force to both leaves (Newton III), as the reference's GPU pair kernel does
+	                       (fmm_cart3_kdtree.cuh:874-959) -- here without atomics: fixed-order sums, bit-reproducible.  Used when
+	                       the leaves hold 17..32 particles (orders 5 and 6 at the reference's leaf sizing); other sizes and
+	                       0 take the one-directional kernel, whose sharded results equal the single-GPU ones bit for bit. */
 	void *stream;       /* hipStream_t; NULL = the null stream */
 } nbco_opts;
 

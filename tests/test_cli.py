@@ -96,8 +96,8 @@ def test_cli_reuse_mode_errors_stay_at_truncation_level(nbco3):
     lines = [l for l in r.stdout.splitlines() if l.startswith("Relative error after")]
     assert [int(l.split()[3]) for l in lines] == list(range(9))          # tree_steps = 8 (constants.cuh:45) -> 9 evaluations
     errs = [float(l.split(":")[1]) for l in lines]
-    assert all(0 < e < 5e-2 for e in errs), errs
-    assert max(errs) < 3 * errs[0], errs                                   # reuse does not degrade the first evaluation's error much
+    assert all(0 < e < 0.1 for e in errs), errs                          # order-4 truncation level on the Gaussian ball: 0.05
+    assert max(errs) < 1.5 * errs[0], errs                                   # reuse does not degrade the first evaluation's error much
 
 
 @pytest.mark.gpu

@@ -341,3 +341,45 @@ def test_list_capacity_overflow_is_reported_and_recoverable(oracle32):
     e.fmm_cart3_kdtree(d2, a, n, dev(par))
     torch.cuda.synchronize()
     assert force_err(a.cpu().numpy(), want) < 1e-5
+
+
+@pytest.mark.parametrize("n,p,inhom", [(4096, 6, 1.0), (5000, 6, 1.0), (30001, 5, 1.0), (65536, 6, 1.0), (40000, 6, 0.75), (3000, 5, 1.3),
+                                       (100000, 6, 1.0)])
+def test_mutual_near_field_matches_oracle_and_the_one_directional_kernel(engine, oracle32, n, p, inhom):
+    """opts.p2p_mutual: every leaf pair evaluated once, the force applied to both leaves (the reference GPU kernel's Newton-III
+    form, fmm_cart3_kdtree.cuh:874-959).  Leaves of 17..32 particles take it (checked); forces stay within 1e-5 of the oracle,
+    within 2e-6 of the one-directional kernel, and are bit-reproducible from run to run (no atomics)."""
+    o = oracle32
+    buf = o.init_reference(n)
+    par = o.params(n)
+    _, a_ref = o.fmm_kd(buf[:2], par, p=p, threads=4, unsort=True, dens_inhom=inhom)
+    _, a_one = run_gpu(engine, buf, par, n, fmm_order=p, unsort=1, dens_inhom=inhom, p2p_mutual=0)
+    info = engine.kd_info()
+    assert 16 < info.mlt_max <= 32, info.mlt_max        # the sizes the mutual kernel serves
+    _, a_mut = run_gpu(engine, buf, par, n, fmm_order=p, unsort=1, dens_inhom=inhom, p2p_mutual=1)
+    _, a_mut2 = run_gpu(engine, buf, par, n, fmm_order=p, unsort=1, dens_inhom=inhom, p2p_mutual=1)
+    assert force_err(a_mut, a_ref) < 1e-5
+    assert force_err(a_mut, a_one) < 2e-6
+    np.testing.assert_array_equal(a_mut, a_mut2)
+    assert engine.kd_info().directed_p2p == info.directed_p2p
+
+
+def test_mutual_near_field_tree_order_and_reuse(engine, oracle32):
+    """unsort = 0 with tree reuse: several leapfrog steps with the mutual kernel stay within rounding of the one-directional run"""
+    import torch
+    from coulomb_oscillators_amd import EVAL_FMM_KDTREE, INTEG_LEAPFROG
+    n, p = 32768, 6
+    buf = oracle32.init_reference(n)
+    par = dev(oracle32.params(n))
+    out = []
+    for mutual in (0, 1):
+        engine.set(fmm_order=p, unsort=0, tree_steps=4, p2p_mutual=mutual)
+        d = dev(buf.copy())
+        engine.compute_force(EVAL_FMM_KDTREE, d, n, par)
+        for _ in range(6):
+            engine.integrate(INTEG_LEAPFROG, EVAL_FMM_KDTREE, d, n, par, 5e-4)
+        out.append(d.cpu().numpy())
+    assert np.isfinite(out[1]).all()
+    # same particle order (the tree is built from positions that agree to rounding; the Gaussian ball has no ties at the splits here)
+    np.testing.assert_allclose(out[1][0], out[0][0], rtol=0, atol=1e-6 * np.abs(out[0][0]).max())
+    assert force_err(out[1][2], out[0][2]) < 1e-5
