@@ -372,7 +372,7 @@ __global__ __launch_bounds__(kBlock) void l2p_gen_kernel(const float4 *__restric
 			for (int e = sr.x; e < sr.y; ++e)
 			{
 				const int pid = desc4[e].z;
-				if (pid >= react_cap) continue;   // (the host repeats an evaluation whose pair list outgrew the records)
+				if (pid < 0 || pid >= react_cap) continue;   // (the host repeats an evaluation whose pair list outgrew the records)
 				const float4 rr = react[(size_t)pid * 32 + j];
 				nx += rr.x; ny += rr.y; nz += rr.z;
 			}
