@@ -1723,7 +1723,9 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 	// indexed by the unordered pair: one per pair of the P2P list, sized from the previous evaluation's count -- the first
 	// evaluation of a context waits for the traversal's count instead (once), and an evaluation whose list outgrew the buffer
 	// is repeated by the caller (the kernels never write beyond it).
-	const bool mutual = c->o.coll && c->o.p2p_mutual && mlt_max > 16 && mlt_max <= 32;
+	const int mutual_th = (c->o.coll && c->o.p2p_mutual) ? p2p_mutual_halves(mlt_max) : 0;   // 32-particle halves per leaf, 0 = one-directional kernel
+	const bool mutual = mutual_th > 0;
+	c->info.p2p_halves = mutual_th;
 	long long react_cap = 0;
 	if (mutual)
 	{
@@ -1734,7 +1736,7 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 			c->hint_nm2l = c->h_flags[1];
 		}
 		react_cap = std::min(cap, c->hint_np2p + c->hint_np2p / 4 + 1024);
-		NBCO_TRY(c->reserve(c->p2p_react, sizeof(float4) * kReactStride * (size_t)react_cap));
+		NBCO_TRY(c->reserve(c->p2p_react, sizeof(float4) * 32 * (size_t)mutual_th * (size_t)react_cap));
 	}
 	// ---- directed sorted lists --------------------------------------------------------------------------
 	{
@@ -1800,7 +1802,7 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		const int2 *pd = c->p2p_desc.as<int2>();
 		const int4 *pc = c->p2p_chunks.as<int4>();
 		const int *pt = c->p2p_chunk_off.as<int>() + nleaf;   // total number of chunks
-		if (mutual) launch_p2p_mutual(c, pos, c->p2p_desc.as<int4>(), pc, pt, chunks_hint, mlt_max, near, c->p2p_react.as<float4>(), react_cap);
+		if (mutual) launch_p2p_mutual(c, mutual_th, pos, c->p2p_desc.as<int4>(), pc, pt, chunks_hint, mlt_max, near, c->p2p_react.as<float4>(), react_cap);
 		else if (mlt_max <= 8) launch_p2p<8>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near);
 		else if (mlt_max <= 16) launch_p2p<16>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near);
 		else if (mlt_max <= 32) launch_p2p<32>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near);
@@ -1813,7 +1815,7 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		PhaseScope ph(c, NBCO_PH_L2P);
 		NBCO_TRY(launch_l2p_gen(c, P, pos, tv.center, tv.local, near, c->p2p_chunk_off.as<int>(), tv.index, mlt_max, unsort, c->o.unsort ? 1 : 0,
 		                        param, a, c->o.coll ? 1 : 0, n, L, own0, own_n, mutual ? c->p2p_sec.as<int2>() : nullptr,
-		                        mutual ? c->p2p_desc.as<int4>() : nullptr, mutual ? c->p2p_react.as<float4>() : nullptr, react_cap));
+		                        mutual ? c->p2p_desc.as<int4>() : nullptr, mutual ? c->p2p_react.as<float4>() : nullptr, react_cap, 32 * mutual_th));
 	}
 	// ---- now look at what the traversal reported (long finished: the GPU is busy with the work queued above) ----------
 	{

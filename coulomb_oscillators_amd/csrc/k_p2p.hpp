@@ -205,14 +205,16 @@ __device__ __forceinline__ void mutual_steps(float px, float py, float pz, float
 	if constexpr (S + 1 < 16) mutual_steps<S + 1, REACT>(px, py, pz, sx, sy, sz, eps2, ax, ay, az, bx, by, bz);
 }
 
-constexpr int kReactStride = 32;   // particles per reaction record
-
+// Leaves of more than 32 particles are taken as TH halves of up to 32 (TH = 1, 2, 4 for leaves of up to 32, 64, 128): a leaf
+// pair is TH x TH passes of the four-block scheme; a wave keeps TH target positions and TH sets of target sums in registers and
+// stores one 32-particle reaction record per source half (react[(pair * TH + half) * 32 + lane]).
+template <int TH>
 __global__ __launch_bounds__(256) void p2p_mutual_kernel(const float4 *__restrict__ pos, const int4 *__restrict__ desc, const int4 *__restrict__ chunk,
                                                          const int *__restrict__ nchunks_total, float eps2, int stride, float4 *__restrict__ partial,
                                                          float4 *__restrict__ react, int react_cap)
 {
 	const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, row = lane >> 4, k = lane & 15;
-	const int tsub = 16 * (row >> 1) + k, ssub = 16 * (row & 1) + k;   // this lane's particle inside the target / source leaf
+	const int tsub = 16 * (row >> 1) + k, ssub = 16 * (row & 1) + k;   // this lane's particle inside a target / source half
 	const int total = *nchunks_total;
 	const int cstride = gridDim.x * 4;
 	const float4 far = make_float4(1.e18f, 1.e18f, 1.e18f, 0.f);
@@ -223,49 +225,107 @@ __global__ __launch_bounds__(256) void p2p_mutual_kernel(const float4 *__restric
 		          mt = __builtin_amdgcn_readfirstlane(ck.w);
 		// (loads always go to a valid particle and the value is replaced afterwards: a select between a load and a constant makes
 		// the compiler select between ADDRESSES, with the constant parked in scratch and a flat load in the loop)
-		float4 pt = pos[it + min(tsub, mt - 1)];
-		if (tsub >= mt) pt = far;
-		float ax = 0.f, ay = 0.f, az = 0.f;
-		// the source of the first entry; every later one is fetched while its predecessor is being evaluated
+		float4 pt[TH];
+		float ax[TH], ay[TH], az[TH];
+#pragma unroll
+		for (int h = 0; h < TH; ++h)
+		{
+			pt[h] = pos[it + min(32 * h + tsub, mt - 1)];
+			if (32 * h + tsub >= mt) pt[h] = far;
+			ax[h] = ay[h] = az[h] = 0.f;
+		}
+		auto load_sources = [&](const int4 &d, float4 (&ps)[TH]) {
+#pragma unroll
+			for (int h = 0; h < TH; ++h)
+			{
+				ps[h] = pos[d.x + min(32 * h + ssub, max(d.y - 1, 0))];
+				if (32 * h + ssub >= d.y) ps[h] = far;
+			}
+		};
+		// the sources of the first entry; every later entry's are fetched while its predecessor is being evaluated
 		int4 d = e0 < e1 ? desc[e0] : make_int4(0, 0, 0, 2);
-		float4 ps = pos[d.x + min(ssub, max(d.y - 1, 0))];
-		if (ssub >= d.y) ps = far;
+		float4 ps[TH];
+		load_sources(d, ps);
 		for (int e = e0; e < e1; ++e)
 		{
 			const int4 dn = e + 1 < e1 ? desc[e + 1] : make_int4(0, 0, 0, 2);
-			float4 pn = pos[dn.x + min(ssub, max(dn.y - 1, 0))];
-			if (ssub >= dn.y) pn = far;
-			const int code = __builtin_amdgcn_readfirstlane(d.w);
+			float4 pn[TH];
+			load_sources(dn, pn);
+			const int code = __builtin_amdgcn_readfirstlane(d.w), ms = __builtin_amdgcn_readfirstlane(d.y);
 			if (code == 1)
 			{
-				float tx = 0.f, ty = 0.f, tz = 0.f, bx = 0.f, by = 0.f, bz = 0.f;
-				mutual_steps<0, true>(pt.x, pt.y, pt.z, ps.x, ps.y, ps.z, eps2, tx, ty, tz, bx, by, bz);
-				ax += tx; ay += ty; az += tz;
-				// rows 0 and 2 (1 and 3) hold the two halves of the sums of B's lower (upper) 16 particles
-				bx += __shfl_xor(bx, 32); by += __shfl_xor(by, 32); bz += __shfl_xor(bz, 32);
 				const int pid = __builtin_amdgcn_readfirstlane(d.z);
-				if (lane < 32 && pid < react_cap) react[(size_t)pid * kReactStride + lane] = make_float4(bx, by, bz, 0.f);
+#pragma unroll
+				for (int hs = 0; hs < TH; ++hs)
+				{
+					if (32 * hs >= ms) break;
+					float bx = 0.f, by = 0.f, bz = 0.f;
+#pragma unroll
+					for (int ht = 0; ht < TH; ++ht)
+					{
+						if (32 * ht >= mt) break;
+						float tx = 0.f, ty = 0.f, tz = 0.f;
+						mutual_steps<0, true>(pt[ht].x, pt[ht].y, pt[ht].z, ps[hs].x, ps[hs].y, ps[hs].z, eps2, tx, ty, tz, bx, by, bz);
+						ax[ht] += tx; ay[ht] += ty; az[ht] += tz;
+					}
+					// rows 0 and 2 (1 and 3) hold the two halves of the sums of this source half's lower (upper) 16 particles
+					bx += __shfl_xor(bx, 32); by += __shfl_xor(by, 32); bz += __shfl_xor(bz, 32);
+					if (lane < 32 && pid < react_cap) react[((size_t)pid * TH + hs) * 32 + lane] = make_float4(bx, by, bz, 0.f);
+				}
 			}
 			else if (code == 0)
 			{
-				float tx = 0.f, ty = 0.f, tz = 0.f, bx, by, bz;
-				mutual_steps<0, false>(pt.x, pt.y, pt.z, ps.x, ps.y, ps.z, eps2, tx, ty, tz, bx, by, bz);
-				ax += tx; ay += ty; az += tz;
+#pragma unroll
+				for (int hs = 0; hs < TH; ++hs)
+				{
+					if (32 * hs >= ms) break;
+#pragma unroll
+					for (int ht = 0; ht < TH; ++ht)
+					{
+						if (32 * ht >= mt) break;
+						float tx = 0.f, ty = 0.f, tz = 0.f, bx, by, bz;
+						mutual_steps<0, false>(pt[ht].x, pt[ht].y, pt[ht].z, ps[hs].x, ps[hs].y, ps[hs].z, eps2, tx, ty, tz, bx, by, bz);
+						ax[ht] += tx; ay[ht] += ty; az[ht] += tz;
+					}
+				}
 			}
-			d = dn; ps = pn;
+			d = dn;
+#pragma unroll
+			for (int h = 0; h < TH; ++h) ps[h] = pn[h];
 		}
-		// rows 0 and 1 (2 and 3) hold the two halves of the sums of A's lower (upper) 16 particles
-		ax += __shfl_xor(ax, 16); ay += __shfl_xor(ay, 16); az += __shfl_xor(az, 16);
-		if ((row & 1) == 0 && tsub < mt) partial[(size_t)cid * stride + tsub] = make_float4(ax, ay, az, 0.f);
+		// rows 0 and 1 (2 and 3) hold the two halves of the sums of a target half's lower (upper) 16 particles
+#pragma unroll
+		for (int h = 0; h < TH; ++h)
+		{
+			const float sx = ax[h] + __shfl_xor(ax[h], 16), sy = ay[h] + __shfl_xor(ay[h], 16), sz = az[h] + __shfl_xor(az[h], 16);
+			if ((row & 1) == 0 && 32 * h + tsub < mt) partial[(size_t)cid * stride + 32 * h + tsub] = make_float4(sx, sy, sz, 0.f);
+		}
 	}
 }
 
-static void launch_p2p_mutual(nbco_ctx *c, const float4 *pos, const int4 *desc, const int4 *chunk, const int *ntotal, long long chunks_hint, int stride,
+// Does the mutual kernel beat the one-directional one for leaves of up to mlt_max particles?  It evaluates (32 TH)^2 lane
+// pairs per leaf pair at 1.5x the pair rate (measured ratio of the two bodies, tools/pair_ceiling.hip); the one-directional
+// kernel wastes the lanes beyond mlt_max of its target group.
+static int p2p_mutual_halves(int mlt_max)
+{
+	if (mlt_max <= 16 || mlt_max > 128) return 0;
+	const int th = mlt_max <= 32 ? 1 : (mlt_max <= 64 ? 2 : 4);
+	const int tpl = mlt_max <= 32 ? 32 : 64, groups = (mlt_max + tpl - 1) / tpl;
+	const double mutual = 1.5 * (double)mlt_max * mlt_max / ((32.0 * th) * (32.0 * th)), one_way = (double)mlt_max / (tpl * groups);
+	return mutual > one_way ? th : 0;
+}
+
+static void launch_p2p_mutual(nbco_ctx *c, int th, const float4 *pos, const int4 *desc, const int4 *chunk, const int *ntotal, long long chunks_hint, int stride,
                               float4 *partial, float4 *react, long long react_cap)
 {
 	const int grid = (int)std::max<long long>(1, (chunks_hint + 3) / 4);
-	hipLaunchKernelGGL(p2p_mutual_kernel, dim3(grid), dim3(256), 0, c->stream, pos, desc, chunk, ntotal, c->o.eps2, stride, partial, react,
-	                   (int)std::min<long long>(react_cap, 0x7fffffff));
+	const int cap = (int)std::min<long long>(react_cap, 0x7fffffff);
+	if (th == 1)
+		hipLaunchKernelGGL(p2p_mutual_kernel<1>, dim3(grid), dim3(256), 0, c->stream, pos, desc, chunk, ntotal, c->o.eps2, stride, partial, react, cap);
+	else if (th == 2)
+		hipLaunchKernelGGL(p2p_mutual_kernel<2>, dim3(grid), dim3(256), 0, c->stream, pos, desc, chunk, ntotal, c->o.eps2, stride, partial, react, cap);
+	else
+		hipLaunchKernelGGL(p2p_mutual_kernel<4>, dim3(grid), dim3(256), 0, c->stream, pos, desc, chunk, ntotal, c->o.eps2, stride, partial, react, cap);
 }
 
 } // namespace

@@ -239,7 +239,7 @@ int launch_kd_centres_top(nbco_ctx *c, float *center, int *mult, int ltop, const
 int launch_l2p_gen(nbco_ctx *c, int P, const float4 *pos, const float *center, const float *local, const float4 *near, const int *chunk_off,
                    const int *index, int mlt_max, const int *unsort, int scatter, const float *param, float *a, int have_near, long long n, int L,
                    long long own0, long long own_n, const int2 *sec_range = nullptr, const int4 *desc4 = nullptr, const float4 *react = nullptr,
-                   long long react_cap = 0);
+                   long long react_cap = 0, int react_stride = 32);
 // k_m2l.hip
 int launch_m2l_lanes(nbco_ctx *c, int P, const float4 *csz, const float *mpole, float *local, const uint64_t *keys, const int *start,
                      int shift, int ntot);

@@ -148,6 +148,8 @@ typedef struct nbco_kd_info {
 	                               resolution of the pivot bucket (default), 1 = three radix passes (after a bucket held
 	                               more candidates than the resolver takes), 2 = stable-sort chain (after a pivot had
 	                               more exact ties than that).  The trees are identical; only the speed differs. */
+	int p2p_halves;             /* near-field kernel of the last evaluation: 0 = one-directional; 1, 2, 4 = mutual (Newton III) with
+	                               leaves taken as that many halves of up to 32 particles (opts.p2p_mutual) */
 } nbco_kd_info;
 int nbco_kd_get_info(nbco_ctx *c, nbco_kd_info *info);
 

@@ -343,25 +343,28 @@ def test_list_capacity_overflow_is_reported_and_recoverable(oracle32):
     assert force_err(a.cpu().numpy(), want) < 1e-5
 
 
-@pytest.mark.parametrize("n,p,inhom", [(4096, 6, 1.0), (5000, 6, 1.0), (30001, 5, 1.0), (65536, 6, 1.0), (40000, 6, 0.75), (3000, 5, 1.3),
-                                       (100000, 6, 1.0)])
-def test_mutual_near_field_matches_oracle_and_the_one_directional_kernel(engine, oracle32, n, p, inhom):
+@pytest.mark.parametrize("n,p,inhom,halves", [(4096, 6, 1.0, 1), (30001, 5, 1.0, 1), (65536, 6, 1.0, 1), (3000, 5, 1.3, 1), (46000, 6, 1.0, 2),
+                                              (100000, 6, 1.0, 2), (65536, 8, 1.0, 2), (32768, 10, 1.0, 4), (20000, 9, 1.0, 4),
+                                              (5000, 6, 1.0, 0), (4096, 4, 1.0, 0)])
+def test_mutual_near_field_matches_oracle_and_the_one_directional_kernel(engine, oracle32, n, p, inhom, halves):
     """opts.p2p_mutual: every leaf pair evaluated once, the force applied to both leaves (the reference GPU kernel's Newton-III
-    form, fmm_cart3_kdtree.cuh:874-959).  Leaves of 17..32 particles take it (checked); forces stay within 1e-5 of the oracle,
-    within 2e-6 of the one-directional kernel, and are bit-reproducible from run to run (no atomics)."""
+    form, fmm_cart3_kdtree.cuh:874-959).  Leaves are taken as 1, 2 or 4 halves of up to 32 particles (0: the leaf size fills the
+    16-lane rows too badly, the one-directional kernel runs); forces stay within 1e-5 of the oracle, within 2e-6 of the
+    one-directional kernel, and are bit-reproducible from run to run (no atomics)."""
     o = oracle32
     buf = o.init_reference(n)
     par = o.params(n)
     _, a_ref = o.fmm_kd(buf[:2], par, p=p, threads=4, unsort=True, dens_inhom=inhom)
     _, a_one = run_gpu(engine, buf, par, n, fmm_order=p, unsort=1, dens_inhom=inhom, p2p_mutual=0)
     info = engine.kd_info()
-    assert 16 < info.mlt_max <= 32, info.mlt_max        # the sizes the mutual kernel serves
+    assert info.p2p_halves == 0
     _, a_mut = run_gpu(engine, buf, par, n, fmm_order=p, unsort=1, dens_inhom=inhom, p2p_mutual=1)
     _, a_mut2 = run_gpu(engine, buf, par, n, fmm_order=p, unsort=1, dens_inhom=inhom, p2p_mutual=1)
     assert force_err(a_mut, a_ref) < 1e-5
     assert force_err(a_mut, a_one) < 2e-6
     np.testing.assert_array_equal(a_mut, a_mut2)
     assert engine.kd_info().directed_p2p == info.directed_p2p
+    assert engine.kd_info().p2p_halves == halves, (engine.kd_info().p2p_halves, info.mlt_max)
 
 
 def test_mutual_near_field_tree_order_and_reuse(engine, oracle32):
