@@ -169,6 +169,7 @@ int launch_direct(nbco_ctx *c, const float *p, float *a, long long n, const floa
 	if (n <= 0) return c->fail(NBCO_ERR_ARG, "nbco_direct: n must be positive");
 	PhaseScope ph(c, NBCO_PH_DIRECT);
 	NBCO_TRY(c->reserve(c->pos4, sizeof(float4) * (size_t)n));
+	c->last_eval.valid = false;   // the tree-ordered positions of the last kd evaluation are overwritten
 	NBCO_TRY(launch_pack4(c, c->pos4.as<float4>(), p, n));
 
 	const long long iblocks = (n + kBlock * IB - 1) / (kBlock * IB);

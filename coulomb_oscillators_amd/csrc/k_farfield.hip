@@ -360,7 +360,9 @@ __global__ __launch_bounds__(kBlock) void l2p_gen_kernel(const float4 *__restric
 	{
 		const int j = (int)(i - index[leaf]);
 		float nx = 0.f, ny = 0.f, nz = 0.f;
-		for (int ck = chunk_off[lf]; ck < chunk_off[lf + 1]; ++ck)
+		int ck0 = chunk_off[lf], ck1 = chunk_off[lf + 1];
+		if (!NBCO_CHECKED_OK(ck0 >= 0 && ck0 <= ck1 && j >= 0 && j < mlt_max, NBCO_CHK_L2P)) ck1 = ck0;
+		for (int ck = ck0; ck < ck1; ++ck)
 		{
 			const float4 nr = near[(size_t)ck * mlt_max + j];
 			nx += nr.x; ny += nr.y; nz += nr.z;
@@ -368,7 +370,8 @@ __global__ __launch_bounds__(kBlock) void l2p_gen_kernel(const float4 *__restric
 		if (sec_range)
 		{
 			// mutual near field: the sums of the leaf pairs that the other leaf's wave evaluated, in list order
-			const int2 sr = sec_range[lf];
+			int2 sr = sec_range[lf];
+			if (!NBCO_CHECKED_OK(sr.x >= 0 && sr.x <= sr.y, NBCO_CHK_L2P)) sr.y = sr.x;
 			for (int e = sr.x; e < sr.y; ++e)
 			{
 				const int pid = desc4[e].z;
@@ -540,3 +543,5 @@ int launch_l2p_gen(nbco_ctx *c, int P, const float4 *pos, const float *center, c
 	NBCO_DISPATCH_P(P, CALL)
 #undef CALL
 }
+
+NBCO_CHECKED_COLLECT(nbco_checked_collect_far)

@@ -948,6 +948,7 @@ __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab
 		if (i < nin)
 		{
 			p0 = fin[region_slot(in_pref, capR, i)];
+			if (!NBCO_CHECKED_OK((unsigned)p0.x < (unsigned)t.ntot && (unsigned)p0.y < (unsigned)t.ntot, NBCO_CHK_FRONTIER)) p0 = make_int2(0, 0);
 			k0 = classify_pair(t, &tab, p0, par, m2l_first, dm);
 			ch = pair_children(k0, p0);
 			if (ch.n > 0) k1 = classify_pair(t, &tab, ch.a, par, m2l_first, dm);
@@ -1113,8 +1114,11 @@ __global__ __launch_bounds__(kBlock) void list_fill_kernel(const int2 *__restric
 		if (i < npairs)
 		{
 			const long long slot = region_slot(pref, capR, i);
+			if (!NBCO_CHECKED_OK(slot >= 0 && slot < capR * kTravK, NBCO_CHK_FILL)) continue;
 			const int2 p = pairs[slot], r = ranks[slot];
 			const uint64_t a = (uint64_t)(p.x - sub), b = (uint64_t)(p.y - sub);
+			if (!NBCO_CHECKED_OK(a < (uint64_t)ntargets && b < (uint64_t)ntargets && (r.x < 0 || start[a] + r.x < start[a + 1])
+			                         && (r.y < 0 || start[b] + r.y < start[b + 1]), NBCO_CHK_FILL)) continue;
 			if (pidmode)
 			{
 				if (r.x >= 0) keys[start[a] + r.x] = (b << 32) | (uint64_t)(uint32_t)i;
@@ -1167,6 +1171,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 	const int lowbit = (DESC && mu.desc4) ? 32 : 0;
 	auto emit = [&](int t, int slot, uint64_t key) {
 		const int src = (int)((key >> lowbit) & smask);
+		if (!NBCO_CHECKED_OK(src >= 0 && src < ntargets && slot >= start[t] && slot < start[t + 1], NBCO_CHK_SORT)) return;
 		if (DESC && mu.desc4)
 		{
 			out[slot] = ((uint64_t)t << shift) | (uint64_t)src;
@@ -1802,11 +1807,11 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		const int2 *pd = c->p2p_desc.as<int2>();
 		const int4 *pc = c->p2p_chunks.as<int4>();
 		const int *pt = c->p2p_chunk_off.as<int>() + nleaf;   // total number of chunks
-		if (mutual) launch_p2p_mutual(c, mutual_th, pos, c->p2p_desc.as<int4>(), pc, pt, chunks_hint, mlt_max, near, c->p2p_react.as<float4>(), react_cap);
-		else if (mlt_max <= 8) launch_p2p<8>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near);
-		else if (mlt_max <= 16) launch_p2p<16>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near);
-		else if (mlt_max <= 32) launch_p2p<32>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near);
-		else launch_p2p<64>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near);
+		if (mutual) launch_p2p_mutual(c, mutual_th, pos, c->p2p_desc.as<int4>(), pc, pt, chunks_hint, mlt_max, near, c->p2p_react.as<float4>(), react_cap, n);
+		else if (mlt_max <= 8) launch_p2p<8>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near, n);
+		else if (mlt_max <= 16) launch_p2p<16>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near, n);
+		else if (mlt_max <= 32) launch_p2p<32>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near, n);
+		else launch_p2p<64>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near, n);
 		NBCO_HIP(hipGetLastError());
 	}
 	// ---- L2P + rescale + (un)sort -------------------------------------------------------------------------
@@ -1836,6 +1841,15 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 	if (h[2] != 0) return c->fail(NBCO_ERR_CAPACITY, "dual tree traversal exceeded the list capacity (raise opts.list_factor or set opts.list_grow)");
 	out.np2p = h[0]; out.nm2l = h[1];
 	c->hint_np2p = h[0]; c->hint_nm2l = h[1];
+	// what nbco_energy_fmm needs of this evaluation: tree, tree-ordered positions, the two sorted lists
+	{
+		nbco_ctx::LastEval &le = c->last_eval;
+		le.valid = true;
+		le.center = tv.center; le.csz = tv.csz; le.mpole = tv.mpole; le.mult = tv.mult; le.index = tv.index;
+		le.L = L; le.ntot = ntot; le.order = P; le.shift = shift;
+		le.pos = pos; le.n = n; le.own0 = own0; le.own_n = own_n;
+		le.have_p2p = c->o.coll != 0;
+	}
 	if (mutual && h[0] > react_cap) out.react_overflow = 1;   // the pair list outgrew the reaction records: same evaluation again, sized from h[0]
 	return NBCO_OK;
 }
@@ -1854,6 +1868,151 @@ static int kd_finish_order(nbco_ctx *c, float *p, long long n)
 	return NBCO_OK;
 }
 
+// ---- FMM potential energy (no reference driver computes an energy) -------------------------------
+// phi_i = sum_{j != i} (|x_i - x_j|^2 + eps2)^(-1/2) with the interaction lists of the last evaluation: the leaf's P2P list
+// pair by pair, and for the M2L list of the leaf and of each of its ancestors the source node's multipole expansion evaluated
+// AT THE PARTICLE (the reference's m2p_pot3, fmm_cart_base3.cuh:1474-1490, instead of an order-0 local: no second truncation).
+// With b_K = d^K f / K!, f = 1/|d|:  phi = sum_K M[K] |K|! b_K(d), d = x_i - c_s, and the Taylor coefficients follow
+//   k R^2 b_K + (2k - 1) sum_a d_a b_{K - e_a} + (k - 1) sum_a b_{K - 2 e_a} = 0,   k = |K|, R^2 = |d|^2
+// (tests/test_oracle_closed_form.py derives the same numbers from the polynomial form of the derivatives).  fp64 throughout:
+// this is a diagnostic that runs once per snapshot, and energy drifts are read at the 1e-6 level.
+__host__ __device__ constexpr int sym_index(int x, int z, int n) { return (n * (n + 1) - (n - z) * (n - z + 1)) / 2 + n - x; }
+__host__ __device__ constexpr int sym_offset(int n) { return n * (n + 1) * (n + 2) / 6; }
+
+template <int P>
+__device__ inline double m2p_potential(const float *__restrict__ M, double dx, double dy, double dz, double eps2)
+{
+	constexpr int offM = sym_offset(P);
+	double B[offM > 0 ? offM : 1];
+	const double R2 = dx * dx + dy * dy + dz * dz + eps2, iR2 = 1.0 / R2;
+	B[0] = sqrt(iR2);
+	double phi = (double)M[0] * B[0], fact = 1.0;
+#pragma unroll
+	for (int k = 1; k < P; ++k)
+	{
+		fact *= (double)k;
+		const double c1 = -(double)(2 * k - 1) * iR2 / (double)k, c2 = -(double)(k - 1) * iR2 / (double)k;
+		double s = 0.0;
+#pragma unroll
+		for (int z = 0; z <= k; ++z)
+#pragma unroll
+			for (int x = k - z; x >= 0; --x)
+			{
+				const int y = k - x - z;
+				double t1 = 0.0, t2 = 0.0;
+				if (x >= 1) t1 += dx * B[sym_offset(k - 1) + sym_index(x - 1, z, k - 1)];
+				if (y >= 1) t1 += dy * B[sym_offset(k - 1) + sym_index(x, z, k - 1)];
+				if (z >= 1) t1 += dz * B[sym_offset(k - 1) + sym_index(x, z - 1, k - 1)];
+				if (k >= 2)
+				{
+					if (x >= 2) t2 += B[sym_offset(k - 2) + sym_index(x - 2, z, k - 2)];
+					if (y >= 2) t2 += B[sym_offset(k - 2) + sym_index(x, z, k - 2)];
+					if (z >= 2) t2 += B[sym_offset(k - 2) + sym_index(x, z - 2, k - 2)];
+				}
+				const double b = c1 * t1 + c2 * t2;
+				B[sym_offset(k) + sym_index(x, z, k)] = b;
+				s += (double)M[sym_offset(k) + sym_index(x, z, k)] * b;
+			}
+		phi += fact * s;
+	}
+	return phi;
+}
+
+template <int P>
+__global__ __launch_bounds__(kBlock) void kd_potential_kernel(nbco_ctx::LastEval le, const uint64_t *__restrict__ m2l_keys, const int *__restrict__ m2l_start,
+                                                              const uint64_t *__restrict__ p2p_keys, const int *__restrict__ p2p_start, float eps2f,
+                                                              double *__restrict__ part)
+{
+	constexpr int offM = sym_offset(P);
+	const long long io = (long long)blockIdx.x * kBlock + threadIdx.x;
+	double phi = 0.0;
+	if (io < le.own_n)
+	{
+		const long long i = le.own0 + io;
+		const int beg = kd_beg(le.L), lf = (int)(((1LL << le.L) * i) / le.n);
+		const uint64_t mask = (1ull << le.shift) - 1;
+		const float4 p = le.pos[i];
+		const double eps2 = (double)eps2f;
+		if (le.have_p2p)
+			for (int e = p2p_start[lf]; e < p2p_start[lf + 1]; ++e)
+			{
+				const int src = beg + (int)(p2p_keys[e] & mask);
+				const int is = le.index[src], ms = le.mult[src];
+				for (int j = 0; j < ms; ++j)
+				{
+					if (is + j == i) continue;
+					const float4 q = le.pos[is + j];
+					const double dx = (double)p.x - (double)q.x, dy = (double)p.y - (double)q.y, dz = (double)p.z - (double)q.z;
+					phi += 1.0 / sqrt(dx * dx + dy * dy + dz * dz + eps2);
+				}
+			}
+		for (int node = beg + lf;; node = (node - 1) >> 1)
+		{
+			for (int e = m2l_start[node]; e < m2l_start[node + 1]; ++e)
+			{
+				const int sn = (int)(m2l_keys[e] & mask);
+				const float4 cs = le.csz[sn];
+				phi += m2p_potential<P>(le.mpole + (size_t)sn * offM, (double)p.x - (double)cs.x, (double)p.y - (double)cs.y, (double)p.z - (double)cs.z, eps2);
+			}
+			if (node == 0) break;
+		}
+	}
+	// block sum -> one partial per block (summed in a fixed order on the host)
+	__shared__ double sh[kBlock / 64];
+	for (int o = 32; o > 0; o >>= 1) phi += __shfl_xor(phi, o);
+	if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = phi;
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		double t = 0.0;
+		for (int k = 0; k < kBlock / 64; ++k) t += sh[k];
+		part[blockIdx.x] = t;
+	}
+}
+
+template <int P> static void launch_potential(nbco_ctx *c, int grid, double *part)
+{
+	hipLaunchKernelGGL(kd_potential_kernel<P>, dim3(grid), dim3(kBlock), 0, c->stream, c->last_eval, (const uint64_t *)c->m2l_keys_alt.as<uint64_t>(),
+	                   (const int *)c->m2l_start.as<int>(), (const uint64_t *)c->p2p_keys_alt.as<uint64_t>(), (const int *)c->p2p_start.as<int>(), c->o.eps2,
+	                   part);
+}
+
+} // namespace
+
+// sum over the own particles of phi_i / 2 (the caller multiplies by param[0] = xi / N)
+int kd_energy_fmm(nbco_ctx *c, long long n_own, double *half_phi_sum)
+{
+	const nbco_ctx::LastEval &le = c->last_eval;
+	if (!le.valid || !c->tree_valid) return c->fail(NBCO_ERR_ARG, "nbco_energy_fmm: no kd-tree evaluation to take the lists from");
+	if (le.own_n != n_own) return c->fail(NBCO_ERR_ARG, "nbco_energy_fmm: particle count differs from the last evaluation's");
+	const int grid = (int)((le.own_n + kBlock - 1) / kBlock);
+	NBCO_TRY(c->reserve(c->part, sizeof(double) * (size_t)grid));
+	double *part = c->part.as<double>();
+	switch (le.order)
+	{
+	case 1: launch_potential<1>(c, grid, part); break;
+	case 2: launch_potential<2>(c, grid, part); break;
+	case 3: launch_potential<3>(c, grid, part); break;
+	case 4: launch_potential<4>(c, grid, part); break;
+	case 5: launch_potential<5>(c, grid, part); break;
+	case 6: launch_potential<6>(c, grid, part); break;
+	case 7: launch_potential<7>(c, grid, part); break;
+	case 8: launch_potential<8>(c, grid, part); break;
+	case 9: launch_potential<9>(c, grid, part); break;
+	case 10: launch_potential<10>(c, grid, part); break;
+	default: return c->fail(NBCO_ERR_UNSUPPORTED, "nbco_energy_fmm: order");
+	}
+	NBCO_HIP(hipGetLastError());
+	std::vector<double> h((size_t)grid);
+	NBCO_HIP(hipMemcpyAsync(h.data(), part, sizeof(double) * (size_t)grid, hipMemcpyDeviceToHost, c->stream));
+	NBCO_HIP(hipStreamSynchronize(c->stream));
+	double s = 0.0;
+	for (double v : h) s += v;
+	*half_phi_sum = 0.5 * s;
+	return NBCO_OK;
+}
+
+namespace {
 } // namespace
 
 int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *param)
@@ -2047,6 +2206,7 @@ int kd_dist_partition(nbco_ctx *c, const float *state_all, long long n_global, i
 		NBCO_TRY(launch_minmax4(c, pos, n, mm));
 		hipLaunchKernelGGL(kd_root_kernel, dim3(1), dim3(64), 0, st, tv, (const float *)mm);
 		hipLaunchKernelGGL(iota_kernel, dim3(grid1d(n)), dim3(kBlock), 0, st, unsort, n);
+		c->perm_primed_n = -1;   // the permutation buffers now hold n_global-range indices: the next local build primes them again
 		const bool use_select = !c->force_sort_build;
 		NBCO_TRY(kd_build_top(c, tv, pos, pos_alt, unsort, unsort_alt, n, d, use_select));
 		int flag = 0;
@@ -2291,3 +2451,5 @@ int kd_copy_out(nbco_ctx *c, int which, void *dst, long long bytes)
 	if (need) NBCO_HIP(hipMemcpy(dst, src, need, hipMemcpyDeviceToHost));
 	return NBCO_OK;
 }
+
+NBCO_CHECKED_COLLECT(nbco_checked_collect_kd)

@@ -565,10 +565,10 @@ static int oct_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 		const int2 *pd = c->p2p_keys.as<int2>();
 		const int4 *pc = c->p2p_chunks.as<int4>();
 		const int *pt = chunk_off + m;
-		if (tpl == 8) launch_p2p<8>(c, pos, pd, pc, pt, nck, kSrcPiece, tpl, near);
-		else if (tpl == 16) launch_p2p<16>(c, pos, pd, pc, pt, nck, kSrcPiece, tpl, near);
-		else if (tpl == 32) launch_p2p<32>(c, pos, pd, pc, pt, nck, kSrcPiece, tpl, near);
-		else launch_p2p<64>(c, pos, pd, pc, pt, nck, kSrcPiece, tpl, near);
+		if (tpl == 8) launch_p2p<8>(c, pos, pd, pc, pt, nck, kSrcPiece, tpl, near, n);
+		else if (tpl == 16) launch_p2p<16>(c, pos, pd, pc, pt, nck, kSrcPiece, tpl, near, n);
+		else if (tpl == 32) launch_p2p<32>(c, pos, pd, pc, pt, nck, kSrcPiece, tpl, near, n);
+		else launch_p2p<64>(c, pos, pd, pc, pt, nck, kSrcPiece, tpl, near, n);
 		NBCO_HIP(hipGetLastError());
 	}
 	// ---- M2L, L2L ------------------------------------------------------------------------------------------
@@ -646,3 +646,5 @@ int oct_copy_out(nbco_ctx *c, int which, void *dst, long long bytes)
 	if (need) NBCO_HIP(hipMemcpy(dst, src, need, hipMemcpyDeviceToHost));
 	return NBCO_OK;
 }
+
+NBCO_CHECKED_COLLECT(nbco_checked_collect_oct)

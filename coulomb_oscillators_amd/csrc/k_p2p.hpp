@@ -54,9 +54,13 @@ constexpr int kP2PWaves = NBCO_P2P_WAVES;   // waves per 256-thread block; 64-th
 template <int TPL>
 __global__ __launch_bounds__(64 * kP2PWaves) NBCO_P2P_ATTR void p2p_kernel(const float4 *__restrict__ pos, const int2 *__restrict__ desc,
                                                              const int4 *__restrict__ chunk, const int *__restrict__ nchunks_total,
-                                                             float eps2, int src_max, int stride, float4 *__restrict__ partial)
+                                                             float eps2, int src_max, int stride, float4 *__restrict__ partial, int npos)
 {
 	constexpr int G = 64 / TPL;
+	// checked build: a work unit must lie inside the particle array and hold an ordered entry range, a source descriptor inside
+	// the particle array; anything else is counted and replaced by an empty one
+	auto sane_chunk = [&](int4 k) { return NBCO_CHECKED_OK(k.x >= 0 && k.w >= 1 && k.x + k.w <= npos && k.y <= k.z, NBCO_CHK_CHUNK) ? k : make_int4(0, 0, 0, 1); };
+	auto sane_desc = [&](int2 d) { return NBCO_CHECKED_OK(d.x >= 0 && d.y >= 0 && d.x + d.y <= npos, NBCO_CHK_DESC) ? d : make_int2(0, 0); };
 	// source tiles as packed xyz triplets: four sources are read with three ds_read_b128 and every loaded
 	// dword is used (a float4-per-source tile is narrowed to ds_read_b96 by hipcc, twice the LDS cycles)
 	__shared__ __attribute__((aligned(16))) float tile_all[kP2PWaves][2][G][3 * TPL];
@@ -70,16 +74,16 @@ __global__ __launch_bounds__(64 * kP2PWaves) NBCO_P2P_ATTR void p2p_kernel(const
 	int cid = blockIdx.x * kP2PWaves + wv;
 	if (cid >= total) return;
 	// header of the current chunk: record, target position (first target block), first batch of descriptors
-	int4 ck = chunk[cid];
+	int4 ck = sane_chunk(chunk[cid]);
 	float4 pt = pos[ck.x + min(li, ck.w - 1)];
-	int2 dsc = lane < ck.z - ck.y ? desc[ck.y + lane] : make_int2(0, 0);
+	int2 dsc = lane < ck.z - ck.y ? sane_desc(desc[ck.y + lane]) : make_int2(0, 0);
 	for (; cid < total; cid += cstride)
 	{
 		const int it = ck.x, mt = ck.w, d0 = ck.y, d1 = ck.z;
 		// the next chunk's record now, its target and descriptors once the record has arrived (below)
 		const int nid = cid + cstride;
 		int4 nk = make_int4(0, 0, 0, 1);
-		if (nid < total) nk = chunk[nid];
+		if (nid < total) nk = sane_chunk(chunk[nid]);
 		float4 npt = pt;
 		int2 ndsc = make_int2(0, 0);
 		bool next_loaded = false;
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(64 * kP2PWaves) NBCO_P2P_ATTR void p2p_kernel(const
 			for (int eb = d0; eb < d1; eb += 64)
 			{
 				const int nent = min(64, d1 - eb);
-				const int2 mine = (eb == d0) ? dsc : ((lane < nent) ? desc[eb + lane] : make_int2(0, 0));
+				const int2 mine = (eb == d0) ? dsc : ((lane < nent) ? sane_desc(desc[eb + lane]) : make_int2(0, 0));
 				const int ntile = (nent + G - 1) / G;
 				// tile (et, jc) covers descriptor et * G + g, source particles jc * TPL + li
 				auto fetch = [&](int et, int jc) -> float4 {
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(64 * kP2PWaves) NBCO_P2P_ATTR void p2p_kernel(const
 						{
 							// last tile of a descriptor batch: the next chunk's record has long arrived
 							npt = pos[nk.x + min(li, nk.w - 1)];
-							ndsc = lane < nk.z - nk.y ? desc[nk.y + lane] : make_int2(0, 0);
+							ndsc = lane < nk.z - nk.y ? sane_desc(desc[nk.y + lane]) : make_int2(0, 0);
 							next_loaded = true;
 						}
 						wave_lds_sync();
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(64 * kP2PWaves) NBCO_P2P_ATTR void p2p_kernel(const
 		if (!next_loaded && nid < total)
 		{
 			npt = pos[nk.x + min(li, nk.w - 1)];
-			ndsc = lane < nk.z - nk.y ? desc[nk.y + lane] : make_int2(0, 0);
+			ndsc = lane < nk.z - nk.y ? sane_desc(desc[nk.y + lane]) : make_int2(0, 0);
 		}
 		ck = nk; pt = npt; dsc = ndsc;
 	}
@@ -160,10 +164,10 @@ __global__ __launch_bounds__(64 * kP2PWaves) NBCO_P2P_ATTR void p2p_kernel(const
 // when the estimate was too small.
 template <int TPL>
 static void launch_p2p(nbco_ctx *c, const float4 *pos, const int2 *desc, const int4 *chunk, const int *ntotal, long long chunks_hint, int src_max,
-                       int stride, float4 *partial)
+                       int stride, float4 *partial, long long npos)
 {
 	const int grid = (int)std::max<long long>(1, (chunks_hint + kP2PWaves - 1) / kP2PWaves);
-	hipLaunchKernelGGL(p2p_kernel<TPL>, dim3(grid), dim3(64 * kP2PWaves), 0, c->stream, pos, desc, chunk, ntotal, c->o.eps2, src_max, stride, partial);
+	hipLaunchKernelGGL(p2p_kernel<TPL>, dim3(grid), dim3(64 * kP2PWaves), 0, c->stream, pos, desc, chunk, ntotal, c->o.eps2, src_max, stride, partial, (int)npos);
 }
 
 
@@ -211,16 +215,18 @@ __device__ __forceinline__ void mutual_steps(float px, float py, float pz, float
 template <int TH>
 __global__ __launch_bounds__(256) void p2p_mutual_kernel(const float4 *__restrict__ pos, const int4 *__restrict__ desc, const int4 *__restrict__ chunk,
                                                          const int *__restrict__ nchunks_total, float eps2, int stride, float4 *__restrict__ partial,
-                                                         float4 *__restrict__ react, int react_cap)
+                                                         float4 *__restrict__ react, int react_cap, int npos)
 {
 	const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, row = lane >> 4, k = lane & 15;
+	auto sane_desc = [&](int4 d) { return NBCO_CHECKED_OK(d.x >= 0 && d.y >= 0 && d.x + d.y <= npos && (unsigned)d.w <= 2u, NBCO_CHK_DESC) ? d : make_int4(0, 0, 0, 2); };
 	const int tsub = 16 * (row >> 1) + k, ssub = 16 * (row & 1) + k;   // this lane's particle inside a target / source half
 	const int total = *nchunks_total;
 	const int cstride = gridDim.x * 4;
 	const float4 far = make_float4(1.e18f, 1.e18f, 1.e18f, 0.f);
 	for (int cid = blockIdx.x * 4 + wv; cid < total; cid += cstride)
 	{
-		const int4 ck = chunk[cid];
+		int4 ck = chunk[cid];
+		if (!NBCO_CHECKED_OK(ck.x >= 0 && ck.w >= 1 && ck.x + ck.w <= npos && ck.y <= ck.z, NBCO_CHK_CHUNK)) ck = make_int4(0, 0, 0, 1);
 		const int it = __builtin_amdgcn_readfirstlane(ck.x), e0 = __builtin_amdgcn_readfirstlane(ck.y), e1 = __builtin_amdgcn_readfirstlane(ck.z),
 		          mt = __builtin_amdgcn_readfirstlane(ck.w);
 		// (loads always go to a valid particle and the value is replaced afterwards: a select between a load and a constant makes
@@ -243,12 +249,12 @@ __global__ __launch_bounds__(256) void p2p_mutual_kernel(const float4 *__restric
 			}
 		};
 		// the sources of the first entry; every later entry's are fetched while its predecessor is being evaluated
-		int4 d = e0 < e1 ? desc[e0] : make_int4(0, 0, 0, 2);
+		int4 d = e0 < e1 ? sane_desc(desc[e0]) : make_int4(0, 0, 0, 2);
 		float4 ps[TH];
 		load_sources(d, ps);
 		for (int e = e0; e < e1; ++e)
 		{
-			const int4 dn = e + 1 < e1 ? desc[e + 1] : make_int4(0, 0, 0, 2);
+			const int4 dn = e + 1 < e1 ? sane_desc(desc[e + 1]) : make_int4(0, 0, 0, 2);
 			float4 pn[TH];
 			load_sources(dn, pn);
 			const int code = __builtin_amdgcn_readfirstlane(d.w), ms = __builtin_amdgcn_readfirstlane(d.y);
@@ -316,16 +322,16 @@ static int p2p_mutual_halves(int mlt_max)
 }
 
 static void launch_p2p_mutual(nbco_ctx *c, int th, const float4 *pos, const int4 *desc, const int4 *chunk, const int *ntotal, long long chunks_hint, int stride,
-                              float4 *partial, float4 *react, long long react_cap)
+                              float4 *partial, float4 *react, long long react_cap, long long npos)
 {
 	const int grid = (int)std::max<long long>(1, (chunks_hint + 3) / 4);
 	const int cap = (int)std::min<long long>(react_cap, 0x7fffffff);
 	if (th == 1)
-		hipLaunchKernelGGL(p2p_mutual_kernel<1>, dim3(grid), dim3(256), 0, c->stream, pos, desc, chunk, ntotal, c->o.eps2, stride, partial, react, cap);
+		hipLaunchKernelGGL(p2p_mutual_kernel<1>, dim3(grid), dim3(256), 0, c->stream, pos, desc, chunk, ntotal, c->o.eps2, stride, partial, react, cap, (int)npos);
 	else if (th == 2)
-		hipLaunchKernelGGL(p2p_mutual_kernel<2>, dim3(grid), dim3(256), 0, c->stream, pos, desc, chunk, ntotal, c->o.eps2, stride, partial, react, cap);
+		hipLaunchKernelGGL(p2p_mutual_kernel<2>, dim3(grid), dim3(256), 0, c->stream, pos, desc, chunk, ntotal, c->o.eps2, stride, partial, react, cap, (int)npos);
 	else
-		hipLaunchKernelGGL(p2p_mutual_kernel<4>, dim3(grid), dim3(256), 0, c->stream, pos, desc, chunk, ntotal, c->o.eps2, stride, partial, react, cap);
+		hipLaunchKernelGGL(p2p_mutual_kernel<4>, dim3(grid), dim3(256), 0, c->stream, pos, desc, chunk, ntotal, c->o.eps2, stride, partial, react, cap, (int)npos);
 }
 
 } // namespace

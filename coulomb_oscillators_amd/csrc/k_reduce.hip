@@ -228,6 +228,19 @@ int launch_pow_sum(nbco_ctx *c, const float *x, int expo, long long n, double *o
 	return finish_sum3(c, g, 1.0, out3_host);
 }
 
+// kinetic and elastic part only (nbco_energy_fmm adds the Coulomb part from the FMM lists)
+int launch_energy_kin_ela(nbco_ctx *c, const float *buf, long long n, const float *param, double *out2_host)
+{
+	if (n <= 0) return c->fail(NBCO_ERR_ARG, "energy: n must be positive");
+	double h1[3];
+	int g = grid_for(n);
+	NBCO_TRY(c->reserve(c->part, sizeof(double) * 3 * kMaxBlocks));
+	hipLaunchKernelGGL(energy1_stage1, dim3(g), dim3(kBlock), 0, c->stream, buf, n, param, c->part.as<double>());
+	NBCO_TRY(finish_sum3(c, g, 1.0, h1));
+	out2_host[0] = h1[0]; out2_host[1] = h1[1];
+	return NBCO_OK;
+}
+
 int launch_energy(nbco_ctx *c, const float *buf, long long n, const float *param, double *out3_host)
 {
 	if (n <= 0) return c->fail(NBCO_ERR_ARG, "energy: n must be positive");
@@ -240,6 +253,7 @@ int launch_energy(nbco_ctx *c, const float *buf, long long n, const float *param
 	}
 	{
 		NBCO_TRY(c->reserve(c->pos4, sizeof(float4) * (size_t)n));
+		c->last_eval.valid = false;   // the tree-ordered positions of the last kd evaluation are overwritten
 		NBCO_TRY(launch_pack4(c, c->pos4.as<float4>(), buf, n));
 		int g = ceil_div(n, kBlock);
 		NBCO_TRY(c->reserve(c->part, sizeof(double) * 3 * (size_t)g));

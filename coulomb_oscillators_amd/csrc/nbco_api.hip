@@ -24,6 +24,7 @@ int nbco_ctx::reserve(DevBuf &b, size_t bytes)
 	size_t want = bytes + bytes / 8 + 256;
 	NBCO_HIP(hipMalloc(&b.ptr, want));
 	b.bytes = want;
+	if (poison) NBCO_HIP(hipMemsetAsync(b.ptr, 0x7f, want, stream));
 	return NBCO_OK;
 }
 
@@ -151,6 +152,7 @@ int nbco_create(nbco_ctx **out, const nbco_opts *o)
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
 	c->stream = (hipStream_t)c->o.stream;
+	c->poison = getenv("NBCO_POISON") && atoi(getenv("NBCO_POISON")) != 0;
 	if (hipMalloc(&c->small.ptr, 4096) != hipSuccess) { delete c; return NBCO_ERR_HIP; }
 	c->small.bytes = 4096;
 	*out = c;
@@ -503,6 +505,18 @@ int nbco_energy(nbco_ctx *c, const float *buf, long long n, const float *param, 
 	return launch_energy(c, buf, n, param, out3_host);
 }
 
+int nbco_energy_fmm(nbco_ctx *c, const float *buf, long long n, const float *param, double *out3_host)
+{
+	if (!c || !buf || !param || !out3_host) return c ? c->fail(NBCO_ERR_ARG, "nbco_energy_fmm: null pointer") : NBCO_ERR_ARG;
+	double ke[2], half_phi = 0;
+	NBCO_TRY(launch_energy_kin_ela(c, buf, n, param, ke));
+	NBCO_TRY(kd_energy_fmm(c, n, &half_phi));
+	float p0;
+	NBCO_HIP(hipMemcpy(&p0, param, sizeof(float), hipMemcpyDeviceToHost));
+	out3_host[0] = ke[0]; out3_host[1] = ke[1]; out3_host[2] = (double)p0 * half_phi;
+	return NBCO_OK;
+}
+
 // ---- introspection -----------------------------------------------------------------------------
 int nbco_kd_get_info(nbco_ctx *c, nbco_kd_info *info)
 {
@@ -521,6 +535,24 @@ int nbco_kd_copy(nbco_ctx *c, int which, void *host_dst, long long host_bytes)
 {
 	if (!c || !host_dst) return NBCO_ERR_ARG;
 	return kd_copy_out(c, which, host_dst, host_bytes);
+}
+
+// ---- checked build -----------------------------------------------------------------------------
+int nbco_debug_violations(nbco_ctx *c, long long *out8)
+{
+	if (!c || !out8) return c ? c->fail(NBCO_ERR_ARG, "nbco_debug_violations: null pointer") : NBCO_ERR_ARG;
+	for (int i = 0; i < NBCO_CHK_SITES; ++i) out8[i] = 0;
+#ifdef NBCO_CHECKED
+	NBCO_HIP(hipDeviceSynchronize());
+	unsigned v[NBCO_CHK_SITES] = {};
+	NBCO_TRY(nbco_checked_collect_kd(v));
+	NBCO_TRY(nbco_checked_collect_oct(v));
+	NBCO_TRY(nbco_checked_collect_far(v));
+	for (int i = 0; i < NBCO_CHK_SITES; ++i) out8[i] = v[i];
+	return NBCO_OK;
+#else
+	return c->fail(NBCO_ERR_UNSUPPORTED, "nbco_debug_violations: this is not the checked build (libnbco_hip_checked.so)");
+#endif
 }
 
 // ---- profiling ---------------------------------------------------------------------------------

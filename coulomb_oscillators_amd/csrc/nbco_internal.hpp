@@ -27,6 +27,40 @@
 		if (rc_ != NBCO_OK) return rc_;  \
 	} while (0)
 
+// ---- checked build (-DNBCO_CHECKED, libnbco_hip_checked.so) ------------------------------------------------------------
+// Every index that a kernel READS FROM A LIST (frontier pairs, unordered pair lists and their slots, sorted entries, source
+// descriptors, work units) is range-checked before it is used as an address: a violation is counted per site and the index
+// replaced by a harmless one, so that a corrupted or stale list shows up as a number (nbco_debug_violations) instead of a GPU
+// memory fault.  The production build compiles the checks away.
+enum
+{
+	NBCO_CHK_FRONTIER = 0,   // traverse_kernel: node ids of a frontier pair
+	NBCO_CHK_FILL = 1,       // list_fill_kernel: region slot, targets, slot inside the target's range
+	NBCO_CHK_SORT = 2,       // list_segsort_kernel: source index of an entry, output slot
+	NBCO_CHK_CHUNK = 3,      // pair kernels: work-unit record
+	NBCO_CHK_DESC = 4,       // pair kernels: source descriptor
+	NBCO_CHK_L2P = 5,        // l2p_gen_kernel: chunk range, reaction record
+	NBCO_CHK_SITES = 8
+};
+#ifdef NBCO_CHECKED
+namespace { __device__ unsigned nbco_violation_count[NBCO_CHK_SITES]; }
+#define NBCO_CHECKED_OK(cond, site) ((cond) ? true : (atomicAdd(&nbco_violation_count[site], 1u), false))
+#define NBCO_CHECKED_COLLECT(fn)                                                                                      \
+	int fn(unsigned *out)                                                                                             \
+	{                                                                                                                 \
+		unsigned v[NBCO_CHK_SITES];                                                                                   \
+		if (hipMemcpyFromSymbol(v, HIP_SYMBOL(nbco_violation_count), sizeof v) != hipSuccess) return NBCO_ERR_HIP;    \
+		for (int i = 0; i < NBCO_CHK_SITES; ++i) out[i] += v[i];                                                      \
+		return NBCO_OK;                                                                                               \
+	}
+#else
+#define NBCO_CHECKED_OK(cond, site) (true)
+#define NBCO_CHECKED_COLLECT(fn) int fn(unsigned *) { return NBCO_OK; }
+#endif
+int nbco_checked_collect_kd(unsigned *out);
+int nbco_checked_collect_oct(unsigned *out);
+int nbco_checked_collect_far(unsigned *out);
+
 // device buffer that only grows (the reference's evaluators keep their scratch in function-local
 // statics that grow monotonically, fmm_cart3_kdtree.cuh:1480-1498)
 struct DevBuf
@@ -85,7 +119,10 @@ struct nbco_ctx
 	bool grow_lists(int ntot)   // false: growth is off or exhausted
 	{
 		if (!o.list_grow || list_growth >= 64) return false;
-		if (4LL * list_growth * o.list_factor * (long long)ntot >= (1LL << 31)) return false;   // 32-bit list offsets
+		// 32-bit offsets: the DIRECTED P2P list holds up to 2 * cap + leaves entries, cap = 2 * (growth * factor * nodes + 4096),
+		// and its prefix sums (start[], chunk_off[], the low word of the packed scan) are ints: the doubled capacity must keep
+		// 2 * cap + nodes below 2^31
+		if (8LL * list_growth * o.list_factor * (long long)ntot + 16384 + ntot >= (1LL << 31)) return false;
 		list_growth *= 2;
 		return true;
 	}
@@ -95,6 +132,8 @@ struct nbco_ctx
 	double host_wait_s = 0, host_call_s = 0;   // diagnostics (NBCO_HOST_TIMING): time blocked on the flags event / inside nbco_integrate
 	long long host_calls = 0;
 	bool aux_is_main = false;   // NBCO_AUX_SERIAL=1 (diagnostics): the second stream is the main stream
+	bool poison = false;        // NBCO_POISON=1 (diagnostics): every new scratch allocation is filled with 0x7f bytes, the way a recycled
+	                            // allocation holds stale data: nothing may depend on fresh memory being zero
 	// traversal counts / flags land in pinned host memory; looked at after the rest of the evaluation is enqueued
 	int *h_flags = nullptr;
 	hipEvent_t ev_flags = nullptr;
@@ -150,6 +189,16 @@ struct nbco_ctx
 		return false;
 	}
 	long long list_cap = 0;
+	// the last kd-tree evaluation, for nbco_energy_fmm (pointers into the context's buffers; valid while tree_valid)
+	struct LastEval
+	{
+		bool valid = false, have_p2p = false;
+		const float *center = nullptr, *mpole = nullptr;
+		const float4 *csz = nullptr, *pos = nullptr;
+		const int *mult = nullptr, *index = nullptr;
+		int L = 0, ntot = 0, order = 0, shift = 0;
+		long long n = 0, own0 = 0, own_n = 0;
+	} last_eval;
 	// bookkeeping of the last evaluation
 	nbco_kd_info info{};
 	long long eval_counter = 0;
@@ -215,6 +264,8 @@ int launch_energy(nbco_ctx *c, const float *buf, long long n, const float *param
 int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *param);
 int kd_copy_out(nbco_ctx *c, int which, void *host_dst, long long host_bytes);
 int kd_count_pairs(nbco_ctx *c, long long *out);
+int kd_energy_fmm(nbco_ctx *c, long long n_own, double *half_phi_sum);
+int launch_energy_kin_ela(nbco_ctx *c, const float *buf, long long n, const float *param, double *out2_host);
 // k_fmm_oct.hip
 int fmm_oct_traceless_eval(nbco_ctx *c, float *p, float *a, long long n, const float *param);
 int oct_copy_out(nbco_ctx *c, int which, void *host_dst, long long host_bytes);

@@ -218,12 +218,13 @@ class DomainRun:
         return mm
 
     def energy(self, param):
-        """(kinetic, elastic) energy of the whole system.  The Coulomb part of nbco_energy is an O(N^2) diagnostic over
-        ONE buffer; for a sharded run gather the positions and evaluate it on one GPU."""
-        kin, ela, _ = self.eng.energy(self.buf, self.n_local, param)
-        t = torch.tensor([kin, ela], dtype=torch.float64, device=self.device)
+        """(kinetic, elastic, coulomb) energy of the whole system at the positions of the last force evaluation: every rank sums
+        its own particles (the Coulomb part from the interaction lists of that evaluation, nbco_energy_fmm), one all-reduce of
+        three scalars"""
+        kin, ela, cou = self.eng.energy_fmm(self.buf, self.n_local, param)
+        t = torch.tensor([kin, ela, cou], dtype=torch.float64, device=self.device)
         self.comm.all_reduce(t, "sum")
-        return float(t[0]), float(t[1])
+        return float(t[0]), float(t[1]), float(t[2])
 
     # ---- kick-drift-kick leapfrog on the local state (integrator.cuh:68-80) --------------------------
     def leapfrog(self, param, dt, elastic=True, first=False):

@@ -106,6 +106,7 @@ def _load():
         "nbco_mean_relerr": [P, P, P, LL, C.POINTER(F)],
         "nbco_pow_sum": [P, P, I, LL, C.POINTER(D)],
         "nbco_energy": [P, P, LL, P, C.POINTER(D)],
+        "nbco_energy_fmm": [P, P, LL, P, C.POINTER(D)],
         "nbco_kd_get_info": [P, C.POINTER(KdInfo)],
         "nbco_kd_copy": [P, I, P, LL],
         "nbco_oct_get_info": [P, C.POINTER(OctInfo)],
@@ -121,6 +122,7 @@ def _load():
         "nbco_dist_finish_traverse": [P, P, P],
         "nbco_dist_finish_rest": [P, P, P, P, P],
         "nbco_aux_stream": [P, C.POINTER(C.c_void_p)],
+        "nbco_debug_violations": [P, C.POINTER(LL)],
         "nbco_profile_enable": [P, I],
         "nbco_profile_reset": [P],
         "nbco_profile_get": [P, I, C.POINTER(D), C.POINTER(LL)],
@@ -258,6 +260,12 @@ class Engine:
         self._chk(self.lib.nbco_energy(self.ctx, _ptr(buf), n, _ptr(param), out))
         return list(out)
 
+    def energy_fmm(self, buf, n, param):
+        """{kinetic, elastic, coulomb} with the Coulomb part from the lists of the last kd-tree evaluation (O(N log N))"""
+        out = (C.c_double * 3)()
+        self._chk(self.lib.nbco_energy_fmm(self.ctx, _ptr(buf), n, _ptr(param), out))
+        return list(out)
+
     # ---- multi-GPU kd-domain sharding (see dist.py for the orchestration) ---------------------------
     def dist_layout(self, n_global, world, rank):
         lay = DistLayout()
@@ -338,6 +346,13 @@ class Engine:
         out = np.empty(shape, dtype=dt)
         self._chk(self.lib.nbco_oct_copy(self.ctx, OCT_FIELDS[name], out.ctypes.data_as(C.c_void_p), out.nbytes))
         return out
+
+    # ---- checked build (libnbco_hip_checked.so, selected with NBCO_LIB) ------------------------------------
+    def violations(self):
+        """per-site counts of list-derived indices that failed their range check on the device (checked build only)"""
+        out = (C.c_longlong * 8)()
+        self._chk(self.lib.nbco_debug_violations(self.ctx, out))
+        return list(out)
 
     # ---- profiling ------------------------------------------------------------------------------
     def profile(self, phases=True):

@@ -135,6 +135,11 @@ int nbco_mean_relerr(nbco_ctx *c, const float *x, const float *ref, long long n,
 int nbco_pow_sum(nbco_ctx *c, const float *x, int expo, long long n, double *out3_host);  /* reductions.cuh:590 powReduce */
 /* total energy {kinetic, elastic, coulomb}; no reference counterpart */
 int nbco_energy(nbco_ctx *c, const float *buf, long long n, const float *param, double *out3_host);
+/* the same with the Coulomb part from the interaction lists and multipoles of the LAST nbco_fmm_kdtree evaluation (which must
+ * have been made at the positions in buf): near field pair by pair over the P2P list, far field by evaluating the multipole
+ * expansions of the M2L sources at the particles (the reference's m2p_pot3, fmm_cart_base3.cuh:1474-1490), fp64, O(N log N)
+ * instead of O(N^2).  Sharded runs: n = the domain's particles, every rank gets its share of the three sums. */
+int nbco_energy_fmm(nbco_ctx *c, const float *buf, long long n, const float *param, double *out3_host);
 
 /* ---- introspection of the last kd-tree evaluation (parity tests, benchmarks) ----------------- */
 typedef struct nbco_kd_info {
@@ -251,6 +256,14 @@ enum {
 int nbco_profile_enable(nbco_ctx *c, int mask);     /* bit i: record a pair of events around phase i; -1 = all, 0 = off */
 int nbco_profile_reset(nbco_ctx *c);
 int nbco_profile_get(nbco_ctx *c, int phase, double *total_ms, long long *launches);  /* syncs */
+
+/* ---- checked build (libnbco_hip_checked.so, compiled with -DNBCO_CHECKED) -----------------------------------------
+ * Same ABI; every index a kernel reads from a list (traversal frontier, pair lists, sorted entries, source descriptors,
+ * work units) is range-checked on the device, counted per site and replaced by a harmless one instead of being used as
+ * an address.  out8[site] = violations since the library was loaded (sites: 0 frontier, 1 list fill, 2 list sort,
+ * 3 work unit, 4 source descriptor, 5 L2P); the production library returns NBCO_ERR_UNSUPPORTED.
+ * NBCO_POISON=1 in the environment (either build) fills every new scratch allocation with 0x7f bytes. */
+int nbco_debug_violations(nbco_ctx *c, long long *out8);
 
 /* ---- initial condition (host only, no GPU needed) ----------------------------------------------
  * The reference's synthetic state: initGA (main3.cu:113-137) over std::mt19937_64(seed) after discard(discard)

@@ -90,7 +90,7 @@ class NumpyDomainEngine:
         q = p.numpy()[:3 * n].reshape(n, 3)
         return torch.from_numpy(np.stack([q.min(0), q.max(0)]))
 
-    def energy(self, buf, n, param):
+    def energy_fmm(self, buf, n, param):
         b = buf.numpy().astype(np.float64)
         x, v = b[:3 * n].reshape(n, 3), b[3 * n:6 * n].reshape(n, 3)
         k = param.numpy()[3:6].astype(np.float64)
@@ -180,7 +180,7 @@ def _worker(rank, world, port, n, steps, dt, rebalance, outdir, split=False):
         res = _drive(run, torch.from_numpy(par), steps, dt)
         np.save(os.path.join(outdir, "rank%d.npy" % rank), res)
         mm = run.minmax().numpy()
-        kin, ela = run.energy(torch.from_numpy(par))
+        kin, ela, _ = run.energy(torch.from_numpy(par))
         np.save(os.path.join(outdir, "scal%d.npy" % rank), np.concatenate([mm.ravel(), [kin, ela]]))
         with open(os.path.join(outdir, "calls%d.txt" % rank), "w") as f:
             f.write(" ".join(eng.calls))

@@ -163,3 +163,55 @@ def test_integrators_with_direct_force(engine, oracle32, scheme):
         scale = np.abs(buf[k]).max()
         assert np.abs(got[k] - buf[k]).max() <= 1e-6 * scale, name
     assert force_err(got[2], buf[2]) < 1e-5
+
+
+@pytest.mark.parametrize("n,p", [(3000, 6), (20000, 6), (65536, 6), (65536, 8), (30001, 10), (4096, 3)])
+def test_energy_fmm_against_fp64_direct_energy(engine, oracle32, oracle64, n, p):
+    """nbco_energy_fmm: Coulomb energy from the lists and multipoles of the last kd-tree evaluation (P2P potential + multipole
+    expansions evaluated at the particles) against the fp64 direct sum over the same fp32 positions.  The far field carries the
+    truncation error of order-p multipoles at the reference's opening radius; what is asserted is what it measures at."""
+    import torch
+    from coulomb_oscillators_amd import EVAL_FMM_KDTREE
+    buf = oracle32.init_reference(n)
+    par = oracle32.params(n)
+    want = oracle64.energy(buf.astype(np.float64), par.astype(np.float64), threads=8)
+    for unsort in (1, 0):
+        engine.set(fmm_order=p, unsort=unsort)
+        d = dev(buf.copy())
+        engine.compute_force(EVAL_FMM_KDTREE, d, n, dev(par))
+        got = engine.energy_fmm(d, n, dev(par))
+        assert abs(got[0] - want[0]) <= 1e-6 * want[0] and abs(got[1] - want[1]) <= 1e-6 * want[1]
+        tol = {3: 3e-3, 6: 2e-4, 8: 5e-5, 10: 2e-5}[p]
+        assert abs(got[2] - want[2]) <= tol * want[2], (got[2], want[2], abs(got[2] - want[2]) / want[2])
+    # the O(N^2) reduction agrees with the oracle to fp32 pair rounding; the FMM one must not be further from it than its tolerance
+    if n <= 20000:
+        ref = engine.energy(d, n, dev(par))
+        assert abs(ref[2] - want[2]) <= 1e-5 * want[2]
+        from coulomb_oscillators_amd import EngineError
+        with pytest.raises(EngineError, match="no kd-tree evaluation"):     # nbco_energy repacked the positions: the lists are stale
+            engine.energy_fmm(d, n, dev(par))
+
+
+def test_energy_fmm_large_system_against_sampled_direct_sum(engine, oracle32):
+    """N = 1M: the FMM potential energy against a direct fp64 sum over a sample of the particles (the O(N^2) reduction takes
+    seconds here and is the thing this entry point replaces)"""
+    import torch
+    from coulomb_oscillators_amd import EVAL_FMM_KDTREE
+    n, p, m = 1 << 20, 6, 2048
+    buf = oracle32.init_reference(n)
+    par = oracle32.params(n)
+    engine.set(fmm_order=p, unsort=0)
+    d = dev(buf.copy())
+    engine.compute_force(EVAL_FMM_KDTREE, d, n, dev(par))
+    got = engine.energy_fmm(d, n, dev(par))
+    x = d[0].double()
+    idx = torch.randperm(n, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))[:m]
+    phi = torch.zeros(m, dtype=torch.float64, device="cuda")
+    for s in range(0, n, 1 << 16):
+        r2 = ((x[idx][:, None, :] - x[None, s:s + (1 << 16), :]) ** 2).sum(-1) + 1e-18
+        w = r2.rsqrt()
+        w[r2 < 1e-17] = 0.0                    # the particle itself
+        phi += w.sum(1)
+    est = float(par[0]) * 0.5 * float(phi.mean()) * n
+    sem = float(par[0]) * 0.5 * float(phi.std()) / np.sqrt(m) * n
+    assert abs(got[2] - est) < 5 * sem + 3e-4 * est, (got[2], est, sem)
