@@ -1046,7 +1046,7 @@ __global__ __launch_bounds__(kBlock) void traverse_init_kernel(int2 *frontier, i
 // The counts and flags the host looks at after the evaluation go straight to pinned host memory (`host_flags`: P2P pairs, M2L
 // pairs, list overflow, tie flag of the build) -- two device-to-host copies less on the critical path.
 __global__ __launch_bounds__(1024) void traverse_finish_kernel(int *counters, int *tctr, long long capR, unsigned *cnt_all, long long ncnt,
-                                                               unsigned *cnt_self, int nself, int *__restrict__ host_flags, int iters)
+                                                               unsigned *cnt_self, int nself, int *__restrict__ host_flags, int iters, int seq)
 {
 	const int lane = threadIdx.x;
 	const bool overflow = counters[2] != 0;
@@ -1070,6 +1070,9 @@ __global__ __launch_bounds__(1024) void traverse_finish_kernel(int *counters, in
 	int left = lane < kTravK ? tctr[kTcFrontier + iters * kTravK + lane] : 0;
 	for (int o = 32; o > 0; o >>= 1) left += __shfl_xor(left, o);
 	if (lane == 0) { host_flags[2] = overflow ? 1 : (left != 0 ? 2 : 0); host_flags[3] = counters[110]; }
+	// the host spins on this word (nbco_ctx::wait_flags): it must land after the four values above
+	__threadfence_system();
+	if (lane == 0) __hip_atomic_store(&host_flags[4], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // dense copy of a region-structured pair list (nbco_kd_copy)
@@ -1708,7 +1711,7 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 			std::swap(fa, fb);
 		}
 		hipLaunchKernelGGL(traverse_finish_kernel, dim3(1), dim3(1024), 0, st, ctr, tctr, capR, c->list_cnt.as<unsigned>(), (long long)(2 * (np_ + nm_)),
-		                   cnt_p2p + self0, c->o.coll ? nself : 0, c->h_flags, iters);
+		                   cnt_p2p + self0, c->o.coll ? nself : 0, c->h_flags, iters, ++c->flags_seq);
 		NBCO_HIP(hipGetLastError());
 		// counts and flags are in pinned host memory once this event has passed; the host looks at them only after it has
 		// enqueued the rest of the evaluation (every later kernel takes its counts from the device), so the GPU never
@@ -1736,16 +1739,31 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 	{
 		if (c->hint_np2p <= 0)
 		{
-			NBCO_HIP(hipEventSynchronize(c->ev_flags));
+			NBCO_TRY(c->wait_flags());
 			c->hint_np2p = c->h_flags[0];
 			c->hint_nm2l = c->h_flags[1];
 		}
 		react_cap = std::min(cap, c->hint_np2p + c->hint_np2p / 4 + 1024);
 		NBCO_TRY(c->reserve(c->p2p_react, sizeof(float4) * 32 * (size_t)mutual_th * (size_t)react_cap));
 	}
+	float4 *near = nullptr;
+	auto enqueue_p2p = [&]() -> int {
+		NBCO_TRY(c->reserve(c->part, sizeof(float4) * (size_t)max_chunks * (size_t)mlt_max));
+		near = c->part.as<float4>();
+		PhaseScope ph(c, NBCO_PH_P2P);
+		const int4 *pc = c->p2p_chunks.as<int4>();
+		const int *pt = c->p2p_chunk_off.as<int>() + nleaf;   // total number of chunks
+		const int2 *pd = c->p2p_desc.as<int2>();
+		if (mutual) launch_p2p_mutual(c, mutual_th, pos, c->p2p_desc.as<int4>(), pc, pt, chunks_hint, mlt_max, near, c->p2p_react.as<float4>(), react_cap, n);
+		else if (mlt_max <= 8) launch_p2p<8>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near, n);
+		else if (mlt_max <= 16) launch_p2p<16>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near, n);
+		else if (mlt_max <= 32) launch_p2p<32>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near, n);
+		else launch_p2p<64>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near, n);
+		NBCO_HIP(hipGetLastError());
+		return NBCO_OK;
+	};
 	// ---- directed sorted lists --------------------------------------------------------------------------
 	{
-		PhaseScope ph(c, NBCO_PH_LISTS);
 		NBCO_TRY(c->reserve(c->p2p_keys, sizeof(uint64_t) * (size_t)(dp2p_cap + 1)));
 		NBCO_TRY(c->reserve(c->p2p_keys_alt, sizeof(uint64_t) * (size_t)(dp2p_cap + 1)));
 		NBCO_TRY(c->reserve(c->m2l_keys, sizeof(uint64_t) * (size_t)(dm2l_cap + 1)));
@@ -1757,6 +1775,7 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		NBCO_TRY(c->fork_mark());
 		if (c->o.coll)
 		{
+			PhaseScope ph(c, NBCO_PH_LISTS);
 			unsigned *cp = c->list_cnt.as<unsigned>();
 			NBCO_TRY(c->reserve(c->p2p_desc, (mutual ? sizeof(int4) : sizeof(int2)) * (size_t)(dp2p_cap + 1)));
 			MutualLists mu;
@@ -1775,6 +1794,7 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 			// remembered for nbco_kd_get_info (the directed pair count is evaluated on demand)
 			c->pc_mult = tv.mult + beg; c->pc_shift = shift; c->pc_total = c->p2p_start.as<int>() + nleaf;
 		}
+		if (c->o.coll) NBCO_TRY(enqueue_p2p());   // before the host spends its time on the far-field chain below: the pair kernel is next on this stream
 		// the far field does not depend on the P2P list: M2L list, M2L and L2L run on the second stream, behind the
 		// multipole chain, and overlap the P2P list chain and the start of P2P
 		// (the locals are cleared on the second stream before it starts waiting for the traversal)
@@ -1798,22 +1818,6 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		}
 		NBCO_HIP(hipGetLastError());
 	}
-	// ---- P2P --------------------------------------------------------------------------------------------
-	if (c->o.coll) NBCO_TRY(c->reserve(c->part, sizeof(float4) * (size_t)max_chunks * (size_t)mlt_max));
-	float4 *near = c->part.as<float4>();
-	if (c->o.coll)
-	{
-		PhaseScope ph(c, NBCO_PH_P2P);
-		const int2 *pd = c->p2p_desc.as<int2>();
-		const int4 *pc = c->p2p_chunks.as<int4>();
-		const int *pt = c->p2p_chunk_off.as<int>() + nleaf;   // total number of chunks
-		if (mutual) launch_p2p_mutual(c, mutual_th, pos, c->p2p_desc.as<int4>(), pc, pt, chunks_hint, mlt_max, near, c->p2p_react.as<float4>(), react_cap, n);
-		else if (mlt_max <= 8) launch_p2p<8>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near, n);
-		else if (mlt_max <= 16) launch_p2p<16>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near, n);
-		else if (mlt_max <= 32) launch_p2p<32>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near, n);
-		else launch_p2p<64>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near, n);
-		NBCO_HIP(hipGetLastError());
-	}
 	// ---- L2P + rescale + (un)sort -------------------------------------------------------------------------
 	NBCO_TRY(c->join_aux());   // far field (multipoles, M2L list, M2L, L2L) complete
 	{
@@ -1825,7 +1829,7 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 	// ---- now look at what the traversal reported (long finished: the GPU is busy with the work queued above) ----------
 	{
 		const auto t0 = std::chrono::steady_clock::now();
-		NBCO_HIP(hipEventSynchronize(c->ev_flags));
+		NBCO_TRY(c->wait_flags());
 		c->host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 	}
 	const int *h = c->h_flags;

@@ -79,9 +79,33 @@ int nbco_ctx::flags_begin()
 	if (!h_flags)
 	{
 		NBCO_HIP_M(this, hipHostMalloc((void **)&h_flags, 64 * sizeof(int), hipHostMallocDefault));
+		memset(h_flags, 0, 64 * sizeof(int));
 		NBCO_HIP_M(this, hipEventCreateWithFlags(&ev_flags, hipEventDisableTiming));
 	}
 	return NBCO_OK;
+}
+
+// The host looks at the traversal's counts and flags once per evaluation, after everything else has been enqueued.  A blocking
+// hipEventSynchronize wakes up tens of microseconds after the kernel has finished -- time the next step's launches start
+// late by -- so the host polls the sequence word that traverse_finish_kernel stores last in pinned memory, and asks the
+// event only now and then (a failed launch or a lost device must not leave it spinning).
+int nbco_ctx::wait_flags()
+{
+	nbco_ctx *c = this;
+	volatile int *seq = h_flags + 4;
+	for (unsigned spin = 1;; ++spin)
+	{
+		if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == flags_seq) return NBCO_OK;
+		if ((spin & 0x3FFu) == 0)
+		{
+			const hipError_t e = hipEventQuery(ev_flags);
+			if (e == hipSuccess) { if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == flags_seq) return NBCO_OK; NBCO_HIP(hipEventSynchronize(ev_flags)); return NBCO_OK; }
+			if (e != hipErrorNotReady) return fail_hip(e, "hipEventQuery(ev_flags)", __FILE__, __LINE__);
+		}
+#if defined(__x86_64__)
+		__builtin_ia32_pause();
+#endif
+	}
 }
 
 int nbco_ctx::join_aux()

@@ -139,6 +139,8 @@ struct nbco_ctx
 	hipEvent_t ev_flags = nullptr;
 	long long hint_np2p = 0, hint_nm2l = 0;   // list sizes of the previous evaluation (launch-size hints only)
 	int flags_begin();
+	int flags_seq = 0;   // sequence number of the traversal whose results h_flags[0..3] hold (h_flags[4], written last)
+	int wait_flags();    // until the traversal enqueued last has reported: spins on the pinned word, no interrupt-driven wake-up
 	DevBuf scan_tmp_aux;
 	int fork_aux();   // aux waits for everything enqueued on `stream` so far
 	int fork_mark();  // remember this point of `stream` ...

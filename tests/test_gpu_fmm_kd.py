@@ -344,7 +344,7 @@ def test_list_capacity_overflow_is_reported_and_recoverable(oracle32):
 
 
 @pytest.mark.parametrize("n,p,inhom,halves", [(4096, 6, 1.0, 1), (30001, 5, 1.0, 1), (65536, 6, 1.0, 1), (3000, 5, 1.3, 1), (46000, 6, 1.0, 2),
-                                              (100000, 6, 1.0, 2), (65536, 8, 1.0, 2), (32768, 10, 1.0, 4), (20000, 9, 1.0, 4),
+                                              (100000, 6, 1.0, 2), (65536, 8, 1.0, 2), (32768, 10, 1.0, 4), (24000, 9, 1.0, 4), (20000, 9, 1.0, 0),
                                               (5000, 6, 1.0, 0), (4096, 4, 1.0, 0)])
 def test_mutual_near_field_matches_oracle_and_the_one_directional_kernel(engine, oracle32, n, p, inhom, halves):
     """opts.p2p_mutual: every leaf pair evaluated once, the force applied to both leaves (the reference GPU kernel's Newton-III
