@@ -12,7 +12,7 @@ no LDS, no tables and no indexing:
     G^_m[x,y,z]  = (-1)^m uz^z sum_{k1<=x/2,k2<=y/2} (-1)^(k1+k2) (2m-2(k1+k2)-1)!! c2(x,k1) c2(y,k2)
                    ux^(x-2k1) uy^(y-2k2),  z in {0,1};  G^[x,y,z>=2] = -G^[x+2,y,z-2] - G^[x,y+2,z-2]
 
-(the same term lists as csrc/fmm_tables.cpp, which tests/test_tables.py checks against the oracle).
+(csrc/genops_host.cpp compiles the generated text for the host; tests/test_genops_host.py checks it against the oracle).
 Usage: gen_m2l.py <out.inc> [PMAX]
 """
 import sys

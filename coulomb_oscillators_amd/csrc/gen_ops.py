@@ -3,7 +3,7 @@
 orders 1..PMAX (companion of gen_m2l.py).
 
 Reference operators: fmm_cart_base3.cuh P2M :908-918, M2M :1042-1076, L2L :1348-1363, L2P :1511-1529
-(same term lists as csrc/fmm_tables.cpp, which tests/test_tables.py checks against the oracle).  With the
+(csrc/genops_host.cpp compiles the generated text for the host; tests/test_genops_host.py checks it against the oracle).  With the
 normalisations
 
     D~[K] = d^K / K!            M~[X] = M[X] |X|! / X!            L~[X] = L[X] |X|!      (X! = x! y! z!)

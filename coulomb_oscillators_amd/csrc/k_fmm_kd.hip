@@ -28,7 +28,6 @@
 //   multi-GPU kd-domain sharding: the same two stages (kd_build_upward on the own subtree, kd_interact on the
 //             assembled global tree, pruned to the own domain), see the section at the end of this file.
 #include "nbco_internal.hpp"
-#include "fmm_tables.hpp"
 #include "k_p2p.hpp"
 #include <rocprim/rocprim.hpp>
 #include <chrono>
@@ -38,8 +37,9 @@
 
 namespace {
 
-using fmmtab::sym_off;
-using fmmtab::tl_off;
+// tuple offsets (fmm_cart_base3.cuh:180-188): symmetric orders 0..n-1 hold n(n+1)(n+2)/6 reals, traceless orders 0..n-1 hold n^2
+constexpr int sym_off(int n) { return n * (n + 1) * (n + 2) / 6; }
+constexpr int tl_off(int n) { return n * n; }
 
 struct TreeView
 {

@@ -7,7 +7,6 @@
 #include <cmath>
 #include <new>
 #include <random>
-#include "fmm_tables.hpp"
 
 int nbco_ctx::reserve(DevBuf &b, size_t bytes)
 {
@@ -658,26 +657,6 @@ int nbco_init_gaussian(float *host_state, long long n, const float *sx, const fl
 		for (long long i = 0; i < n; ++i) { pos[i].x = dx(gen); pos[i].y = dy(gen); pos[i].z = dz(gen); }
 		centre_dist(pos, n);
 	}
-	return NBCO_OK;
-}
-
-int nbco_debug_table(int order, const char *name, void *out, long long cap, long long *count)
-{
-	if (order < 1 || order > kMaxOrder || !name || !count) return NBCO_ERR_ARG;
-	fmmtab::Tables t = fmmtab::build(order);
-	std::string s(name);
-	const void *src = nullptr;
-	long long n = 0;
-	bool found = false;
-#define NBCO_TAB(field) if (s == #field) { src = t.field.data(); n = (long long)t.field.size(); found = true; }
-	NBCO_TAB(sym_xyz) NBCO_TAB(mono_rec) NBCO_TAB(p2m_coef) NBCO_TAB(m2m_start) NBCO_TAB(m2m_idx) NBCO_TAB(m2m_coef)
-	NBCO_TAB(tl2full) NBCO_TAB(tl_order) NBCO_TAB(gp_start) NBCO_TAB(gp_exp) NBCO_TAB(gp_coef) NBCO_TAB(rf_start)
-	NBCO_TAB(rf_dst) NBCO_TAB(rf_a) NBCO_TAB(rf_b) NBCO_TAB(m2l_start) NBCO_TAB(m2l_idx) NBCO_TAB(m2l_coef)
-	NBCO_TAB(m_order) NBCO_TAB(l2l_start) NBCO_TAB(l2l_idx) NBCO_TAB(l2l_coef) NBCO_TAB(l2p_coef) NBCO_TAB(l2p_idx)
-#undef NBCO_TAB
-	if (!found) return NBCO_ERR_ARG;
-	*count = n;
-	if (out && src && n > 0) memcpy(out, src, (size_t)(n < cap ? n : cap) * 4);
 	return NBCO_OK;
 }
 

@@ -276,14 +276,6 @@ int nbco_debug_violations(nbco_ctx *c, long long *out8);
 int nbco_init_gaussian(float *host_state, long long n, const float *sigma_x3, const float *sigma_u3,
                        unsigned long long seed, unsigned long long discard, int uniform_positions);
 
-/* ---- operator tables (host only, no GPU needed) ------------------------------------------------
- * Copies the flattened coefficient / index table `name` for expansion order `order` into `out`
- * (int32 or float32 elements, at most `cap` of them) and stores the element count in *count.
- * The tables are the term lists (index pairs + coefficients) of P2M / M2M / M2L / L2L / L2P that the code
- * generators of csrc/ (gen_ops.py, gen_m2l.py) unroll into straight-line device code; applying them on the
- * host checks those term lists against the oracle on a machine without a GPU (tests/test_tables.py). */
-int nbco_debug_table(int order, const char *name, void *out, long long cap, long long *count);
-
 #ifdef __cplusplus
 }
 #endif
