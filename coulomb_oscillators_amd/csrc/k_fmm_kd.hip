@@ -1342,7 +1342,7 @@ __global__ __launch_bounds__(kBlock) void pair_count_kernel(const int *__restric
 // copy (the gather cannot run in place)
 __global__ __launch_bounds__(kBlock) void reorder_state_kernel(const float4 *__restrict__ pos, const int *__restrict__ unsort,
                                                                const float *__restrict__ v_in, float *__restrict__ p_out, float *__restrict__ v_tmp,
-                                                               long long n)
+                                                               long long n, const int *__restrict__ order_in, int *__restrict__ order_out)
 {
 	for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock)
 	{
@@ -1350,6 +1350,9 @@ __global__ __launch_bounds__(kBlock) void reorder_state_kernel(const float4 *__r
 		p_out[3 * i] = q.x; p_out[3 * i + 1] = q.y; p_out[3 * i + 2] = q.z;
 		const long long s = unsort[i];
 		v_tmp[3 * i] = v_in[3 * s]; v_tmp[3 * i + 1] = v_in[3 * s + 1]; v_tmp[3 * i + 2] = v_in[3 * s + 2];
+		// opts.track_order: the particle now at position i was at position s before this rebuild, i.e. it is particle
+		// order_in[s] of the state the tracking started from (order_in == nullptr: this is the first permutation)
+		if (order_out) order_out[i] = order_in ? order_in[s] : (int)s;
 	}
 }
 
@@ -1864,8 +1867,20 @@ static int kd_finish_order(nbco_ctx *c, float *p, long long n)
 	PhaseScope ph(c, NBCO_PH_FINISH);
 	hipStream_t st = c->stream;
 	NBCO_TRY(c->reserve(c->tmp3, sizeof(float) * 3 * (size_t)n));
+	const int *order_in = nullptr;
+	int *order_out = nullptr;
+	if (c->o.track_order)
+	{
+		// cumulative permutation across rebuilds (the reference keeps none: its snapshots are in tree order, main3.cu:855-858)
+		NBCO_TRY(c->reserve(c->order, sizeof(int) * (size_t)n));
+		NBCO_TRY(c->reserve(c->order_alt, sizeof(int) * (size_t)n));
+		if (c->order_n == n) order_in = c->order.as<int>();
+		order_out = c->order_alt.as<int>();
+	}
+	else c->order_n = -1;
 	hipLaunchKernelGGL(reorder_state_kernel, dim3(grid1d(n)), dim3(kBlock), 0, st, (const float4 *)c->pos4.as<float4>(), (const int *)c->unsort.as<int>(),
-	                   (const float *)(p + 3 * n), p, c->tmp3.as<float>(), n);
+	                   (const float *)(p + 3 * n), p, c->tmp3.as<float>(), n, order_in, order_out);
+	if (order_out) { std::swap(c->order, c->order_alt); c->order_n = n; }
 	if (c->defer_v_copy) c->v_deferred = c->tmp3.as<float>();   // the caller's next pass over the velocities reads them from here
 	else NBCO_HIP(hipMemcpyAsync(p + 3 * n, c->tmp3.ptr, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToDevice, st));
 	NBCO_HIP(hipGetLastError());
@@ -2448,6 +2463,9 @@ int kd_copy_out(nbco_ctx *c, int which, void *dst, long long bytes)
 		break;
 	}
 	case NBCO_KD_UNSORT: src = c->unsort.ptr; need = 4 * (size_t)k.n; break;
+	case NBCO_KD_ORDER:
+		if (!c->o.track_order || c->order_n != k.n) return c->fail(NBCO_ERR_ARG, "nbco_kd_copy: NBCO_KD_ORDER needs opts.track_order and unsort = 0 evaluations");
+		src = c->order.ptr; need = 4 * (size_t)k.n; break;
 	default: return c->fail(NBCO_ERR_ARG, "nbco_kd_copy: unknown array");
 	}
 	if ((long long)need > bytes) return c->fail(NBCO_ERR_ARG, "nbco_kd_copy: destination too small");

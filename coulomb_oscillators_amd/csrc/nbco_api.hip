@@ -147,6 +147,7 @@ int nbco_opts_default(nbco_opts *o)
 	o->list_grow = 1;
 	o->far_fp64 = 0;
 	o->p2p_mutual = 1;
+	o->track_order = 0;
 	o->stream = nullptr;
 	return NBCO_OK;
 }
@@ -193,7 +194,7 @@ int nbco_destroy(nbco_ctx *c)
 	                  &c->unsort, &c->unsort_alt, &c->sort_tmp, &c->treebuf, &c->frontier_a, &c->frontier_b, &c->p2p_list,
 	                  &c->m2l_list, &c->counters, &c->p2p_keys, &c->p2p_keys_alt, &c->m2l_keys, &c->m2l_keys_alt,
 	                  &c->p2p_start, &c->m2l_start, &c->p2p_chunk_off, &c->p2p_chunks, &c->sel_hist, &c->sel_nodes, &c->sel_ties, &c->list_cnt,
-	                  &c->dist_top, &c->dist_tree, &c->oct_tree, &c->oct_groups, &c->scan_tmp_aux, &c->p2p_desc, &c->trav_ctr, &c->prep_state, &c->p2p_sec, &c->p2p_react};
+	                  &c->dist_top, &c->dist_tree, &c->oct_tree, &c->oct_groups, &c->scan_tmp_aux, &c->p2p_desc, &c->trav_ctr, &c->prep_state, &c->p2p_sec, &c->p2p_react, &c->order, &c->order_alt};
 	if (c->aux && !c->aux_is_main) { hipStreamSynchronize(c->aux); hipStreamDestroy(c->aux); }
 	if (c->ev_fork) hipEventDestroy(c->ev_fork);
 	if (c->ev_join) hipEventDestroy(c->ev_join);
@@ -214,10 +215,11 @@ int nbco_set_opts(nbco_ctx *c, const nbco_opts *o)
 	if ((hipStream_t)o->stream != c->stream) NBCO_HIP(hipStreamSynchronize(c->stream));
 	if (o->list_factor != c->o.list_factor) c->list_growth = 1;
 	bool topo = o->fmm_order != c->o.fmm_order || o->dens_inhom != c->o.dens_inhom || o->tree_L != c->o.tree_L
-	            || o->unsort != c->o.unsort;
+	            || o->unsort != c->o.unsort || o->p2p_mutual != c->o.p2p_mutual || o->track_order != c->o.track_order;
 	c->o = *o;
 	c->stream = (hipStream_t)o->stream;
 	if (topo) { c->tree_valid = false; c->eval_counter = 0; }
+	if (!o->track_order) c->order_n = -1;
 	return NBCO_OK;
 }
 

@@ -164,6 +164,8 @@ struct nbco_ctx
 	DevBuf frontier_a, frontier_b, p2p_list, m2l_list, counters;
 	DevBuf p2p_keys, p2p_keys_alt, m2l_keys, m2l_keys_alt, p2p_start, m2l_start;
 	DevBuf p2p_chunk_off, p2p_chunks, p2p_desc;
+	DevBuf order, order_alt;     // opts.track_order: position in the state -> particle number of the state the tracking started from
+	long long order_n = -1;
 	DevBuf p2p_sec, p2p_react;   // mutual near field: per-target range of entries delivered by other waves, reaction records
 	const int *pc_mult = nullptr, *pc_total = nullptr;   // inputs of the on-demand directed pair count
 	int pc_shift = 0;

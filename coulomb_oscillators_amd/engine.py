@@ -20,7 +20,7 @@ INTEG_EULER, INTEG_PRE_EULER, INTEG_LEAPFROG, INTEG_FORESTRUTH, INTEG_PEFRL = 0,
 PHASES = ["build", "p2m_m2m", "traverse", "lists", "p2p", "m2l", "l2l", "l2p", "finish", "direct", "axpy"]
 
 KD_FIELDS = {"mult": 0, "index": 1, "splitdim": 2, "center": 3, "lbound": 4, "rbound": 5,
-             "mpole": 6, "local": 7, "p2p": 8, "m2l": 9, "unsort": 10}
+             "mpole": 6, "local": 7, "p2p": 8, "m2l": 9, "unsort": 10, "order": 11}
 
 
 class EngineError(RuntimeError):
@@ -31,7 +31,7 @@ class Opts(C.Structure):
     _fields_ = [("fmm_order", C.c_int), ("tree_radius", C.c_float), ("eps2", C.c_float), ("coll", C.c_int),
                 ("unsort", C.c_int), ("dens_inhom", C.c_float), ("tree_L", C.c_int), ("tree_steps", C.c_int),
                 ("m2l_first", C.c_int), ("sync", C.c_int), ("list_factor", C.c_int), ("list_grow", C.c_int), ("far_fp64", C.c_int),
-                ("p2p_mutual", C.c_int), ("stream", C.c_void_p)]
+                ("p2p_mutual", C.c_int), ("track_order", C.c_int), ("stream", C.c_void_p)]
 
 
 class KdInfo(C.Structure):
@@ -321,7 +321,7 @@ class Engine:
                   "center": ((info.ntot, 3), np.float32), "lbound": ((info.ntot, 3), np.float32),
                   "rbound": ((info.ntot, 3), np.float32), "mpole": ((info.ntot, offM), np.float32),
                   "local": ((info.ntot, offL), np.float32), "p2p": ((info.p2p_pairs, 2), np.int32),
-                  "m2l": ((info.m2l_pairs, 2), np.int32), "unsort": ((info.n,), np.int32)}
+                  "m2l": ((info.m2l_pairs, 2), np.int32), "unsort": ((info.n,), np.int32), "order": ((info.n,), np.int32)}
         shape, dt = shapes[name]
         out = np.empty(shape, dtype=dt)
         if out.size:

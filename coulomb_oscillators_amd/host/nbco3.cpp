@@ -55,6 +55,8 @@ const char *kHelp =
     "  -test             Print relative errors and the time of one evaluation.\n"
     "  -test2            Relative error while the tree is reused.\n"
     "  -xi <v>, -omega0 <wx> <wy>, -x <sx> <sy> <sz>, -u <ux> <uy> <uz>   physical parameters.\n"
+    "  -snapshot-order <tree|input>   order of the particles in the snapshots: tree (default, as the reference: the order the\n"
+    "                    last tree rebuild left them in) or input (every particle keeps the row it had in the initial state).\n"
     "  -cpu, -cpu-threads <n>, -cacheline <n>   not available: this build is GPU (MI355X) only.\n";
 
 // device allocation that frees itself
@@ -182,9 +184,11 @@ struct Session
 
 	// simulation: accelerations first, then nIters fused integrator steps; a snapshot [pos | vel] every nSteps iterations
 	// (main3.cu:832-874).  Evaluations are enqueued without a drain; the copy of a snapshot is what waits for the device.
-	int simulate(int scheme, SCAL dt, int nIters, int nSteps, const std::string &folder, std::vector<float> &host, size_t state_bytes)
+	int simulate(int scheme, SCAL dt, int nIters, int nSteps, const std::string &folder, std::vector<float> &host, size_t state_bytes, bool input_order)
 	{
-		change([](nbco_opts &c) { c.unsort = 0; c.sync = 0; });
+		change([&](nbco_opts &c) { c.unsort = 0; c.sync = 0; c.track_order = input_order ? 1 : 0; });
+		std::vector<int> order(input_order ? (size_t)n : 0);
+		std::vector<float> rows(input_order ? host.size() : 0);
 		check(nbco_force(ctx(), NBCO_EVAL_FMM_KDTREE, state.ptr, n, par.ptr, 1), "compute_force");
 		for (int iter = 0; iter < nIters; ++iter)
 		{
@@ -199,7 +203,19 @@ struct Session
 				std::cerr << "Error: cannot write on output location. Check that \"" << folder << "\" folder exists. Create it if not." << std::endl;
 				return -1;
 			}
-			fout.write(reinterpret_cast<const char *>(host.data()), (std::streamsize)state_bytes);
+			if (input_order)
+			{
+				// the engine composes the permutations of all tree rebuilds: row i of the state is particle order[i] of the initial state
+				check(nbco_kd_copy(ctx(), NBCO_KD_ORDER, order.data(), (long long)(order.size() * sizeof(int))), "kd_copy");
+				for (size_t i = 0; i < (size_t)n; ++i)
+					for (int k = 0; k < 3; ++k)
+					{
+						rows[3 * (size_t)order[i] + k] = host[3 * i + k];
+						rows[3 * ((size_t)n + order[i]) + k] = host[3 * ((size_t)n + i) + k];
+					}
+				fout.write(reinterpret_cast<const char *>(rows.data()), (std::streamsize)state_bytes);
+			}
+			else fout.write(reinterpret_cast<const char *>(host.data()), (std::streamsize)state_bytes);
 		}
 		check(nbco_sync(ctx()), "sync");
 		std::cout << std::endl;
@@ -218,7 +234,7 @@ int main(int argc, const char **argv)
 	SCAL dt = (SCAL)5.e-4;
 	int nIters = 30001, nSteps = 200;
 	std::string strout("out"), strin;
-	bool in = false, test = false, test2 = false, b_accuracy = false;
+	bool in = false, test = false, test2 = false, b_accuracy = false, input_order = false;
 	SCAL accuracy = (SCAL)0.001;
 	int scheme = NBCO_INTEG_LEAPFROG;   // main3.cu:238
 	SCAL xi = (SCAL)2.e-6;
@@ -331,6 +347,15 @@ int main(int argc, const char **argv)
 			std::cerr << "Error: '" << a << "' is not available: this build runs the force path on the GPU only\n";
 			return -1;
 		}
+		else if (a == "-snapshot-order")
+		{
+			if (!need(i, 1, "-snapshot-order")) return -1;
+			const std::string_view v(argv[i + 1]);
+			if (v == "input") input_order = true;
+			else if (v == "tree") input_order = false;
+			else { std::cerr << "Error: invalid argument to '-snapshot-order': " << argv[i + 1] << '\n'; return -1; }
+			++i;
+		}
 		else if (a == "-test") test = true;
 		else if (a == "-test2") test2 = true;
 		else if (a == "-xi")
@@ -404,7 +429,7 @@ int main(int argc, const char **argv)
 	{
 		if (test) s.print_error_table(host);
 		else if (test2) s.print_reuse_errors(dt);
-		else rc = s.simulate(scheme, dt, nIters, nSteps, strout, host, state_bytes);
+		else rc = s.simulate(scheme, dt, nIters, nSteps, strout, host, state_bytes, input_order);
 	}
 	return rc;
 }

@@ -91,6 +91,10 @@ typedef struct nbco_opts {
 	                       (fmm_cart3_kdtree.cuh:874-959) -- here without atomics: fixed-order sums, bit-reproducible.  Used when
 	                       the leaves hold 17..32 particles (orders 5 and 6 at the reference's leaf sizing); other sizes and
 	                       0 take the one-directional kernel, whose sharded results equal the single-GPU ones bit for bit. */
+	int   track_order;  /* != 0: with unsort = 0 the context composes the permutations of all rebuilds since tracking started, so that
+	                       NBCO_KD_ORDER maps a position of the (tree-ordered) state to the particle's number in the state the
+	                       first tracked evaluation received: snapshots can be written in input order (the
+	                       reference writes them in tree order, main3.cu:855-858) */
 	void *stream;       /* hipStream_t; NULL = the null stream */
 } nbco_opts;
 
@@ -164,7 +168,8 @@ enum {
 	NBCO_KD_MPOLE = 6,   /* float[ntot][offM], offM = p(p+1)(p+2)/6 */
 	NBCO_KD_LOCAL = 7,   /* float[ntot][offL], offL = (p+1)^2 */
 	NBCO_KD_P2P_LIST = 8, NBCO_KD_M2L_LIST = 9,                  /* int[pairs][2], unordered */
-	NBCO_KD_UNSORT = 10  /* int[n]: tree position -> caller's index */
+	NBCO_KD_UNSORT = 10, /* int[n]: tree position -> caller's index (of the last rebuild) */
+	NBCO_KD_ORDER = 11   /* int[n]: position in the state -> particle number since opts.track_order was set (cumulative) */
 };
 int nbco_kd_copy(nbco_ctx *c, int which, void *host_dst, long long host_bytes);
 

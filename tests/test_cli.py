@@ -119,3 +119,55 @@ def test_cli_accuracy_search_stays_inside_the_grid(nbco3, tmp_path):
     # an impossible bound fails the way the reference does
     r = run(nbco3, "-n", "4096", "-accuracy", "1e-12", "-o", str(out))
     assert r.returncode != 0 and "Optimization failed!" in r.stdout
+
+
+def test_snap2d_writes_the_viewer_format(nbco3, tmp_path):
+    """nbco_snap2d: fp32 [pos n x 3 | vel n x 3] -> doubles [pos n x 2 | vel n x 2] (Graphics/main.cpp:155,181-184), single files
+    and a renamed series out<steps k>_<dt>.bin -> out<20 k>_0.005000.bin"""
+    tool = os.path.join(HOST, "nbco_snap2d")
+    rng = np.random.default_rng(3)
+    n = 257
+    src, dst = tmp_path / "in", tmp_path / "view"
+    src.mkdir(); dst.mkdir()
+    states = [rng.standard_normal((2, n, 3)).astype(np.float32) for _ in range(3)]
+    for k, s in enumerate(states):
+        s.tofile(src / ("out%d_0.000500.bin" % (200 * k)))
+    r = run(tool, "-axes", "xz", str(src / "out0_0.000500.bin"), str(dst / "one.bin"))
+    assert r.returncode == 0, r.stderr
+    one = np.fromfile(dst / "one.bin", dtype=np.float64).reshape(2, n, 2)
+    np.testing.assert_array_equal(one, states[0][:, :, [0, 2]].astype(np.float64))
+    r = run(tool, "-series", str(src), "200", "5e-4", str(dst))
+    assert r.returncode == 0 and "3 frame(s) written" in r.stdout, r.stderr
+    for k, s in enumerate(states):
+        f = np.fromfile(dst / ("out%d_0.005000.bin" % (20 * k)), dtype=np.float64)
+        assert f.size == 4 * n                                             # the viewer reads nBodies = bytes / 4 / sizeof(double)
+        np.testing.assert_array_equal(f.reshape(2, n, 2), s[:, :, :2].astype(np.float64))
+    (src / "bad.bin").write_bytes(b"12345")
+    assert run(tool, str(src / "bad.bin"), str(dst / "x.bin")).returncode != 0
+    assert run(tool, "-axes", "xx", str(src / "out0_0.000500.bin"), str(dst / "x.bin")).returncode != 0
+    assert run(tool, str(src / "missing.bin"), str(dst / "x.bin")).returncode != 0
+
+
+@pytest.mark.gpu
+def test_snapshots_in_input_order(nbco3, oracle32, tmp_path):
+    """`-snapshot-order input`: every particle keeps its row through all tree rebuilds (the engine composes the permutations,
+    opts.track_order); the same run in tree order holds the same particles in another order"""
+    n, p, iters = 8192, 4, 24          # tree_steps = 8: the tree is rebuilt -- and the state permuted -- four times
+    a, b = tmp_path / "tree", tmp_path / "input"
+    a.mkdir(); b.mkdir()
+    common = ["-n", str(n), "-p", str(p), "-iters", str(iters), "-steps", str(iters)]
+    assert run(nbco3, *common, "-o", str(a)).returncode == 0
+    r = run(nbco3, *common, "-snapshot-order", "input", "-o", str(b))
+    assert r.returncode == 0, r.stderr
+    name = "out%d_0.000500.bin" % iters
+    st_tree = np.fromfile(a / name, dtype=np.float32).reshape(2, n, 3)
+    st_in = np.fromfile(b / name, dtype=np.float32).reshape(2, n, 3)
+    key = lambda x: np.lexsort((x[:, 2], x[:, 1], x[:, 0]))
+    np.testing.assert_array_equal(st_tree[0][key(st_tree[0])], st_in[0][key(st_in[0])])      # same particles ...
+    assert not np.array_equal(st_tree[0], st_in[0])                                          # ... other order
+    # identity: after 25 steps of dt = 5e-4 a particle has moved ~1 % of sigma from where the initial state put it
+    init = oracle32.init_reference(n)
+    sig = np.array([0.003, 0.001, 0.01], dtype=np.float32)
+    assert (np.abs(st_in[0] - init[0]) / sig).max() < 0.25
+    assert (np.abs(st_tree[0] - init[0]) / sig).max() > 1.0
+    assert run(nbco3, "-snapshot-order", "sideways").returncode != 0

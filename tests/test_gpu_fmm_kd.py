@@ -376,6 +376,7 @@ def test_mutual_near_field_tree_order_and_reuse(engine, oracle32):
     par = dev(oracle32.params(n))
     out = []
     for mutual in (0, 1):
+        # (switching the kernel drops the tree: a reused tree belongs to the state it was built on)
         engine.set(fmm_order=p, unsort=0, tree_steps=8, p2p_mutual=mutual)   # one build, seven evaluations on it: the particle order stays comparable
         d = dev(buf.copy())
         engine.compute_force(EVAL_FMM_KDTREE, d, n, par)
