@@ -7,12 +7,12 @@ PyTorch device pointers / streams through the C ABI.  There is no CPU fallback: 
 anywhere, but creating an :class:`Engine` without the built library or without a HIP device raises.
 """
 from .engine import (Engine, EngineError, lib_path, build_library, default_opts,
-                     EVAL_DIRECT, EVAL_DIRECT_KAHAN, EVAL_FMM_KDTREE, EVAL_FMM_TRACELESS,
+                     EVAL_DIRECT, EVAL_DIRECT_KAHAN, EVAL_FMM_KDTREE, EVAL_FMM_TRACELESS, EVAL_FMM_SYMMETRIC,
                      INTEG_EULER, INTEG_PRE_EULER, INTEG_LEAPFROG, INTEG_FORESTRUTH, INTEG_PEFRL,
                      PHASES)
 from .dist import DomainRun, TorchComm, SingleComm, LoopbackWorld
 
 __all__ = ["Engine", "EngineError", "lib_path", "build_library", "default_opts",
-           "EVAL_DIRECT", "EVAL_DIRECT_KAHAN", "EVAL_FMM_KDTREE", "EVAL_FMM_TRACELESS",
+           "EVAL_DIRECT", "EVAL_DIRECT_KAHAN", "EVAL_FMM_KDTREE", "EVAL_FMM_TRACELESS", "EVAL_FMM_SYMMETRIC",
            "INTEG_EULER", "INTEG_PRE_EULER", "INTEG_LEAPFROG", "INTEG_FORESTRUTH", "INTEG_PEFRL", "PHASES",
            "DomainRun", "TorchComm", "SingleComm", "LoopbackWorld"]

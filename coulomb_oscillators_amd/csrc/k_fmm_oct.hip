@@ -113,10 +113,12 @@ __global__ __launch_bounds__(kBlock) void oct_index_kernel(OctView<T> t, const u
 }
 
 // ---- leaves: multLeaves + centerLeaves + P2M, one wave per cell ------------------------------------------------
-template <int P, typename T>
+// SYM: symmetric multipoles of orders 0..P about the centroid (fmm_multipoleLeaves3, fmm_cart3_symmetric.cuh:71-99): the kd-tree
+// flavour's generated P2M of order P + 1, whose tuple holds orders 0..P
+template <int P, typename T, bool SYM>
 __global__ __launch_bounds__(kBlock) void oct_leaf_kernel(OctView<T> t, const float4 *__restrict__ pos)
 {
-	constexpr int offL = NBCO_OFFL(P);
+	constexpr int offL = SYM ? NBCO_OFFM(P + 1) : NBCO_OFFL(P);
 	const int m = oct_cnt(t.L), beg = oct_beg(t.L);
 	const int c = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
 	if (c >= m) return;
@@ -136,7 +138,8 @@ __global__ __launch_bounds__(kBlock) void oct_leaf_kernel(OctView<T> t, const fl
 	for (int j = lane; j < mlt; j += 64)
 	{
 		const float4 q = pos[i0 + j];
-		p2m_tl_accum<P>((T)q.x - (T)cx, (T)q.y - (T)cy, (T)q.z - (T)cz, A);
+		if constexpr (SYM) p2m_accum<P + 1>((T)q.x - (T)cx, (T)q.y - (T)cy, (T)q.z - (T)cz, A);
+		else p2m_tl_accum<P>((T)q.x - (T)cx, (T)q.y - (T)cy, (T)q.z - (T)cz, A);
 	}
 #pragma unroll
 	for (int q = 4; q < offL; ++q)
@@ -147,11 +150,15 @@ __global__ __launch_bounds__(kBlock) void oct_leaf_kernel(OctView<T> t, const fl
 		t.mult[node] = mlt;
 		t.csz[node] = make_float4(cx, cy, cz, 0.f);
 		M[0] = (T)mlt; M[1] = T(0); M[2] = T(0); M[3] = T(0);
+		if constexpr (SYM) p2m_store<P + 1>(A, M);   // normalised accumulators -> the reference's normalisation, orders 2..P
 	}
 	// lane q stores component q (every lane holds the full sums after the butterfly)
+	if constexpr (!SYM)
+	{
 #pragma unroll
-	for (int q = 4; q < offL; ++q)
-		if (lane == (q & 63)) M[q] = A[q];
+		for (int q = 4; q < offL; ++q)
+			if (lane == (q & 63)) M[q] = A[q];
+	}
 }
 
 // children of cell (i, j, k) of level l (fmm_cart3_traceless.cuh:128-139): level-major, row-major cells
@@ -165,10 +172,10 @@ __device__ inline void oct_children(int l, int c0, int inds[8])
 }
 
 // ---- M2M, one thread per parent (fmm_cart3_traceless.cuh:110-168) ------------------------------------------------
-template <int P, typename T>
+template <int P, typename T, bool SYM>
 __global__ __launch_bounds__(kBlock) void oct_m2m_kernel(OctView<T> t, int l)
 {
-	constexpr int offL = NBCO_OFFL(P);
+	constexpr int offL = SYM ? NBCO_OFFM(P + 1) : NBCO_OFFL(P);
 	const int c0 = blockIdx.x * kBlock + threadIdx.x;
 	if (c0 >= oct_cnt(l)) return;
 	const int node = oct_beg(l) + c0;
@@ -197,11 +204,20 @@ __global__ __launch_bounds__(kBlock) void oct_m2m_kernel(OctView<T> t, int l)
 		{
 			if (t.mult[inds[q]] == 0) continue;
 			const float4 cc = t.csz[inds[q]];
-			m2m_tl_accum<P>((const T *)(t.mpole + (size_t)inds[q] * offL), (T)cx - (T)cc.x, (T)cy - (T)cc.y, (T)cz - (T)cc.z, A);
+			if constexpr (SYM)
+			{
+				// fmm_buildTree3 (fmm_cart3_symmetric.cuh:121-179): m2m_acc3 over the children, orders 2..P
+				if (P + 1 >= 3) m2m_accum<P + 1>((const T *)(t.mpole + (size_t)inds[q] * offL), (T)cx - (T)cc.x, (T)cy - (T)cc.y, (T)cz - (T)cc.z, A);
+			}
+			else m2m_tl_accum<P>((const T *)(t.mpole + (size_t)inds[q] * offL), (T)cx - (T)cc.x, (T)cy - (T)cc.y, (T)cz - (T)cc.z, A);
 		}
 		M[0] = (T)mlt; M[1] = T(0); M[2] = T(0); M[3] = T(0);
+		if constexpr (SYM) m2m_store<P + 1>(A, M);
+		else
+		{
 #pragma unroll
-		for (int q = 4; q < offL; ++q) M[q] = A[q];
+			for (int q = 4; q < offL; ++q) M[q] = A[q];
+		}
 	}
 	else
 		for (int q = 0; q < offL; ++q) M[q] = T(0);
@@ -426,19 +442,23 @@ static int scan_ints(nbco_ctx *c, int *in, int *out, size_t count)
 	return NBCO_OK;
 }
 
-static int m2l_lanes(nbco_ctx *c, int P, const float4 *csz, const float *mpole, float *local, const uint64_t *keys, const int *start, int shift, int ntot)
+static int m2l_lanes(nbco_ctx *c, int P, const float4 *csz, const float *mpole, float *local, const uint64_t *keys, const int *start, int shift, int ntot, int mstride)
 {
-	return launch_m2l_lanes(c, P, csz, mpole, local, keys, start, shift, ntot);
+	return launch_m2l_lanes(c, P, csz, mpole, local, keys, start, shift, ntot, mstride);
 }
-static int m2l_lanes(nbco_ctx *c, int P, const float4 *csz, const double *mpole, double *local, const uint64_t *keys, const int *start, int shift, int ntot)
+static int m2l_lanes(nbco_ctx *c, int P, const float4 *csz, const double *mpole, double *local, const uint64_t *keys, const int *start, int shift, int ntot, int mstride)
 {
-	return launch_m2l_lanes_f64(c, P, csz, mpole, local, keys, start, shift, ntot);
+	return launch_m2l_lanes_f64(c, P, csz, mpole, local, keys, start, shift, ntot, mstride);
 }
 
-template <int P, typename T>
+template <int P, typename T, bool SYM>
 static int oct_eval(nbco_ctx *c, float *p, float *a, long long n, const float *param)
 {
+	// SYM: fmm_cart3 (fmm_cart3_symmetric.cuh:413-580) -- multipole tuples in the symmetric layout, orders 0..P (offMP reals);
+	// the M2L kernel reads their first offM reals (orders 0..P-1: an order-P multipole only meets the order-0 local, which is not
+	// formed, m2l_acc3 with minm = 1), everything from the M2L list on is shared with the traceless evaluator
 	constexpr int offL = NBCO_OFFL(P), offM = P * (P + 1) * (P + 2) / 6;
+	constexpr int offMP = SYM ? NBCO_OFFM(P + 1) : offL;   // reals per stored multipole tuple
 	hipStream_t st = c->stream;
 	const int radius = (int)c->o.tree_radius;   // fmm_cart3_traceless.cuh:439
 	if (radius < 1) return c->fail(NBCO_ERR_ARG, "nbco_fmm_traceless: tree_radius must be >= 1");
@@ -449,14 +469,14 @@ static int oct_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 
 	// ---- storage -----------------------------------------------------------------------------------------
 	{
-		size_t bytes = (size_t)ntot * (sizeof(float4) + sizeof(T) * (2 * (size_t)offL + offM) + 2 * sizeof(int)) + 256;
+		size_t bytes = (size_t)ntot * (sizeof(float4) + sizeof(T) * ((size_t)offL + offMP + offM) + 2 * sizeof(int)) + 256;
 		NBCO_TRY(c->reserve(c->oct_tree, bytes));
 	}
 	OctView<T> t;
 	{
 		char *q = (char *)c->oct_tree.ptr;
 		t.csz = (float4 *)q; q += sizeof(float4) * (size_t)ntot;
-		t.mpole = (T *)q; q += sizeof(T) * (size_t)ntot * offL;
+		t.mpole = (T *)q; q += sizeof(T) * (size_t)ntot * offMP;
 		t.local = (T *)q; q += sizeof(T) * (size_t)ntot * offL;
 		t.msym = (T *)q; q += sizeof(T) * (size_t)ntot * offM;
 		t.mult = (int *)q; q += sizeof(int) * (size_t)ntot;
@@ -499,9 +519,9 @@ static int oct_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 	// ---- P2M, M2M ----------------------------------------------------------------------------------------
 	{
 		PhaseScope ph(c, NBCO_PH_P2M_M2M);
-		hipLaunchKernelGGL((oct_leaf_kernel<P, T>), dim3((m + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, t, (const float4 *)pos);
-		for (int l = L - 1; l >= 2; --l) hipLaunchKernelGGL((oct_m2m_kernel<P, T>), dim3((oct_cnt(l) + kBlock - 1) / kBlock), dim3(kBlock), 0, st, t, l);
-		hipLaunchKernelGGL(oct_expand_kernel<T>, dim3(grid1d(ntot - first)), dim3(kBlock), 0, st, t, P, first);
+		hipLaunchKernelGGL((oct_leaf_kernel<P, T, SYM>), dim3((m + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, t, (const float4 *)pos);
+		for (int l = L - 1; l >= 2; --l) hipLaunchKernelGGL((oct_m2m_kernel<P, T, SYM>), dim3((oct_cnt(l) + kBlock - 1) / kBlock), dim3(kBlock), 0, st, t, l);
+		if (!SYM) hipLaunchKernelGGL(oct_expand_kernel<T>, dim3(grid1d(ntot - first)), dim3(kBlock), 0, st, t, P, first);
 		NBCO_HIP(hipGetLastError());
 	}
 	// ---- work lists: M2L stencil entries, P2P groups / descriptors / chunks -----------------------------------------
@@ -575,7 +595,7 @@ static int oct_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 	{
 		PhaseScope ph(c, NBCO_PH_M2L);
 		NBCO_HIP(hipMemsetAsync(t.local, 0, sizeof(T) * (size_t)ntot * offL, st));
-		if (nm2l > 0) NBCO_TRY(m2l_lanes(c, P, t.csz, t.msym, t.local, c->m2l_keys_alt.as<uint64_t>(), m2l_start, shift, ntot));
+		if (nm2l > 0) NBCO_TRY(m2l_lanes(c, P, t.csz, SYM ? t.mpole : t.msym, t.local, c->m2l_keys_alt.as<uint64_t>(), m2l_start, shift, ntot, SYM ? offMP : 0));
 	}
 	{
 		PhaseScope ph(c, NBCO_PH_L2L);
@@ -602,18 +622,31 @@ static int oct_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 	o.L = L; o.ntot = ntot; o.order = P; o.n = n; o.csz = t.csz; o.mpole = t.mpole; o.local = t.local; o.mult = t.mult; o.index = t.index;
 	o.keys = keys; o.perm = idx; o.m2l_entries = nm2l; o.p2p_groups = ngr; o.p2p_desc = h_tot[2]; o.p2p_chunks = nck; o.tpl = tpl;
 	o.real_bytes = (int)sizeof(T);
+	o.mpole_reals = offMP;
 	o.valid = true;
 	return NBCO_OK;
 }
 
 } // namespace
 
-int fmm_oct_traceless_eval(nbco_ctx *c, float *p, float *a, long long n, const float *param)
+int fmm_oct_traceless_eval(nbco_ctx *c, float *p, float *a, long long n, const float *param, bool symmetric)
 {
 	if (n <= 0) return c->fail(NBCO_ERR_ARG, "nbco_fmm_traceless: n must be positive");
 	if (n > 0x7fffffffLL / 4) return c->fail(NBCO_ERR_UNSUPPORTED, "nbco_fmm_traceless: n too large for 32-bit indices");
 	const bool f64 = c->o.far_fp64 != 0;
-#define NBCO_OCT_CASE(PP) case PP: return f64 ? oct_eval<PP, double>(c, p, a, n, param) : oct_eval<PP, float>(c, p, a, n, param);
+	if (symmetric)
+	{
+		// symmetric multipoles of orders 0..p come from the generated operators of order p + 1: p <= 9
+#define NBCO_OCT_CASE(PP) case PP: return f64 ? oct_eval<PP, double, true>(c, p, a, n, param) : oct_eval<PP, float, true>(c, p, a, n, param);
+		switch (c->o.fmm_order)
+		{
+		NBCO_OCT_CASE(1) NBCO_OCT_CASE(2) NBCO_OCT_CASE(3) NBCO_OCT_CASE(4) NBCO_OCT_CASE(5)
+		NBCO_OCT_CASE(6) NBCO_OCT_CASE(7) NBCO_OCT_CASE(8) NBCO_OCT_CASE(9)
+		default: return c->fail(NBCO_ERR_UNSUPPORTED, "nbco_fmm_symmetric: orders 1..9");
+		}
+#undef NBCO_OCT_CASE
+	}
+#define NBCO_OCT_CASE(PP) case PP: return f64 ? oct_eval<PP, double, false>(c, p, a, n, param) : oct_eval<PP, float, false>(c, p, a, n, param);
 	switch (c->o.fmm_order)
 	{
 	NBCO_OCT_CASE(1) NBCO_OCT_CASE(2) NBCO_OCT_CASE(3) NBCO_OCT_CASE(4) NBCO_OCT_CASE(5)
@@ -635,7 +668,7 @@ int oct_copy_out(nbco_ctx *c, int which, void *dst, long long bytes)
 	case NBCO_OCT_MULT: src = o.mult; need = 4 * (size_t)o.ntot; break;
 	case NBCO_OCT_INDEX: src = o.index; need = 4 * (size_t)o.ntot; break;
 	case NBCO_OCT_CENTER4: src = o.csz; need = 16 * (size_t)o.ntot; break;
-	case NBCO_OCT_MPOLE: src = o.mpole; need = (size_t)o.real_bytes * (size_t)o.ntot * offL; break;
+	case NBCO_OCT_MPOLE: src = o.mpole; need = (size_t)o.real_bytes * (size_t)o.ntot * (size_t)o.mpole_reals; break;
 	case NBCO_OCT_LOCAL: src = o.local; need = (size_t)o.real_bytes * (size_t)o.ntot * offL; break;
 	case NBCO_OCT_KEYS: src = o.keys; need = 4 * (size_t)o.n; break;
 	case NBCO_OCT_PERM: src = o.perm; need = 4 * (size_t)o.n; break;

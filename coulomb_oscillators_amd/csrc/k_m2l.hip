@@ -27,7 +27,7 @@ constexpr int kTargets = 6;
 template <int P, typename T>
 __global__ __launch_bounds__(64) void m2l_lane_kernel(const float4 *__restrict__ csz, const T *__restrict__ mpole,
                                                       T *__restrict__ local, const uint64_t *__restrict__ keys,
-                                                      const int *__restrict__ start, int shift, int ntot, float eps2)
+                                                      const int *__restrict__ start, int shift, int ntot, float eps2, int mstride)
 {
 	constexpr int offM = P * (P + 1) * (P + 2) / 6, offL = (P + 1) * (P + 1), NOUT = offL - 1;
 	constexpr int CPL = (NOUT + 63) / 64;   // components per lane in the reduction walk
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(64) void m2l_lane_kernel(const float4 *__restrict__
 			const T dx = (T)ct.x - (T)cs.x, dy = (T)ct.y - (T)cs.y, dz = (T)ct.z - (T)cs.z;
 			const T r = nb_sqrt(dx * dx + dy * dy + dz * dz + (T)eps2);
 			const T rinv = T(1) / r;
-			M2LBody<P, T>::run(mpole + (size_t)src * offM, dx * rinv, dy * rinv, dz * rinv, rinv, L);
+			M2LBody<P, T>::run(mpole + (size_t)src * mstride, dx * rinv, dy * rinv, dz * rinv, rinv, L);
 		}
 		else
 		{
@@ -106,27 +106,28 @@ __global__ __launch_bounds__(64) void m2l_lane_kernel(const float4 *__restrict__
 }
 
 template <int P, typename T>
-static void launch(nbco_ctx *c, const float4 *csz, const T *mpole, T *local, const uint64_t *keys, const int *start, int shift, int ntot)
+static void launch(nbco_ctx *c, const float4 *csz, const T *mpole, T *local, const uint64_t *keys, const int *start, int shift, int ntot, int mstride)
 {
 	const int grid = (ntot + kTargets - 1) / kTargets;
-	hipLaunchKernelGGL((m2l_lane_kernel<P, T>), dim3(grid), dim3(64), 0, c->stream, csz, mpole, local, keys, start, shift, ntot, c->o.eps2);
+	hipLaunchKernelGGL((m2l_lane_kernel<P, T>), dim3(grid), dim3(64), 0, c->stream, csz, mpole, local, keys, start, shift, ntot, c->o.eps2,
+	                   mstride > 0 ? mstride : P * (P + 1) * (P + 2) / 6);
 }
 
 template <typename T>
-static int dispatch(nbco_ctx *c, int P, const float4 *csz, const T *mpole, T *local, const uint64_t *keys, const int *start, int shift, int ntot)
+static int dispatch(nbco_ctx *c, int P, const float4 *csz, const T *mpole, T *local, const uint64_t *keys, const int *start, int shift, int ntot, int mstride)
 {
 	switch (P)
 	{
-	case 1: launch<1, T>(c, csz, mpole, local, keys, start, shift, ntot); break;
-	case 2: launch<2, T>(c, csz, mpole, local, keys, start, shift, ntot); break;
-	case 3: launch<3, T>(c, csz, mpole, local, keys, start, shift, ntot); break;
-	case 4: launch<4, T>(c, csz, mpole, local, keys, start, shift, ntot); break;
-	case 5: launch<5, T>(c, csz, mpole, local, keys, start, shift, ntot); break;
-	case 6: launch<6, T>(c, csz, mpole, local, keys, start, shift, ntot); break;
-	case 7: launch<7, T>(c, csz, mpole, local, keys, start, shift, ntot); break;
-	case 8: launch<8, T>(c, csz, mpole, local, keys, start, shift, ntot); break;
-	case 9: launch<9, T>(c, csz, mpole, local, keys, start, shift, ntot); break;
-	case 10: launch<10, T>(c, csz, mpole, local, keys, start, shift, ntot); break;
+	case 1: launch<1, T>(c, csz, mpole, local, keys, start, shift, ntot, mstride); break;
+	case 2: launch<2, T>(c, csz, mpole, local, keys, start, shift, ntot, mstride); break;
+	case 3: launch<3, T>(c, csz, mpole, local, keys, start, shift, ntot, mstride); break;
+	case 4: launch<4, T>(c, csz, mpole, local, keys, start, shift, ntot, mstride); break;
+	case 5: launch<5, T>(c, csz, mpole, local, keys, start, shift, ntot, mstride); break;
+	case 6: launch<6, T>(c, csz, mpole, local, keys, start, shift, ntot, mstride); break;
+	case 7: launch<7, T>(c, csz, mpole, local, keys, start, shift, ntot, mstride); break;
+	case 8: launch<8, T>(c, csz, mpole, local, keys, start, shift, ntot, mstride); break;
+	case 9: launch<9, T>(c, csz, mpole, local, keys, start, shift, ntot, mstride); break;
+	case 10: launch<10, T>(c, csz, mpole, local, keys, start, shift, ntot, mstride); break;
 	default: return c->fail(NBCO_ERR_UNSUPPORTED, "launch_m2l_lanes: order not generated");
 	}
 	NBCO_HIP(hipGetLastError());
@@ -137,13 +138,13 @@ static int dispatch(nbco_ctx *c, int P, const float4 *csz, const T *mpole, T *lo
 
 // targets without sources are never visited: `local` must be zero-filled by the caller.
 int launch_m2l_lanes(nbco_ctx *c, int P, const float4 *csz, const float *mpole, float *local, const uint64_t *keys, const int *start,
-                     int shift, int ntot)
+                     int shift, int ntot, int mstride)
 {
-	return dispatch<float>(c, P, csz, mpole, local, keys, start, shift, ntot);
+	return dispatch<float>(c, P, csz, mpole, local, keys, start, shift, ntot, mstride);
 }
 // fp64 far field (octree evaluator with opts.far_fp64): centres stay fp32, everything else is double
 int launch_m2l_lanes_f64(nbco_ctx *c, int P, const float4 *csz, const double *mpole, double *local, const uint64_t *keys, const int *start,
-                         int shift, int ntot)
+                         int shift, int ntot, int mstride)
 {
-	return dispatch<double>(c, P, csz, mpole, local, keys, start, shift, ntot);
+	return dispatch<double>(c, P, csz, mpole, local, keys, start, shift, ntot, mstride);
 }

@@ -311,6 +311,12 @@ int nbco_fmm_traceless(nbco_ctx *c, float *p, float *a, long long n, const float
 	NBCO_TRY(fmm_oct_traceless_eval(c, p, a, n, param));
 	return maybe_sync(c);
 }
+int nbco_fmm_symmetric(nbco_ctx *c, float *p, float *a, long long n, const float *param)
+{
+	if (!c || !p || !a) return c ? c->fail(NBCO_ERR_ARG, "nbco_fmm_symmetric: null pointer") : NBCO_ERR_ARG;
+	NBCO_TRY(fmm_oct_traceless_eval(c, p, a, n, param, true));
+	return maybe_sync(c);
+}
 int nbco_oct_get_info(nbco_ctx *c, nbco_oct_info *out)
 {
 	if (!c || !out) return c ? c->fail(NBCO_ERR_ARG, "nbco_oct_get_info: null pointer") : NBCO_ERR_ARG;
@@ -319,6 +325,7 @@ int nbco_oct_get_info(nbco_ctx *c, nbco_oct_info *out)
 	out->L = o.L; out->ntot = o.ntot; out->order = o.order; out->tpl = o.tpl; out->n = o.n;
 	out->m2l_entries = o.m2l_entries; out->p2p_groups = o.p2p_groups; out->p2p_desc = o.p2p_desc; out->p2p_chunks = o.p2p_chunks;
 	out->real_bytes = o.real_bytes;
+	out->mpole_reals = o.mpole_reals;
 	return NBCO_OK;
 }
 int nbco_oct_copy(nbco_ctx *c, int which, void *host_dst, long long host_bytes)
@@ -400,7 +407,8 @@ static int eval_kind(nbco_ctx *c, int kind, float *p, float *a, long long n, con
 	case NBCO_EVAL_DIRECT: return launch_direct(c, p, a, n, param, false);
 	case NBCO_EVAL_DIRECT_KAHAN: return launch_direct(c, p, a, n, param, true);
 	case NBCO_EVAL_FMM_KDTREE: return fmm_kdtree_eval(c, p, a, n, param);
-	case NBCO_EVAL_FMM_TRACELESS: return nbco_fmm_traceless(c, p, a, n, param);
+	case NBCO_EVAL_FMM_TRACELESS: return fmm_oct_traceless_eval(c, p, a, n, param, false);
+	case NBCO_EVAL_FMM_SYMMETRIC: return fmm_oct_traceless_eval(c, p, a, n, param, true);
 	default: return c->fail(NBCO_ERR_ARG, "unknown evaluator kind");
 	}
 }

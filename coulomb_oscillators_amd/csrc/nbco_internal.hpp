@@ -100,6 +100,7 @@ struct OctTreeDev
 	float4 *csz = nullptr;
 	void *mpole = nullptr, *local = nullptr;   // float or double (real_bytes)
 	int real_bytes = 4;
+	int mpole_reals = 0;   // reals per multipole tuple: (p+1)^2 traceless, (p+1)(p+2)(p+3)/6 symmetric
 	int *mult = nullptr, *index = nullptr;
 	uint32_t *keys = nullptr, *perm = nullptr;
 };
@@ -271,7 +272,7 @@ int kd_count_pairs(nbco_ctx *c, long long *out);
 int kd_energy_fmm(nbco_ctx *c, long long n_own, double *half_phi_sum);
 int launch_energy_kin_ela(nbco_ctx *c, const float *buf, long long n, const float *param, double *out2_host);
 // k_fmm_oct.hip
-int fmm_oct_traceless_eval(nbco_ctx *c, float *p, float *a, long long n, const float *param);
+int fmm_oct_traceless_eval(nbco_ctx *c, float *p, float *a, long long n, const float *param, bool symmetric = false);
 int oct_copy_out(nbco_ctx *c, int which, void *host_dst, long long host_bytes);
 // multi-GPU kd-domain sharding (k_fmm_kd.hip)
 int kd_dist_layout(nbco_ctx *c, long long n_global, int world, int rank, nbco_dist_layout *out);
@@ -296,7 +297,8 @@ int launch_l2p_gen(nbco_ctx *c, int P, const float4 *pos, const float *center, c
                    long long own0, long long own_n, const int2 *sec_range = nullptr, const int4 *desc4 = nullptr, const float4 *react = nullptr,
                    long long react_cap = 0, int react_stride = 32);
 // k_m2l.hip
+// mstride: reals per multipole tuple in `mpole` (0 = the offM(P) of the kd-tree layout; the symmetric octree evaluator keeps orders 0..P)
 int launch_m2l_lanes(nbco_ctx *c, int P, const float4 *csz, const float *mpole, float *local, const uint64_t *keys, const int *start,
-                     int shift, int ntot);
+                     int shift, int ntot, int mstride = 0);
 int launch_m2l_lanes_f64(nbco_ctx *c, int P, const float4 *csz, const double *mpole, double *local, const uint64_t *keys, const int *start,
-                         int shift, int ntot);
+                         int shift, int ntot, int mstride = 0);

@@ -15,7 +15,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.environ.get("NBCO_LIB") or os.path.join(_HERE, "libnbco_hip.so")   # NBCO_LIB: A/B builds of the same ABI (diagnostics)
 
-EVAL_DIRECT, EVAL_DIRECT_KAHAN, EVAL_FMM_KDTREE, EVAL_FMM_TRACELESS = 0, 1, 2, 3
+EVAL_DIRECT, EVAL_DIRECT_KAHAN, EVAL_FMM_KDTREE, EVAL_FMM_TRACELESS, EVAL_FMM_SYMMETRIC = 0, 1, 2, 3, 4
 INTEG_EULER, INTEG_PRE_EULER, INTEG_LEAPFROG, INTEG_FORESTRUTH, INTEG_PEFRL = 0, 1, 2, 3, 4
 PHASES = ["build", "p2m_m2m", "traverse", "lists", "p2p", "m2l", "l2l", "l2p", "finish", "direct", "axpy"]
 
@@ -43,7 +43,7 @@ class KdInfo(C.Structure):
 class OctInfo(C.Structure):
     _fields_ = [("L", C.c_int), ("ntot", C.c_int), ("order", C.c_int), ("tpl", C.c_int), ("n", C.c_longlong),
                 ("m2l_entries", C.c_longlong), ("p2p_groups", C.c_longlong), ("p2p_desc", C.c_longlong),
-                ("p2p_chunks", C.c_longlong), ("real_bytes", C.c_int)]
+                ("p2p_chunks", C.c_longlong), ("real_bytes", C.c_int), ("mpole_reals", C.c_int)]
 
 
 OCT_FIELDS = {"mult": 0, "index": 1, "center4": 2, "mpole": 3, "local": 4, "keys": 5, "perm": 6}
@@ -100,6 +100,7 @@ def _load():
         "nbco_direct3": [P, P, P, LL, P],
         "nbco_fmm_kdtree": [P, P, P, LL, P],
         "nbco_fmm_traceless": [P, P, P, LL, P],
+        "nbco_fmm_symmetric": [P, P, P, LL, P],
         "nbco_force": [P, I, P, LL, P, I],
         "nbco_integrate": [P, I, I, P, LL, P, D, D, I],
         "nbco_minmax": [P, P, LL, P],
@@ -233,6 +234,10 @@ class Engine:
     def fmm_cart3_traceless(self, p, a, n, param=None):
         self._chk(self.lib.nbco_fmm_traceless(self.ctx, _ptr(p), _ptr(a), n, _ptr(param)))
 
+    def fmm_cart3(self, p, a, n, param=None):
+        """the uniform-octree evaluator with symmetric multipoles (fmm_cart3_symmetric.cuh:413)"""
+        self._chk(self.lib.nbco_fmm_symmetric(self.ctx, _ptr(p), _ptr(a), n, _ptr(param)))
+
     def compute_force(self, kind, buf, n, param, elastic=True):
         self._chk(self.lib.nbco_force(self.ctx, kind, _ptr(buf), n, _ptr(param), int(elastic)))
 
@@ -340,7 +345,7 @@ class Engine:
         off = (info.order + 1) ** 2
         real = np.float64 if info.real_bytes == 8 else np.float32
         shapes = {"mult": ((info.ntot,), np.int32), "index": ((info.ntot,), np.int32), "center4": ((info.ntot, 4), np.float32),
-                  "mpole": ((info.ntot, off), real), "local": ((info.ntot, off), real),
+                  "mpole": ((info.ntot, info.mpole_reals), real), "local": ((info.ntot, off), real),
                   "keys": ((info.n,), np.uint32), "perm": ((info.n,), np.uint32)}
         shape, dt = shapes[name]
         out = np.empty(shape, dtype=dt)

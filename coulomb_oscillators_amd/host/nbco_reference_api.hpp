@@ -42,6 +42,7 @@ inline void direct(VEC *p, VEC *a, int n, const SCAL *param) { check(nbco_direct
 inline void direct3(VEC *p, VEC *a, int n, const SCAL *param) { check(nbco_direct3(ctx(), &p->x, &a->x, n, param), "direct3"); }
 inline void fmm_cart3_kdtree(VEC *p, VEC *a, int n, const SCAL *param) { check(nbco_fmm_kdtree(ctx(), &p->x, &a->x, n, param), "fmm_cart3_kdtree"); }
 inline void fmm_cart3_traceless(VEC *p, VEC *a, int n, const SCAL *param) { check(nbco_fmm_traceless(ctx(), &p->x, &a->x, n, param), "fmm_cart3_traceless"); }   // fmm_cart3_traceless.cuh:282
+inline void fmm_cart3(VEC *p, VEC *a, int n, const SCAL *param) { check(nbco_fmm_symmetric(ctx(), &p->x, &a->x, n, param), "fmm_cart3"); }   // fmm_cart3_symmetric.cuh:413
 // basic kernels
 inline void step(VEC *b, const VEC *a, SCAL ds, int n) { check(nbco_step(ctx(), &b->x, &a->x, ds, n), "step"); }
 inline void add_elastic(VEC *p, VEC *a, int n, const SCAL *param) { check(nbco_add_elastic(ctx(), &p->x, &a->x, n, param), "add_elastic"); }

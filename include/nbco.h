@@ -41,7 +41,8 @@ enum {
 	NBCO_EVAL_DIRECT = 0,         /* direct.cuh:104 `direct` / :171 `direct2` (LDS-tiled all pairs) */
 	NBCO_EVAL_DIRECT_KAHAN = 1,   /* direct.cuh:233 `direct3` (compensated accumulation) */
 	NBCO_EVAL_FMM_KDTREE = 2,     /* fmm_cart3_kdtree.cuh:1478 `fmm_cart3_kdtree` */
-	NBCO_EVAL_FMM_TRACELESS = 3   /* fmm_cart3_traceless.cuh:282 `fmm_cart3_traceless` */
+	NBCO_EVAL_FMM_TRACELESS = 3,  /* fmm_cart3_traceless.cuh:282 `fmm_cart3_traceless` */
+	NBCO_EVAL_FMM_SYMMETRIC = 4   /* fmm_cart3_symmetric.cuh:413 `fmm_cart3` (uniform octree, symmetric multipoles) */
 };
 
 /* integrators of integrator.cuh:32-167 */
@@ -123,6 +124,7 @@ int nbco_direct(nbco_ctx *c, const float *p, float *a, long long n, const float 
 int nbco_direct3(nbco_ctx *c, const float *p, float *a, long long n, const float *param);  /* direct.cuh:233 */
 int nbco_fmm_kdtree(nbco_ctx *c, float *p, float *a, long long n, const float *param);     /* fmm_cart3_kdtree.cuh:1478 */
 int nbco_fmm_traceless(nbco_ctx *c, float *p, float *a, long long n, const float *param);  /* fmm_cart3_traceless.cuh:282 */
+int nbco_fmm_symmetric(nbco_ctx *c, float *p, float *a, long long n, const float *param);  /* fmm_cart3_symmetric.cuh:413 `fmm_cart3`, orders 1..9 */
 
 /* evaluator `kind` on buf = [pos|vel|acc], followed by add_elastic(param+3) when elastic != 0:
  * compute_force (integrator.cuh:22) over the coulombOscillator* wrappers of main3.cu:47-69 */
@@ -184,6 +186,8 @@ typedef struct nbco_oct_info {
 	long long m2l_entries;  /* directed (target, source) stencil entries with a non-empty source */
 	long long p2p_groups, p2p_desc, p2p_chunks;
 	int real_bytes;         /* 4 or 8: element size of NBCO_OCT_MPOLE / NBCO_OCT_LOCAL */
+	int mpole_reals;        /* reals per tuple of NBCO_OCT_MPOLE: (order + 1)^2 after nbco_fmm_traceless (traceless, orders 0..order),
+	                           (order + 1)(order + 2)(order + 3) / 6 after nbco_fmm_symmetric (symmetric layout, orders 0..order) */
 } nbco_oct_info;
 int nbco_oct_get_info(nbco_ctx *c, nbco_oct_info *out);
 enum {

@@ -319,14 +319,15 @@ static void m2m_traceless_acc(real* Mout, real* temp, const real* Mtuple, int n,
 // traceless=false, b_atomic, no_dipole=true> (fmm_cart_base3.cuh:1309-1346): for N<=5 the unrolled
 // path rescales per m with r^(m+1) (:1283-1296), for N>=6 the loop path rescales once with
 // r^(N+1)/N! (:1181-1208).  temp: (N+1)(N+2)/2 reals.
+// loop_form: always the loop path's single rescaling (the symmetric octree evaluator calls m2l_acc3 directly, :1181-1208).
 static void m2l_sym_acc(real* Ltuple, real* temp, const real* Mtuple, int N, vec3 d, real r,
-                        bool no_dipole, bool atomic)
+                        bool no_dipole, bool atomic, bool loop_form = false)
 {
 	const int minm = 1, maxm = N, maxn = N;
 	real scal_loop = binarypow(r, maxm + 1) * T.inv_fact[maxm];
 	for (int m = minm; m <= maxm; ++m)
 	{
-		real scal = (N <= 5) ? binarypow(r, m + 1) : scal_loop;
+		real scal = (N <= 5 && !loop_form) ? binarypow(r, m + 1) : scal_loop;
 		gradient(temp, m, d, r, scal);
 		traceless_refine(temp, m);
 		for (int n = std::max(minm, m - N); n <= std::min(maxn, m); ++n)
@@ -786,6 +787,7 @@ static int fmm_kd(vec3* p, vec3* a, int n, const real* param, const Opts& o)
 struct OctTree
 {
 	int L = 0, ntot = 0, p = 0, n = 0;
+	bool symmetric = false;   // multipole tuples in the symmetric layout, orders 0..p (fmm_cart3) instead of traceless (fmm_cart3_traceless)
 	std::vector<vec3> center;
 	std::vector<real> mpole, local;
 	std::vector<int> mult, index, keys, perm;
@@ -801,7 +803,11 @@ static int oct_levels(int n, int p, real dens_inhom) // fmm_cart3_traceless.cuh:
 	return std::max(L, 2);
 }
 
-static int fmm_oct_traceless(vec3* p, vec3* a, int n, const real* param, const Opts& o)
+// Both octree evaluators share everything but the multipole algebra: `symmetric` = false is fmm_cart3_traceless_cpu
+// (fmm_cart3_traceless.cuh:437-571), true is fmm_cart3_cpu (fmm_cart3_symmetric.cuh:582-716): symmetric multipoles of orders
+// 0..P about the cell centres (p2m_acc3 / m2m_acc3, :71-99, :121-179) and the loop form of the symmetric -> traceless M2L with
+// all orders m = 1..P and no dipole skip (m2l_acc3(..., nM = P, nL = P, minm = 1, maxm = P), :207-265).
+static int fmm_oct(vec3* p, vec3* a, int n, const real* param, const Opts& o, bool symmetric)
 {
 	OctTree& t = g_oct;
 	const int P = o.p, T_ = std::max(1, o.threads);
@@ -810,9 +816,10 @@ static int fmm_oct_traceless(vec3* p, vec3* a, int n, const real* param, const O
 	const int L = oct_levels(n, P, o.dens_inhom);
 	if (L > 9) return -2;
 	const int side = 1 << L, ntot = ((1 << (3 * (L + 1))) - 1) / 7, off = tl_off(P + 1);
-	t.L = L; t.ntot = ntot; t.p = P; t.n = n;
+	const int offM = symmetric ? sym_off(P + 1) : off;   // reals per multipole tuple
+	t.L = L; t.ntot = ntot; t.p = P; t.n = n; t.symmetric = symmetric;
 	t.center.assign(ntot, vec3{0, 0, 0});
-	t.mpole.assign((size_t)ntot * off, 0);
+	t.mpole.assign((size_t)ntot * offM, 0);
 	t.local.assign((size_t)ntot * off, 0);
 	t.mult.assign(ntot, 0);
 	t.index.assign(ntot, 0);
@@ -875,13 +882,14 @@ static int fmm_oct_traceless(vec3* p, vec3* a, int n, const real* param, const O
 	parallel_ranges(m, T_, [&](long long ib, long long ie, int) {
 		for (long long i = beg + ib; i < beg + ie; ++i)
 		{
-			real* M = t.mpole.data() + (size_t)off * i;
+			real* M = t.mpole.data() + (size_t)offM * i;
 			const vec3* pi = p + t.index[i];
 			M[0] = (real)t.mult[i];
 			if (P >= 2)
 				for (int j = 0; j < t.mult[i]; ++j)
 				{
 					vec3 d = pi[j] - t.center[i];
+					if (symmetric) { for (int q = 2; q <= P; ++q) p2m_acc(M + sym_off(q), q, d); continue; }
 					real r = std::sqrt(dot(d, d));
 					if (r != 0) d = d / r;
 					for (int q = 2; q <= P; ++q) p2m_traceless_acc(M + tl_off(q), q, d, r);
@@ -910,14 +918,15 @@ static int fmm_oct_traceless(vec3* p, vec3* a, int n, const real* param, const O
 				{
 					for (int q = 0; q < 8; ++q) c = c + (real)t.mult[inds[q]] * t.center[inds[q]];
 					c = c / (real)mlt;
-					real* M = t.mpole.data() + (size_t)off * node;
+					real* M = t.mpole.data() + (size_t)offM * node;
 					if (P >= 2)
 						for (int q = 0; q < 8; ++q)
 						{
 							vec3 d = c - t.center[inds[q]];
+							const real* Mc = t.mpole.data() + (size_t)offM * inds[q];
+							if (symmetric) { for (int k = 2; k <= P; ++k) m2m_acc(M + sym_off(k), Mc, k, d); continue; }
 							real r = std::sqrt(dot(d, d));
 							if (r != 0) d = d / r;
-							const real* Mc = t.mpole.data() + (size_t)off * inds[q];
 							for (int k = 2; k <= P; ++k) m2m_traceless_acc(M + tl_off(k), temp.data(), Mc, k, d, r);
 						}
 					M[0] = (real)mlt;
@@ -964,7 +973,7 @@ static int fmm_oct_traceless(vec3* p, vec3* a, int n, const real* param, const O
 	// M2L per level L..2 over the parent's-neighbour stencil (fmm_cart3_traceless.cuh:196-254)
 	for (int l = L; l >= 2; --l)
 		parallel_ranges(oct_cnt(l), T_, [&](long long ib, long long ie, int) {
-			std::vector<real> temp(4 * P + 16);
+			std::vector<real> temp(sym_elems(P) + 4 * P + 16);
 			int sl = 1 << l, lb = oct_beg(l);
 			for (long long c = ib; c < ie; ++c)
 			{
@@ -986,7 +995,10 @@ static int fmm_oct_traceless(vec3* p, vec3* a, int n, const real* param, const O
 							vec3 d = t.center[c1] - t.center[c2];
 							real r = std::sqrt(dot(d, d) + o.eps2);
 							d = d / r;
-							m2l_tl_acc(t.local.data() + (size_t)off * c1, temp.data(), t.mpole.data() + (size_t)off * c2, P, d, r);
+							if (symmetric)
+								m2l_sym_acc(t.local.data() + (size_t)off * c1, temp.data(), t.mpole.data() + (size_t)offM * c2, P, d, r, false, false, true);
+							else
+								m2l_tl_acc(t.local.data() + (size_t)off * c1, temp.data(), t.mpole.data() + (size_t)off * c2, P, d, r);
 						}
 			}
 		});
@@ -1119,7 +1131,9 @@ void oracle_rescale(real* a, int n, real c) { for (long long i = 0; i < 3LL * n;
 int oracle_fmm_kd(real* p, real* a, int n, const real* param, const oracle_opts* o)
 { return fmm_kd((vec3*)p, (vec3*)a, n, param, to_opts(o)); }
 int oracle_fmm_oct_traceless(real* p, real* a, int n, const real* param, const oracle_opts* o)
-{ return fmm_oct_traceless((vec3*)p, (vec3*)a, n, param, to_opts(o)); }
+{ return fmm_oct((vec3*)p, (vec3*)a, n, param, to_opts(o), false); }
+int oracle_fmm_oct_symmetric(real* p, real* a, int n, const real* param, const oracle_opts* o)
+{ return fmm_oct((vec3*)p, (vec3*)a, n, param, to_opts(o), true); }
 
 int oracle_kd_levels(int n, int p, real dens_inhom) { return kd_levels(n, p, dens_inhom); }
 int oracle_oct_levels(int n, int p, real dens_inhom) { return oct_levels(n, p, dens_inhom); }
@@ -1161,7 +1175,7 @@ void oracle_oct_get_reals(int which, real* out)
 }
 
 // The wrappers of main3.cu:47-69: evaluator + add_elastic(param+3).  kind: 0 direct3, 1 kd FMM,
-// 2 octree-traceless FMM, 3 direct2.
+// 2 octree-traceless FMM, 3 direct2, 4 octree-symmetric FMM.
 static void eval_force(int kind, real* buf, int n, const real* param, const oracle_opts* o, int elastic)
 {
 	vec3* p = (vec3*)buf;
@@ -1170,7 +1184,8 @@ static void eval_force(int kind, real* buf, int n, const real* param, const orac
 	{
 	case 0: direct3(p, a, n, param, o->eps2, o->threads); break;
 	case 1: fmm_kd(p, a, n, param, to_opts(o)); break;
-	case 2: fmm_oct_traceless(p, a, n, param, to_opts(o)); break;
+	case 2: fmm_oct(p, a, n, param, to_opts(o), false); break;
+	case 4: fmm_oct(p, a, n, param, to_opts(o), true); break;
 	default: direct2(p, a, n, param, o->eps2, o->threads); break;
 	}
 	if (elastic) oracle_add_elastic((real*)p, (real*)a, n, param + 3);

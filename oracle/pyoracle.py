@@ -17,7 +17,7 @@ SIGMA_X = (0.003, 0.001, 0.01)      # main3.cu:244
 OMEGA0 = (1.095, 1.0, 1.0)          # main3.cu:241
 XI = 2e-6                           # main3.cu:240
 
-KIND_DIRECT3, KIND_FMM_KD, KIND_FMM_OCT, KIND_DIRECT2 = 0, 1, 2, 3
+KIND_DIRECT3, KIND_FMM_KD, KIND_FMM_OCT, KIND_DIRECT2, KIND_FMM_OCT_SYM = 0, 1, 2, 3, 4
 SCHEME_EULER, SCHEME_PRE_EULER, SCHEME_LEAPFROG, SCHEME_FR, SCHEME_PEFRL = 0, 1, 2, 3, 4
 
 
@@ -57,6 +57,8 @@ class Oracle:
         L.oracle_fmm_kd.restype = C.c_int
         L.oracle_fmm_oct_traceless.argtypes = [P, P, C.c_int, P, C.POINTER(Opts)]
         L.oracle_fmm_oct_traceless.restype = C.c_int
+        L.oracle_fmm_oct_symmetric.argtypes = [P, P, C.c_int, P, C.POINTER(Opts)]
+        L.oracle_fmm_oct_symmetric.restype = C.c_int
         L.oracle_kd_levels.argtypes = [C.c_int, C.c_int, r]
         L.oracle_oct_levels.argtypes = [C.c_int, C.c_int, r]
         L.oracle_kd_list_size.argtypes = [C.c_int]
@@ -141,6 +143,15 @@ class Oracle:
         assert rc == 0, rc
         return pv, a
 
+    def fmm_oct_symmetric(self, posvel, param, **kw):
+        """fmm_cart3_cpu (fmm_cart3_symmetric.cuh:582-716): the octree evaluator with symmetric multipoles of orders 0..p"""
+        pv = self.arr(posvel).copy(); n = pv.shape[1]
+        a = np.zeros((n, 3), dtype=self.dtype)
+        o = self.opts(**kw)
+        rc = self.lib.oracle_fmm_oct_symmetric(self.ptr(pv), self.ptr(a), n, self.ptr(param), C.byref(o))
+        assert rc == 0, rc
+        return pv, a
+
     def kd_tree(self, offM=None, offL=None):
         """Arrays of the tree built by the last fmm_kd call."""
         L = self.lib
@@ -173,12 +184,13 @@ class Oracle:
             a = np.empty(m, dtype=np.int32); L.oracle_oct_get_ints(i, self.ptr(a)); out[k] = a
         return out
 
-    def oct_expansions(self, p):
-        """centre / mpole / local arrays of the last fmm_oct_traceless call (order p)"""
+    def oct_expansions(self, p, symmetric=False):
+        """centre / mpole / local arrays of the last octree call (order p); symmetric: multipole tuples of (p+1)(p+2)(p+3)/6 reals"""
         L = self.lib
         ntot, off = L.oracle_oct_ntot(), (p + 1) ** 2
+        offm = (p + 1) * (p + 2) * (p + 3) // 6 if symmetric else off
         out = {}
-        for i, (k, shape) in enumerate([("center", (ntot, 3)), ("mpole", (ntot, off)), ("local", (ntot, off))]):
+        for i, (k, shape) in enumerate([("center", (ntot, 3)), ("mpole", (ntot, offm)), ("local", (ntot, off))]):
             a = np.empty(shape, dtype=self.dtype); L.oracle_oct_get_reals(i, self.ptr(a)); out[k] = a
         return out
 

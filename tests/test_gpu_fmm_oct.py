@@ -268,3 +268,66 @@ def test_far_fp64_is_rejected_by_the_kdtree_evaluator(engine, oracle32):
     engine.fmm_cart3_kdtree(d, a, n, None)
     torch.cuda.synchronize()
     assert bool(torch.isfinite(a).all())
+
+
+# ---- the octree evaluator with SYMMETRIC multipoles, `fmm_cart3` (fmm_cart3_symmetric.cuh:413-580) ----------------------------
+@pytest.mark.parametrize("n,p,kind", [(4096, 6, "cube"), (4096, 6, "gauss"), (30001, 5, "blob"), (5000, 8, "cube"), (20000, 4, "blob"),
+                                      (700, 3, "cube"), (3000, 1, "blob"), (3000, 2, "blob"), (8000, 9, "blob")])
+def test_symmetric_evaluator_matches_oracle(engine, oracle32, oracle64, n, p, kind):
+    """nbco_fmm_symmetric: same cells, same sort, same stencils as the traceless evaluator; symmetric multipole tuples of orders
+    0..p (compared with the oracle's fmm_cart3_cpu restatement), accelerations within 1e-5"""
+    import torch
+    o = oracle32
+    buf = state(o, n, kind)
+    par = o.params(n)
+    pv, want = o.fmm_oct_symmetric(buf[:2], par, p=p, threads=8)
+    tree = o.oct_tree(n)
+    ex = o.oct_expansions(p, symmetric=True)
+    engine.set(fmm_order=p)
+    d = dev(buf[:2])
+    a = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+    engine.fmm_cart3(d, a, n, dev(par))
+    torch.cuda.synchronize()
+    info = engine.oct_info()
+    assert info.mpole_reals == (p + 1) * (p + 2) * (p + 3) // 6
+    np.testing.assert_array_equal(engine.oct_array("keys").astype(np.int64), tree["keys"])
+    np.testing.assert_array_equal(engine.oct_array("perm").astype(np.int64), tree["perm"])
+    np.testing.assert_array_equal(d.cpu().numpy(), pv)
+    assert force_err(a.cpu().numpy(), want) < 1e-5
+    # multipole and local tuples against the fp64 oracle: as good as the fp32 oracle is
+    first = 9
+    occupied = tree["mult"][first:] > 0
+    oracle64.fmm_oct_symmetric(buf[:2].astype(np.float64), par.astype(np.float64), p=p, threads=8)
+    if np.array_equal(oracle64.oct_tree(n)["keys"], tree["keys"]):
+        ex64 = oracle64.oct_expansions(p, symmetric=True)
+        for name in ("mpole", "local"):
+            g, w, t = (x[name][first:][occupied] for x in ({"mpole": engine.oct_array("mpole"), "local": engine.oct_array("local")}, ex, ex64))
+            sc = np.abs(t).max(axis=0, keepdims=True).clip(1e-30)
+            floor = (np.abs(w - t) / sc).max()
+            assert (np.abs(g - t) / sc).max() < 2 * floor + 2e-5, name
+
+
+def test_symmetric_and_traceless_evaluators_agree(engine, oracle32):
+    """contracting with the (traceless) gradient of 1/r only sees the traceless part of a multipole: both octree evaluators
+    describe the same far field, and reach the direct sum equally well at an order where the reference's traceless M2M is exact"""
+    import torch
+    o = oracle32
+    n, p = 20000, 8
+    buf = state(o, n, "blob")
+    par = dev(o.params(n))
+    engine.set(fmm_order=p)
+    d1, d2 = dev(buf[:2]), dev(buf[:2])
+    a1 = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+    a2 = torch.zeros_like(a1)
+    engine.fmm_cart3_traceless(d1, a1, n, par)
+    engine.fmm_cart3(d2, a2, n, par)
+    torch.cuda.synchronize()
+    assert torch.equal(d1, d2)
+    ref = o.direct3(d1[0].cpu().numpy(), o.params(n), threads=8)
+    e1, e2 = o.mean_relerr(a1.cpu().numpy(), ref), o.mean_relerr(a2.cpu().numpy(), ref)
+    assert e2 < 1.05 * e1 + 1e-6 and e2 < 3e-4
+    # order 10 has no generated symmetric operators (they come from the order p + 1 kd-tree set)
+    from coulomb_oscillators_amd import EngineError
+    engine.set(fmm_order=10)
+    with pytest.raises(EngineError, match="orders 1..9"):
+        engine.fmm_cart3(d2, a2, n, par)
