@@ -177,7 +177,7 @@ static void launch_p2p(nbco_ctx *c, const float4 *pos, const int2 *desc, const i
 // row r holds targets A[16 (r >> 1) ..] and sources B[16 (r & 1) ..], one of each per lane, in registers.  At step s a lane
 // meets the source held by the lane s places away in its row -- the rotation is a DPP modifier (row_ror) on the subtraction's
 // operand, no instruction moves data -- and the contribution u = d r^-3 goes to the lane's own target (a -= u) and, rotated
-// back by the same modifier on the addition, to the owner of the source (b += u): 18 vector instructions for two directed
+// back by the same modifier, to the owner of the source (b += d w): 16 vector instructions for two directed
 // pairs instead of 26, one v_rsq_f32 instead of two, and no LDS traffic at all.  Sums stay in a fixed order (bit-reproducible,
 // no atomics): the wave keeps the target sums of a work unit in registers and stores them as the unit's partial sums, and it
 // stores the source sums of every (A, B) as a 32-particle "reaction" record that the L2P kernel adds to B's particles in
@@ -196,15 +196,28 @@ __device__ __forceinline__ void mutual_steps(float px, float py, float pz, float
 	const float r2 = fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, eps2)));
 	const float ri = __builtin_amdgcn_rsqf(r2);
 	const float w = ri * ri * ri;
+	ax = fmaf(-dx, w, ax); ay = fmaf(-dy, w, ay); az = fmaf(-dz, w, az);
 	if constexpr (REACT)
 	{
-		const float ux = dx * w, uy = dy * w, uz = dz * w;
-		ax -= ux; ay -= uy; az -= uz;
-		bx += row_ror16<(16 - S) % 16>(ux); by += row_ror16<(16 - S) % 16>(uy); bz += row_ror16<(16 - S) % 16>(uz);
-	}
-	else
-	{
-		ax = fmaf(-dx, w, ax); ay = fmaf(-dy, w, ay); az = fmaf(-dz, w, az);
+		// the owner of the source adds d * w of the lane that met it: w is rotated once (v_mov_b32_dpp), d rides on the DPP operand
+		// of three v_fmac_f32_dpp -- 16 vector instructions per step and lane for two directed pairs.  Written out as one asm
+		// block: hipcc folds a DPP move into v_sub / v_add but not into the tied v_fmac.  The leading s_nop covers the two wait
+		// states a DPP read needs after a VALU write of the same register (the compiler cannot see the hazard inside asm).
+		if constexpr (S == 0)
+		{
+			bx = fmaf(dx, w, bx); by = fmaf(dy, w, by); bz = fmaf(dz, w, bz);
+		}
+		else
+		{
+			float wr;
+			asm volatile("s_nop 1\n\t"
+			             "v_mov_b32_dpp %3, %7 row_ror:%8 row_mask:0xf bank_mask:0xf\n\t"
+			             "v_fmac_f32_dpp %0, %4, %3 row_ror:%8 row_mask:0xf bank_mask:0xf\n\t"
+			             "v_fmac_f32_dpp %1, %5, %3 row_ror:%8 row_mask:0xf bank_mask:0xf\n\t"
+			             "v_fmac_f32_dpp %2, %6, %3 row_ror:%8 row_mask:0xf bank_mask:0xf"
+			             : "+v"(bx), "+v"(by), "+v"(bz), "=&v"(wr)
+			             : "v"(dx), "v"(dy), "v"(dz), "v"(w), "n"((16 - S) % 16));
+		}
 	}
 	if constexpr (S + 1 < 16) mutual_steps<S + 1, REACT>(px, py, pz, sx, sy, sz, eps2, ax, ay, az, bx, by, bz);
 }
@@ -309,6 +322,39 @@ __global__ __launch_bounds__(256) void p2p_mutual_kernel(const float4 *__restric
 	}
 }
 
+// Sum of the reaction records of every target leaf, in list order: one wave per leaf, the two half-waves take alternate
+// entries (four records in flight per lane), fixed combination order.  rsum[leaf * stride + j] is what the L2P kernel adds to
+// particle j of the leaf.  (Inside the L2P kernel the same loop cost 0.15 ms: two dependent loads per entry at the occupancy
+// its 49-component local expansion leaves.)
+__global__ __launch_bounds__(256) void p2p_react_reduce_kernel(const int2 *__restrict__ sec_range, const int4 *__restrict__ desc, const float4 *__restrict__ react,
+                                                               int react_cap, int react_stride, int nleaf, int stride, float4 *__restrict__ rsum)
+{
+	const int leaf = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, j0 = lane & 31, h = lane >> 5;
+	if (leaf >= nleaf) return;
+	const int2 sr = sec_range[leaf];
+	const int e0 = __builtin_amdgcn_readfirstlane(sr.x), e1 = __builtin_amdgcn_readfirstlane(sr.y);
+	for (int jb = 0; jb < react_stride; jb += 32)
+	{
+		const int j = jb + j0;
+		float sx = 0.f, sy = 0.f, sz = 0.f;
+		for (int e = e0 + h; e < e1; e += 8)
+		{
+			float4 r[4];
+#pragma unroll
+			for (int q = 0; q < 4; ++q)
+			{
+				const int eq = e + 2 * q;
+				const int pid = eq < e1 ? desc[eq].z : -1;
+				r[q] = (pid >= 0 && pid < react_cap) ? react[(size_t)pid * react_stride + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+			}
+#pragma unroll
+			for (int q = 0; q < 4; ++q) { sx += r[q].x; sy += r[q].y; sz += r[q].z; }
+		}
+		sx += __shfl_xor(sx, 32); sy += __shfl_xor(sy, 32); sz += __shfl_xor(sz, 32);
+		if (h == 0 && j < stride) rsum[(size_t)leaf * stride + j] = make_float4(sx, sy, sz, 0.f);
+	}
+}
+
 // Does the mutual kernel beat the one-directional one for leaves of up to mlt_max particles?  It evaluates (32 TH)^2 lane
 // pairs per leaf pair at 1.5x the pair rate (measured ratio of the two bodies, tools/pair_ceiling.hip); the one-directional
 // kernel wastes the lanes beyond mlt_max of its target group.
@@ -319,6 +365,13 @@ static int p2p_mutual_halves(int mlt_max)
 	const int tpl = mlt_max <= 32 ? 32 : 64, groups = (mlt_max + tpl - 1) / tpl;
 	const double mutual = 1.5 * (double)mlt_max * mlt_max / ((32.0 * th) * (32.0 * th)), one_way = (double)mlt_max / (tpl * groups);
 	return mutual > one_way ? th : 0;
+}
+
+static void launch_react_reduce(nbco_ctx *c, const int2 *sec_range, const int4 *desc, const float4 *react, long long react_cap, int react_stride, int nleaf,
+                                int stride, float4 *rsum)
+{
+	hipLaunchKernelGGL(p2p_react_reduce_kernel, dim3((nleaf + 3) / 4), dim3(256), 0, c->stream, sec_range, desc, react,
+	                   (int)std::min<long long>(react_cap, 0x7fffffff), react_stride, nleaf, stride, rsum);
 }
 
 static void launch_p2p_mutual(nbco_ctx *c, int th, const float4 *pos, const int4 *desc, const int4 *chunk, const int *ntotal, long long chunks_hint, int stride,

@@ -177,7 +177,8 @@ __global__ __launch_bounds__(256) void k_mutual(const float *in, float *out, Sta
 
 // The mutual body as a real kernel issues it: lanes of a 16-lane row hold one target and one source each; at step s a lane
 // meets the source of the lane s places away (DPP row_ror on the operands, no data movement instructions), and its
-// contribution to that source travels back the same way into the owner's accumulator: 18 instructions per 2 directed pairs.
+// contribution to that source travels back the same way into the owner's accumulator (r^-3 rotated once, the distance on the DPP operand
+// of the multiply-adds): 16 instructions per 2 directed pairs.  This is the step of csrc/k_p2p.hpp's p2p_mutual_kernel.
 template <int S> __device__ __forceinline__ float row_ror(float v)
 {
 	if constexpr (S == 0) return v;
@@ -191,9 +192,19 @@ __device__ __forceinline__ void mutual_step(float px, float py, float pz, float 
 	const float r2 = fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, eps2)));
 	const float ri = __builtin_amdgcn_rsqf(r2);
 	const float w = ri * ri * ri;
-	const float ux = dx * w, uy = dy * w, uz = dz * w;
-	ax -= ux; ay -= uy; az -= uz;
-	bx += row_ror<(16 - S) % 16>(ux); by += row_ror<(16 - S) % 16>(uy); bz += row_ror<(16 - S) % 16>(uz);
+	ax = fmaf(-dx, w, ax); ay = fmaf(-dy, w, ay); az = fmaf(-dz, w, az);
+	if constexpr (S == 0) { bx = fmaf(dx, w, bx); by = fmaf(dy, w, by); bz = fmaf(dz, w, bz); }
+	else
+	{
+		float wr;   // (see csrc/k_p2p.hpp: one asm block, the s_nop covers the DPP read-after-write wait states)
+		asm volatile("s_nop 1\n\t"
+		             "v_mov_b32_dpp %3, %7 row_ror:%8 row_mask:0xf bank_mask:0xf\n\t"
+		             "v_fmac_f32_dpp %0, %4, %3 row_ror:%8 row_mask:0xf bank_mask:0xf\n\t"
+		             "v_fmac_f32_dpp %1, %5, %3 row_ror:%8 row_mask:0xf bank_mask:0xf\n\t"
+		             "v_fmac_f32_dpp %2, %6, %3 row_ror:%8 row_mask:0xf bank_mask:0xf"
+		             : "+v"(bx), "+v"(by), "+v"(bz), "=&v"(wr)
+		             : "v"(dx), "v"(dy), "v"(dz), "v"(w), "n"((16 - S) % 16));
+	}
 }
 template <int S>
 __device__ __forceinline__ void mutual_steps(float px, float py, float pz, float sx, float sy, float sz, float eps2, float &ax, float &ay, float &az,
