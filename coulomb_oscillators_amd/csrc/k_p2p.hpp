@@ -322,36 +322,49 @@ __global__ __launch_bounds__(256) void p2p_mutual_kernel(const float4 *__restric
 	}
 }
 
-// Sum of the reaction records of every target leaf, in list order: one wave per leaf, the two half-waves take alternate
-// entries (four records in flight per lane), fixed combination order.  rsum[leaf * stride + j] is what the L2P kernel adds to
-// particle j of the leaf.  (Inside the L2P kernel the same loop cost 0.15 ms: two dependent loads per entry at the occupancy
-// its 49-component local expansion leaves.)
+// Sum of the reaction records of every target leaf: one WORKGROUP per leaf -- the eight half-waves take entries e = slot (mod 8),
+// four records in flight per lane -- because the lists are very uneven (mean 8 records per leaf, more than 250 for a few):
+// with one wave per leaf the longest list alone took 0.1 ms.  The eight partial sums are combined in slot order (fixed:
+// bit-reproducible).  rsum[leaf * stride + j] is what the L2P kernel adds to particle j of the leaf.
 __global__ __launch_bounds__(256) void p2p_react_reduce_kernel(const int2 *__restrict__ sec_range, const int4 *__restrict__ desc, const float4 *__restrict__ react,
                                                                int react_cap, int react_stride, int nleaf, int stride, float4 *__restrict__ rsum)
 {
-	const int leaf = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, j0 = lane & 31, h = lane >> 5;
-	if (leaf >= nleaf) return;
+	__shared__ float part[8][3][32];
+	const int leaf = blockIdx.x, lane = threadIdx.x & 63, j0 = lane & 31, slot = threadIdx.x >> 5;   // slot 0..7
 	const int2 sr = sec_range[leaf];
-	const int e0 = __builtin_amdgcn_readfirstlane(sr.x), e1 = __builtin_amdgcn_readfirstlane(sr.y);
+	const int e0 = sr.x, e1 = sr.y;
+	if (e0 >= e1)
+	{
+		for (int j = threadIdx.x; j < stride; j += 256) rsum[(size_t)leaf * stride + j] = make_float4(0.f, 0.f, 0.f, 0.f);
+		return;
+	}
 	for (int jb = 0; jb < react_stride; jb += 32)
 	{
 		const int j = jb + j0;
 		float sx = 0.f, sy = 0.f, sz = 0.f;
-		for (int e = e0 + h; e < e1; e += 8)
+		for (int e = e0 + slot; e < e1; e += 32)
 		{
 			float4 r[4];
 #pragma unroll
 			for (int q = 0; q < 4; ++q)
 			{
-				const int eq = e + 2 * q;
+				const int eq = e + 8 * q;
 				const int pid = eq < e1 ? desc[eq].z : -1;
 				r[q] = (pid >= 0 && pid < react_cap) ? react[(size_t)pid * react_stride + j] : make_float4(0.f, 0.f, 0.f, 0.f);
 			}
 #pragma unroll
 			for (int q = 0; q < 4; ++q) { sx += r[q].x; sy += r[q].y; sz += r[q].z; }
 		}
-		sx += __shfl_xor(sx, 32); sy += __shfl_xor(sy, 32); sz += __shfl_xor(sz, 32);
-		if (h == 0 && j < stride) rsum[(size_t)leaf * stride + j] = make_float4(sx, sy, sz, 0.f);
+		part[slot][0][j0] = sx; part[slot][1][j0] = sy; part[slot][2][j0] = sz;
+		__syncthreads();
+		if (threadIdx.x < 32 && j < stride)
+		{
+			float tx = 0.f, ty = 0.f, tz = 0.f;
+#pragma unroll
+			for (int q = 0; q < 8; ++q) { tx += part[q][0][j0]; ty += part[q][1][j0]; tz += part[q][2][j0]; }
+			rsum[(size_t)leaf * stride + j] = make_float4(tx, ty, tz, 0.f);
+		}
+		__syncthreads();
 	}
 }
 
@@ -370,7 +383,7 @@ static int p2p_mutual_halves(int mlt_max)
 static void launch_react_reduce(nbco_ctx *c, const int2 *sec_range, const int4 *desc, const float4 *react, long long react_cap, int react_stride, int nleaf,
                                 int stride, float4 *rsum)
 {
-	hipLaunchKernelGGL(p2p_react_reduce_kernel, dim3((nleaf + 3) / 4), dim3(256), 0, c->stream, sec_range, desc, react,
+	hipLaunchKernelGGL(p2p_react_reduce_kernel, dim3(nleaf), dim3(256), 0, c->stream, sec_range, desc, react,
 	                   (int)std::min<long long>(react_cap, 0x7fffffff), react_stride, nleaf, stride, rsum);
 }
 
