@@ -54,6 +54,8 @@ def parse(argv=None):
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the tree-reuse, strong-scaling, octree and nbco3 CLI legs after the timed region")
     ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--profile-all", action="store_true", help="record HIP events around every phase (perturbs value)")
+    ap.add_argument("--engine-opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="diagnostics: an nbco_opts field for the engine, e.g. p2p_mutual=0 (one-directional near-field kernel) or m2l_first=1")
     return ap.parse_args(argv)
 
 
@@ -299,7 +301,12 @@ def main():
         buf = gaussian_ball(n_local, rank)
         d = torch.from_numpy(buf).cuda()
         prm = torch.from_numpy(coulomb_params(n_sys)).cuda()
-        eng = Engine(fmm_order=args.order, unsort=0, tree_steps=args.tree_steps, sync=0, far_fp64=int(args.far_fp64), dens_inhom=args.dens_inhom)
+        extra_opts = {}
+        for kv in args.engine_opt:
+            k, v = kv.split("=", 1)
+            extra_opts[k] = float(v) if k in ("tree_radius", "eps2", "dens_inhom") else int(v)
+        eng = Engine(**{**dict(fmm_order=args.order, unsort=0, tree_steps=args.tree_steps, sync=0, far_fp64=int(args.far_fp64),
+                               dens_inhom=args.dens_inhom), **extra_opts})
         run = None
         if sharded:
             run = DomainRun(eng, n_sys, TorchComm(), rebalance=args.rebalance)
@@ -331,7 +338,10 @@ def main():
     if args.workload == "fmm_kd":
         info = eng.kd_info()
         pairs_per_eval = int(info.directed_p2p)   # this rank's directed pair interactions per evaluation
-        extra = {"L": info.L, "p2p_pairs": int(info.p2p_pairs), "m2l_pairs": int(info.m2l_pairs), "build_mode": int(info.build_mode)}
+        extra = {"L": info.L, "p2p_pairs": int(info.p2p_pairs), "m2l_pairs": int(info.m2l_pairs), "build_mode": int(info.build_mode),
+                 "near_field": ("mutual (Newton III), %d half(s) of 32 per leaf" % info.p2p_halves) if info.p2p_halves else "one-directional"}
+        if args.engine_opt:
+            extra["engine_opt"] = args.engine_opt
         if sharded:
             extra.update({"n_system": n_sys, "rebalance_every": args.rebalance,
                           "allgather_bytes_per_eval_per_gpu": run.exchange_bytes(), "backend": args.backend})
@@ -411,7 +421,7 @@ def main():
         if launches and pairs_per_eval:
             avg_s = ms * 1e-3 / launches
             ach = pairs_per_eval * FLOP_PER_PAIR / avg_s / 1e12
-            kname = "p2p_kernel" if dom == "p2p" else "direct_tiles"
+            kname = ("p2p_mutual_kernel" if args.workload == "fmm_kd" and info.p2p_halves else "p2p_kernel") if dom == "p2p" else "direct_tiles"
             default_cfg = world == 1 and n == 1048576 and args.order == 6
             traffic, src = measured_traffic(kname) if default_cfg else (None, None)
             ceil_frac, ceil_src = measured_ceiling()

@@ -225,8 +225,8 @@ __device__ __forceinline__ void mutual_steps(float px, float py, float pz, float
 // Leaves of more than 32 particles are taken as TH halves of up to 32 (TH = 1, 2, 4 for leaves of up to 32, 64, 128): a leaf
 // pair is TH x TH passes of the four-block scheme; a wave keeps TH target positions and TH sets of target sums in registers and
 // stores one 32-particle reaction record per source half (react[(pair * TH + half) * 32 + lane]).
-template <int TH>
-__global__ __launch_bounds__(256) void p2p_mutual_kernel(const float4 *__restrict__ pos, const int4 *__restrict__ desc, const int4 *__restrict__ chunk,
+template <int TH, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void p2p_mutual_kernel(const float4 *__restrict__ pos, const int4 *__restrict__ desc, const int4 *__restrict__ chunk,
                                                          const int *__restrict__ nchunks_total, float eps2, int stride, float4 *__restrict__ partial,
                                                          float4 *__restrict__ react, int react_cap, int npos)
 {
@@ -234,9 +234,9 @@ __global__ __launch_bounds__(256) void p2p_mutual_kernel(const float4 *__restric
 	auto sane_desc = [&](int4 d) { return NBCO_CHECKED_OK(d.x >= 0 && d.y >= 0 && d.x + d.y <= npos && (unsigned)d.w <= 2u, NBCO_CHK_DESC) ? d : make_int4(0, 0, 0, 2); };
 	const int tsub = 16 * (row >> 1) + k, ssub = 16 * (row & 1) + k;   // this lane's particle inside a target / source half
 	const int total = *nchunks_total;
-	const int cstride = gridDim.x * 4;
+	const int cstride = gridDim.x * WAVES;
 	const float4 far = make_float4(1.e18f, 1.e18f, 1.e18f, 0.f);
-	for (int cid = blockIdx.x * 4 + wv; cid < total; cid += cstride)
+	for (int cid = blockIdx.x * WAVES + wv; cid < total; cid += cstride)
 	{
 		int4 ck = chunk[cid];
 		if (!NBCO_CHECKED_OK(ck.x >= 0 && ck.w >= 1 && ck.x + ck.w <= npos && ck.y <= ck.z, NBCO_CHK_CHUNK)) ck = make_int4(0, 0, 0, 1);
@@ -387,17 +387,28 @@ static void launch_react_reduce(nbco_ctx *c, const int2 *sec_range, const int4 *
 	                   (int)std::min<long long>(react_cap, 0x7fffffff), react_stride, nleaf, stride, rsum);
 }
 
+template <int WAVES>
+static void launch_p2p_mutual_w(nbco_ctx *c, int th, const float4 *pos, const int4 *desc, const int4 *chunk, const int *ntotal, long long chunks_hint, int stride,
+                                float4 *partial, float4 *react, long long react_cap, long long npos)
+{
+	const int grid = (int)std::max<long long>(1, (chunks_hint + WAVES - 1) / WAVES);
+	const int cap = (int)std::min<long long>(react_cap, 0x7fffffff);
+	if (th == 1)
+		hipLaunchKernelGGL((p2p_mutual_kernel<1, WAVES>), dim3(grid), dim3(64 * WAVES), 0, c->stream, pos, desc, chunk, ntotal, c->o.eps2, stride, partial, react, cap, (int)npos);
+	else if (th == 2)
+		hipLaunchKernelGGL((p2p_mutual_kernel<2, WAVES>), dim3(grid), dim3(64 * WAVES), 0, c->stream, pos, desc, chunk, ntotal, c->o.eps2, stride, partial, react, cap, (int)npos);
+	else
+		hipLaunchKernelGGL((p2p_mutual_kernel<4, WAVES>), dim3(grid), dim3(64 * WAVES), 0, c->stream, pos, desc, chunk, ntotal, c->o.eps2, stride, partial, react, cap, (int)npos);
+}
+// Workgroups of two waves: a workgroup keeps its wave slots until its longest work unit is done, and the units are uneven
+// (1..16 entries), while four waves per SIMD already saturate this register-only body (tools/pair_ceiling.hip)
 static void launch_p2p_mutual(nbco_ctx *c, int th, const float4 *pos, const int4 *desc, const int4 *chunk, const int *ntotal, long long chunks_hint, int stride,
                               float4 *partial, float4 *react, long long react_cap, long long npos)
 {
-	const int grid = (int)std::max<long long>(1, (chunks_hint + 3) / 4);
-	const int cap = (int)std::min<long long>(react_cap, 0x7fffffff);
-	if (th == 1)
-		hipLaunchKernelGGL(p2p_mutual_kernel<1>, dim3(grid), dim3(256), 0, c->stream, pos, desc, chunk, ntotal, c->o.eps2, stride, partial, react, cap, (int)npos);
-	else if (th == 2)
-		hipLaunchKernelGGL(p2p_mutual_kernel<2>, dim3(grid), dim3(256), 0, c->stream, pos, desc, chunk, ntotal, c->o.eps2, stride, partial, react, cap, (int)npos);
-	else
-		hipLaunchKernelGGL(p2p_mutual_kernel<4>, dim3(grid), dim3(256), 0, c->stream, pos, desc, chunk, ntotal, c->o.eps2, stride, partial, react, cap, (int)npos);
+	static const int waves = getenv("NBCO_MUT_WAVES") ? atoi(getenv("NBCO_MUT_WAVES")) : 2;
+	if (waves == 1) launch_p2p_mutual_w<1>(c, th, pos, desc, chunk, ntotal, chunks_hint, stride, partial, react, react_cap, npos);
+	else if (waves == 2) launch_p2p_mutual_w<2>(c, th, pos, desc, chunk, ntotal, chunks_hint, stride, partial, react, react_cap, npos);
+	else launch_p2p_mutual_w<4>(c, th, pos, desc, chunk, ntotal, chunks_hint, stride, partial, react, react_cap, npos);
 }
 
 } // namespace
