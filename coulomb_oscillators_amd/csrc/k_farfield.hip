@@ -342,7 +342,8 @@ __global__ __launch_bounds__(kBlock) void l2p_gen_kernel(const float4 *__restric
                                                          const int *__restrict__ chunk_off, const int *__restrict__ index, int mlt_max,
                                                          const int *__restrict__ unsort, int scatter, const float *__restrict__ param,
                                                          float *__restrict__ a_out, int have_near, long long n, int L, long long own0,
-                                                         long long own_n, const float4 *__restrict__ react_sum)
+                                                         long long own_n, const int2 *__restrict__ sec_range, const float4 *__restrict__ react,
+                                                         int react_cap, int react_stride)
 {
 	constexpr int offL = (P + 1) * (P + 1);
 	const long long io = (long long)blockIdx.x * kBlock + threadIdx.x;   // index among the domain's own particles
@@ -366,11 +367,18 @@ __global__ __launch_bounds__(kBlock) void l2p_gen_kernel(const float4 *__restric
 			const float4 nr = near[(size_t)ck * mlt_max + j];
 			nx += nr.x; ny += nr.y; nz += nr.z;
 		}
-		if (react_sum)
+		if (sec_range)
 		{
-			// mutual near field: the leaf pairs that the other leaf's wave evaluated, summed per leaf by p2p_react_reduce_kernel
-			const float4 rr = react_sum[(size_t)lf * mlt_max + j];
-			nx += rr.x; ny += rr.y; nz += rr.z;
+			// mutual near field: the sums of the leaf pairs that the other leaf's wave evaluated lie side by side at the sorted
+			// positions of this leaf's entries [sr.x, sr.y) (independent loads, added in list order)
+			int2 sr = sec_range[lf];
+			if (!NBCO_CHECKED_OK(sr.x >= 0 && sr.x <= sr.y, NBCO_CHK_L2P)) sr.y = sr.x;
+			if (sr.y > react_cap) sr.y = max(sr.x, react_cap);   // (the host repeats an evaluation whose list outgrew the records)
+			for (int e = sr.x; e < sr.y; ++e)
+			{
+				const float4 rr = react[(size_t)e * react_stride + j];
+				nx += rr.x; ny += rr.y; nz += rr.z;
+			}
 		}
 		fx += nx; fy += ny; fz += nz;
 	}
@@ -453,10 +461,10 @@ static int run_downward(nbco_ctx *c, const float *center, float *local, int L, i
 template <int P>
 static int run_l2p(nbco_ctx *c, const float4 *pos, const float *center, const float *local, const float4 *near, const int *chunk_off,
                    const int *index, int mlt_max, const int *unsort, int scatter, const float *param, float *a, int have_near, long long n, int L,
-                   long long own0, long long own_n, const float4 *react_sum)
+                   long long own0, long long own_n, const int2 *sec_range, const float4 *react, long long react_cap, int react_stride)
 {
 	hipLaunchKernelGGL(l2p_gen_kernel<P>, dim3(grid_for(own_n)), dim3(kBlock), 0, c->stream, pos, center, local, near, chunk_off, index, mlt_max,
-	                   unsort, scatter, param, a, have_near, n, L, own0, own_n, react_sum);
+	                   unsort, scatter, param, a, have_near, n, L, own0, own_n, sec_range, react, (int)std::min<long long>(react_cap, 0x7fffffff), react_stride);
 	NBCO_HIP(hipGetLastError());
 	return NBCO_OK;
 }
@@ -529,9 +537,9 @@ int launch_downward_gen(nbco_ctx *c, int P, const float *center, float *local, i
 
 int launch_l2p_gen(nbco_ctx *c, int P, const float4 *pos, const float *center, const float *local, const float4 *near, const int *chunk_off,
                    const int *index, int mlt_max, const int *unsort, int scatter, const float *param, float *a, int have_near, long long n, int L,
-                   long long own0, long long own_n, const float4 *react_sum)
+                   long long own0, long long own_n, const int2 *sec_range, const float4 *react, long long react_cap, int react_stride)
 {
-#define CALL(PP) run_l2p<PP>(c, pos, center, local, near, chunk_off, index, mlt_max, unsort, scatter, param, a, have_near, n, L, own0, own_n, react_sum)
+#define CALL(PP) run_l2p<PP>(c, pos, center, local, near, chunk_off, index, mlt_max, unsort, scatter, param, a, have_near, n, L, own0, own_n, sec_range, react, react_cap, react_stride)
 	NBCO_DISPATCH_P(P, CALL)
 #undef CALL
 }

@@ -1746,7 +1746,9 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 			c->hint_np2p = c->h_flags[0];
 			c->hint_nm2l = c->h_flags[1];
 		}
-		react_cap = std::min(cap, c->hint_np2p + c->hint_np2p / 4 + 1024);
+		// one record slot per DIRECTED entry (only the slots of entries delivered by other waves are ever written)
+		const long long pairs_room = std::min(cap, c->hint_np2p + c->hint_np2p / 4 + 1024);
+		react_cap = 2 * pairs_room + nself;
 		NBCO_TRY(c->reserve(c->p2p_react, sizeof(float4) * 32 * (size_t)mutual_th * (size_t)react_cap));
 	}
 	float4 *near = nullptr;
@@ -1760,20 +1762,11 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		if (mutual)
 		{
 			launch_p2p_mutual(c, mutual_th, pos, c->p2p_desc.as<int4>(), pc, pt, chunks_hint, mlt_max, near, c->p2p_react.as<float4>(), react_cap, n);
-			// per-leaf sums of the reaction records, for the L2P kernel (timed with the lists: NBCO_PH_P2P stays the pair kernel)
-			NBCO_TRY(c->reserve(c->p2p_rsum, sizeof(float4) * (size_t)nleaf * (size_t)mlt_max));
 		}
 		else if (mlt_max <= 8) launch_p2p<8>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near, n);
 		else if (mlt_max <= 16) launch_p2p<16>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near, n);
 		else if (mlt_max <= 32) launch_p2p<32>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near, n);
 		else launch_p2p<64>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near, n);
-		NBCO_HIP(hipGetLastError());
-		return NBCO_OK;
-	};
-	auto enqueue_react_reduce = [&]() -> int {
-		PhaseScope ph(c, NBCO_PH_LISTS);
-		launch_react_reduce(c, c->p2p_sec.as<int2>(), c->p2p_desc.as<int4>(), c->p2p_react.as<float4>(), react_cap, 32 * mutual_th, nleaf, mlt_max,
-		                    c->p2p_rsum.as<float4>());
 		NBCO_HIP(hipGetLastError());
 		return NBCO_OK;
 	};
@@ -1806,11 +1799,11 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 			                             c->p2p_start.as<int>(), c->p2p_keys.as<uint64_t>(), c->p2p_keys_alt.as<uint64_t>(), c->sort_tmp,
 			                             tv.index + beg, tv.mult + beg, c->p2p_desc.as<int2>(), c->p2p_chunk_off.as<int>(), c->p2p_chunks.as<int4>(),
 			                             mutual ? &mu : nullptr));
+			if (mutual) launch_p2p_link(c, c->p2p_desc.as<int4>(), c->p2p_keys_alt.as<uint64_t>(), c->p2p_start.as<int>(), c->p2p_start.as<int>() + nleaf, shift, dp2p_hint);
 			// remembered for nbco_kd_get_info (the directed pair count is evaluated on demand)
 			c->pc_mult = tv.mult + beg; c->pc_shift = shift; c->pc_total = c->p2p_start.as<int>() + nleaf;
 		}
 		if (c->o.coll) NBCO_TRY(enqueue_p2p());   // before the host spends its time on the far-field chain below: the pair kernel is next on this stream
-		if (mutual) NBCO_TRY(enqueue_react_reduce());
 		// the far field does not depend on the P2P list: M2L list, M2L and L2L run on the second stream, behind the
 		// multipole chain, and overlap the P2P list chain and the start of P2P
 		// (the locals are cleared on the second stream before it starts waiting for the traversal)
@@ -1839,7 +1832,8 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 	{
 		PhaseScope ph(c, NBCO_PH_L2P);
 		NBCO_TRY(launch_l2p_gen(c, P, pos, tv.center, tv.local, near, c->p2p_chunk_off.as<int>(), tv.index, mlt_max, unsort, c->o.unsort ? 1 : 0,
-		                        param, a, c->o.coll ? 1 : 0, n, L, own0, own_n, mutual ? c->p2p_rsum.as<float4>() : nullptr));
+		                        param, a, c->o.coll ? 1 : 0, n, L, own0, own_n, mutual ? c->p2p_sec.as<int2>() : nullptr,
+		                        mutual ? c->p2p_react.as<float4>() : nullptr, react_cap, 32 * mutual_th));
 	}
 	// ---- now look at what the traversal reported (long finished: the GPU is busy with the work queued above) ----------
 	{
@@ -1869,7 +1863,7 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		le.pos = pos; le.n = n; le.own0 = own0; le.own_n = own_n;
 		le.have_p2p = c->o.coll != 0;
 	}
-	if (mutual && h[0] > react_cap) out.react_overflow = 1;   // the pair list outgrew the reaction records: same evaluation again, sized from h[0]
+	if (mutual && 2LL * h[0] + nself > react_cap) out.react_overflow = 1;   // the pair list outgrew the reaction records: same evaluation again, sized from h[0]
 	return NBCO_OK;
 }
 

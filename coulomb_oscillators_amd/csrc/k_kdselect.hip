@@ -28,7 +28,7 @@ using namespace kdc;
 // Atomics on one address retire at ~27 ns each on this part, and every workgroup of a node adds to the node's histogram
 // bins, completion counters and partition cursors: levels whose nodes hold >= 8192 particles use 1024-thread workgroups
 // (8192-element chunks), a quarter of the workgroups per node; the rest (nodes of 4097..8191) use 256 / 2048.
-constexpr int kBlockBig = 1024, kBlockMid = 512, kBlockSmall = 256;
+constexpr int kBlockBig = 1024, kBlockSmall = 256;
 constexpr int kBins = 2048;
 constexpr int kTieCap = 64;
 
@@ -534,24 +534,12 @@ int kd_select_level(nbco_ctx *c, int l, long long n, const float4 *pos_in, const
 	// caller falls back to three passes everywhere (sel_three_pass), then to the sorting build.
 	const long long node = n >> l;
 	const int np = (c->sel_three_pass || node > (1LL << 22)) ? 3 : 2;
-	// Workgroup size by the number of workgroups that share a node's counters: every workgroup of a node adds to the same
-	// cursors (same-address atomics retire at ~27 ns each), so the top levels take 8192-element chunks; but 1024-thread
-	// workgroups are only n / 8192 of them -- 128 at N = 1M, half the CUs idle -- so as soon as a node is shared by few enough
-	// workgroups the chunks shrink (a chunk may touch at most two nodes: it never exceeds the node size).
-	static const int cap = getenv("NBCO_SEL_WG_PER_NODE") ? atoi(getenv("NBCO_SEL_WG_PER_NODE")) : 32;
-	int block = kBlockBig;
-	while (block > kBlockSmall && node / (8 * (block / 2)) <= cap && node >= 8 * (block / 2)) block /= 2;
-	if (node < 8 * kBlockBig) block = kBlockSmall;
+	const bool big = node >= 8 * kBlockBig;
 #define NBCO_SEL_ARGS c, l, n, pos_in, unsort_in, pos_out, unsort_out, lbound, rbound, splitdim, index, flag
-	if (block == kBlockBig)
+	if (big)
 	{
 		if (np == 2) select_level_launch<kBlockBig, 2>(NBCO_SEL_ARGS);
 		else select_level_launch<kBlockBig, 3>(NBCO_SEL_ARGS);
-	}
-	else if (block == kBlockMid)
-	{
-		if (np == 2) select_level_launch<kBlockMid, 2>(NBCO_SEL_ARGS);
-		else select_level_launch<kBlockMid, 3>(NBCO_SEL_ARGS);
 	}
 	else
 	{

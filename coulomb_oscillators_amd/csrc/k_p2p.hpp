@@ -182,7 +182,8 @@ static void launch_p2p(nbco_ctx *c, const float4 *pos, const int2 *desc, const i
 // no atomics): the wave keeps the target sums of a work unit in registers and stores them as the unit's partial sums, and it
 // stores the source sums of every (A, B) as a 32-particle "reaction" record that the L2P kernel adds to B's particles in
 // list order.  Entry codes (desc.w): 0 = one direction only (the leaf with itself; a source leaf of another kd-domain),
-// 1 = both directions, reaction stored at react[desc.z], 2 = the other leaf's wave delivers this entry's sum (skipped here).
+// 1 = both directions, reaction stored at react[desc.z] (desc.z = sorted position of the mirror entry, p2p_link_kernel),
+// 2 = the other leaf's wave delivers this entry's sum (skipped here).
 template <int S> __device__ __forceinline__ float row_ror16(float v)
 {
 	if constexpr (S == 0) return v;
@@ -253,23 +254,28 @@ __global__ __launch_bounds__(64 * WAVES) void p2p_mutual_kernel(const float4 *__
 			if (32 * h + tsub >= mt) pt[h] = far;
 			ax[h] = ay[h] = az[h] = 0.f;
 		}
-		auto load_sources = [&](const int4 &d, float4 (&ps)[TH]) {
+		// Software pipeline over the entries, two deep: the descriptor of entry e + 2 (scalar load) and the source positions of entry
+		// e + 1 (vector load, raw: the out-of-range lanes are replaced by the far point only when the values are taken over)
+		// are requested BEFORE entry e is evaluated and first touched after it, so neither latency sits in front of the 16 steps.
+		// (Selecting the far point right behind the load put an s_waitcnt vmcnt(0) ahead of every entry's arithmetic.)
+		auto request_sources = [&](const int4 &d, float4 (&raw)[TH]) {
 #pragma unroll
-			for (int h = 0; h < TH; ++h)
-			{
-				ps[h] = pos[d.x + min(32 * h + ssub, max(d.y - 1, 0))];
-				if (32 * h + ssub >= d.y) ps[h] = far;
-			}
+			for (int h = 0; h < TH; ++h) raw[h] = pos[d.x + min(32 * h + ssub, max(d.y - 1, 0))];
 		};
-		// the sources of the first entry; every later entry's are fetched while its predecessor is being evaluated
-		int4 d = e0 < e1 ? sane_desc(desc[e0]) : make_int4(0, 0, 0, 2);
-		float4 ps[TH];
-		load_sources(d, ps);
+		auto take_sources = [&](const int4 &d, const float4 (&raw)[TH], float4 (&ps)[TH]) {
+#pragma unroll
+			for (int h = 0; h < TH; ++h) ps[h] = (32 * h + ssub < d.y) ? raw[h] : far;
+		};
+		const int4 none = make_int4(0, 0, 0, 2);
+		int4 d = e0 < e1 ? sane_desc(desc[e0]) : none;
+		int4 dn = e0 + 1 < e1 ? sane_desc(desc[e0 + 1]) : none;
+		float4 ps[TH], raw[TH];
+		request_sources(d, raw);
+		take_sources(d, raw, ps);
 		for (int e = e0; e < e1; ++e)
 		{
-			const int4 dn = e + 1 < e1 ? sane_desc(desc[e + 1]) : make_int4(0, 0, 0, 2);
-			float4 pn[TH];
-			load_sources(dn, pn);
+			const int4 dnn = e + 2 < e1 ? sane_desc(desc[e + 2]) : none;
+			request_sources(dn, raw);
 			const int code = __builtin_amdgcn_readfirstlane(d.w), ms = __builtin_amdgcn_readfirstlane(d.y);
 			if (code == 1)
 			{
@@ -289,7 +295,7 @@ __global__ __launch_bounds__(64 * WAVES) void p2p_mutual_kernel(const float4 *__
 					}
 					// rows 0 and 2 (1 and 3) hold the two halves of the sums of this source half's lower (upper) 16 particles
 					bx += __shfl_xor(bx, 32); by += __shfl_xor(by, 32); bz += __shfl_xor(bz, 32);
-					if (lane < 32 && pid < react_cap) react[((size_t)pid * TH + hs) * 32 + lane] = make_float4(bx, by, bz, 0.f);
+					if (lane < 32 && pid >= 0 && pid < react_cap) react[((size_t)pid * TH + hs) * 32 + lane] = make_float4(bx, by, bz, 0.f);
 				}
 			}
 			else if (code == 0)
@@ -308,9 +314,8 @@ __global__ __launch_bounds__(64 * WAVES) void p2p_mutual_kernel(const float4 *__
 					}
 				}
 			}
-			d = dn;
-#pragma unroll
-			for (int h = 0; h < TH; ++h) ps[h] = pn[h];
+			take_sources(dn, raw, ps);
+			d = dn; dn = dnn;
 		}
 		// rows 0 and 1 (2 and 3) hold the two halves of the sums of a target half's lower (upper) 16 particles
 #pragma unroll
@@ -322,49 +327,27 @@ __global__ __launch_bounds__(64 * WAVES) void p2p_mutual_kernel(const float4 *__
 	}
 }
 
-// Sum of the reaction records of every target leaf: one WORKGROUP per leaf -- the eight half-waves take entries e = slot (mod 8),
-// four records in flight per lane -- because the lists are very uneven (mean 8 records per leaf, more than 250 for a few):
-// with one wave per leaf the longest list alone took 0.1 ms.  The eight partial sums are combined in slot order (fixed:
-// bit-reproducible).  rsum[leaf * stride + j] is what the L2P kernel adds to particle j of the leaf.
-__global__ __launch_bounds__(256) void p2p_react_reduce_kernel(const int2 *__restrict__ sec_range, const int4 *__restrict__ desc, const float4 *__restrict__ react,
-                                                               int react_cap, int react_stride, int nleaf, int stride, float4 *__restrict__ rsum)
+// Where a reaction record goes: the wave of (A, B), A before B, stores B's sums at the SORTED position of the mirror entry
+// (B <- A) in B's list, so that the records of a leaf lie side by side in list order and the L2P kernel reads them with
+// independent, contiguous loads (a per-leaf reduction over records scattered by pair number cost 0.06-0.1 ms).  One thread per
+// entry of code 1 finds that position by binary search over B's sorted sources and leaves it in desc.z.
+__global__ __launch_bounds__(256) void p2p_link_kernel(int4 *__restrict__ desc, const uint64_t *__restrict__ keys, const int *__restrict__ start,
+                                                       const int *__restrict__ total_ptr, int shift)
 {
-	__shared__ float part[8][3][32];
-	const int leaf = blockIdx.x, lane = threadIdx.x & 63, j0 = lane & 31, slot = threadIdx.x >> 5;   // slot 0..7
-	const int2 sr = sec_range[leaf];
-	const int e0 = sr.x, e1 = sr.y;
-	if (e0 >= e1)
+	const int total = *total_ptr;
+	const uint64_t mask = (1ull << shift) - 1;
+	for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256)
 	{
-		for (int j = threadIdx.x; j < stride; j += 256) rsum[(size_t)leaf * stride + j] = make_float4(0.f, 0.f, 0.f, 0.f);
-		return;
-	}
-	for (int jb = 0; jb < react_stride; jb += 32)
-	{
-		const int j = jb + j0;
-		float sx = 0.f, sy = 0.f, sz = 0.f;
-		for (int e = e0 + slot; e < e1; e += 32)
+		if (desc[e].w != 1) continue;
+		const uint64_t key = keys[e];
+		const int a = (int)(key >> shift), b = (int)(key & mask);   // target, source: look for source a in the list of target b
+		int lo = start[b], hi = start[b + 1];
+		while (lo < hi)
 		{
-			float4 r[4];
-#pragma unroll
-			for (int q = 0; q < 4; ++q)
-			{
-				const int eq = e + 8 * q;
-				const int pid = eq < e1 ? desc[eq].z : -1;
-				r[q] = (pid >= 0 && pid < react_cap) ? react[(size_t)pid * react_stride + j] : make_float4(0.f, 0.f, 0.f, 0.f);
-			}
-#pragma unroll
-			for (int q = 0; q < 4; ++q) { sx += r[q].x; sy += r[q].y; sz += r[q].z; }
+			const int mid = (lo + hi) >> 1;
+			if ((int)(keys[mid] & mask) < a) lo = mid + 1; else hi = mid;
 		}
-		part[slot][0][j0] = sx; part[slot][1][j0] = sy; part[slot][2][j0] = sz;
-		__syncthreads();
-		if (threadIdx.x < 32 && j < stride)
-		{
-			float tx = 0.f, ty = 0.f, tz = 0.f;
-#pragma unroll
-			for (int q = 0; q < 8; ++q) { tx += part[q][0][j0]; ty += part[q][1][j0]; tz += part[q][2][j0]; }
-			rsum[(size_t)leaf * stride + j] = make_float4(tx, ty, tz, 0.f);
-		}
-		__syncthreads();
+		desc[e].z = lo;
 	}
 }
 
@@ -380,11 +363,10 @@ static int p2p_mutual_halves(int mlt_max)
 	return mutual > one_way ? th : 0;
 }
 
-static void launch_react_reduce(nbco_ctx *c, const int2 *sec_range, const int4 *desc, const float4 *react, long long react_cap, int react_stride, int nleaf,
-                                int stride, float4 *rsum)
+static void launch_p2p_link(nbco_ctx *c, int4 *desc, const uint64_t *keys, const int *start, const int *total_ptr, int shift, long long entries_hint)
 {
-	hipLaunchKernelGGL(p2p_react_reduce_kernel, dim3(nleaf), dim3(256), 0, c->stream, sec_range, desc, react,
-	                   (int)std::min<long long>(react_cap, 0x7fffffff), react_stride, nleaf, stride, rsum);
+	const int grid = (int)std::min<long long>(std::max<long long>(1, (entries_hint + 255) / 256), 4096);
+	hipLaunchKernelGGL(p2p_link_kernel, dim3(grid), dim3(256), 0, c->stream, desc, keys, start, total_ptr, shift);
 }
 
 template <int WAVES>

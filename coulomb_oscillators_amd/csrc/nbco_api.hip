@@ -194,7 +194,7 @@ int nbco_destroy(nbco_ctx *c)
 	                  &c->unsort, &c->unsort_alt, &c->sort_tmp, &c->treebuf, &c->frontier_a, &c->frontier_b, &c->p2p_list,
 	                  &c->m2l_list, &c->counters, &c->p2p_keys, &c->p2p_keys_alt, &c->m2l_keys, &c->m2l_keys_alt,
 	                  &c->p2p_start, &c->m2l_start, &c->p2p_chunk_off, &c->p2p_chunks, &c->sel_hist, &c->sel_nodes, &c->sel_ties, &c->list_cnt,
-	                  &c->dist_top, &c->dist_tree, &c->oct_tree, &c->oct_groups, &c->scan_tmp_aux, &c->p2p_desc, &c->trav_ctr, &c->prep_state, &c->p2p_sec, &c->p2p_react, &c->p2p_rsum, &c->order, &c->order_alt};
+	                  &c->dist_top, &c->dist_tree, &c->oct_tree, &c->oct_groups, &c->scan_tmp_aux, &c->p2p_desc, &c->trav_ctr, &c->prep_state, &c->p2p_sec, &c->p2p_react, &c->order, &c->order_alt};
 	if (c->aux && !c->aux_is_main) { hipStreamSynchronize(c->aux); hipStreamDestroy(c->aux); }
 	if (c->ev_fork) hipEventDestroy(c->ev_fork);
 	if (c->ev_join) hipEventDestroy(c->ev_join);

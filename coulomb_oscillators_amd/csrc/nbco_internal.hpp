@@ -167,7 +167,7 @@ struct nbco_ctx
 	DevBuf p2p_chunk_off, p2p_chunks, p2p_desc;
 	DevBuf order, order_alt;     // opts.track_order: position in the state -> particle number of the state the tracking started from
 	long long order_n = -1;
-	DevBuf p2p_sec, p2p_react, p2p_rsum;   // mutual near field: per-target range of entries delivered by other waves, reaction records
+	DevBuf p2p_sec, p2p_react;   // mutual near field: per-target range of entries delivered by other waves, reaction records
 	const int *pc_mult = nullptr, *pc_total = nullptr;   // inputs of the on-demand directed pair count
 	int pc_shift = 0;
 	DevBuf list_cnt, trav_ctr;
@@ -294,7 +294,8 @@ int launch_m2m_top_gen(nbco_ctx *c, int P, float *center, float *mpole, int *mul
 int launch_kd_centres_top(nbco_ctx *c, float *center, int *mult, int ltop, const float *lbound, const float *rbound, float4 *csz);
 int launch_l2p_gen(nbco_ctx *c, int P, const float4 *pos, const float *center, const float *local, const float4 *near, const int *chunk_off,
                    const int *index, int mlt_max, const int *unsort, int scatter, const float *param, float *a, int have_near, long long n, int L,
-                   long long own0, long long own_n, const float4 *react_sum = nullptr);
+                   long long own0, long long own_n, const int2 *sec_range = nullptr, const float4 *react = nullptr, long long react_cap = 0,
+                   int react_stride = 32);
 // k_m2l.hip
 // mstride: reals per multipole tuple in `mpole` (0 = the offM(P) of the kd-tree layout; the symmetric octree evaluator keeps orders 0..P)
 int launch_m2l_lanes(nbco_ctx *c, int P, const float4 *csz, const float *mpole, float *local, const uint64_t *keys, const int *start,
