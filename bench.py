@@ -129,16 +129,21 @@ def measured_traffic(kernel):
 
 
 def measured_ceiling():
-    """fraction of the nominal fp32 peak that the bare 13-instruction pair body reaches on register operands
-    (tools/pair_ceiling.hip, summary committed under profiles/): the issue ceiling of any non-mutual pair kernel"""
+    """fraction of the nominal fp32 peak that the bare pair bodies reach on register operands (tools/pair_ceiling.hip, summary
+    committed under profiles/): {"pair": the 13-instruction one-directional body, "mutual": the 16-instruction Newton-III step},
+    each as (sustained, burst) -- burst = launches of 0.2 ms, the length of the near-field kernel inside a step"""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pair_ceiling.json")))
     if not files:
         return None, None
     with open(files[-1]) as f:
         res = json.load(f)["results"]
-    best = max((r["frac_of_157.3"] for r in res if r["variant"] in ("pair", "pair4")), default=None)
-    return best, os.path.relpath(files[-1], ROOT)
+    out = {}
+    for key, variants in (("pair", ("pair", "pair4")), ("mutual", ("mutual_dpp",))):
+        for mode in ("sustained", "burst"):
+            v = [r["frac_of_157.3"] for r in res if r["variant"] in variants and r.get("mode", "sustained") == mode]
+            out["%s_%s" % (key, mode)] = max(v) if v else None
+    return out, os.path.relpath(files[-1], ROOT)
 
 
 # ---- synthetic workload: the initial condition of main3.cu:629-692 (Gaussian ball, centred, RMS-normalised) --------------
@@ -373,6 +378,31 @@ def main():
         reuse = {"tree_steps": 8, "steps": k8, "ms_per_step": 1e3 * e8 / k8, "value": n * k8 / e8, "unit": "particle-steps/s"}
         eng.set(tree_steps=1)
 
+    # the same steps with the mutual (Newton III) near-field kernel, opts.p2p_mutual: its pair kernel runs at a higher fraction of
+    # the fp32 peak, the step as a whole is slower (reaction records: written, linked, summed) -- which is why it is not the default
+    mutual = None
+    if legs and world == 1 and args.workload == "fmm_kd" and not any(o.startswith("p2p_mutual") for o in args.engine_opt):
+        eng.set(p2p_mutual=1)
+        for _ in range(max(2, args.warmup)):
+            step()
+        if eng.kd_info().p2p_halves:
+            eng.profile([dom])
+            eng.profile_reset()
+            barrier()
+            tm = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            barrier()
+            em = time.perf_counter() - tm
+            pm = eng.profile_get()[dom]
+            eng.profile(False)
+            pairs_m = int(eng.kd_info().directed_p2p)
+            avg_m = pm[0] * 1e-3 / max(pm[1], 1)
+            mutual = {"opts": "p2p_mutual=1", "kernel": "p2p_mutual_kernel", "ms_per_step": 1e3 * em / args.steps, "value": n * args.steps / em,
+                      "avg_launch_ms": avg_m * 1e3, "pairs_per_launch": pairs_m,
+                      "frac": pairs_m * FLOP_PER_PAIR / avg_m / 1e12 / FP32_VECTOR_PEAK_TFLOPS}
+        eng.set(p2p_mutual=0)
+
     # the metric reads "N = 1M ... at 1/2/4/8 GPUs": ONE system of --particles cut into `world` kd-domains (strong scaling),
     # next to the headline value, which keeps --particles per GPU (weak scaling)
     strong = None
@@ -410,6 +440,7 @@ def main():
         "data": "synthetic",
         "gpair_per_s": pairs_all * args.steps / elapsed / 1e9,
         "tree_reuse": reuse,
+        "near_field_mutual": mutual,
         "strong": strong,
         "config": {"workload": wl, "n_per_gpu": n, "order": args.order, "dt": args.dt,
                    "init": "reference stream mt19937_64(%d + rank), discard %d (main3.cu:662-664)" % (REF_SEED, REF_DISCARD),
@@ -424,12 +455,13 @@ def main():
             kname = ("p2p_mutual_kernel" if args.workload == "fmm_kd" and info.p2p_halves else "p2p_kernel") if dom == "p2p" else "direct_tiles"
             default_cfg = world == 1 and n == 1048576 and args.order == 6
             traffic, src = measured_traffic(kname) if default_cfg else (None, None)
-            ceil_frac, ceil_src = measured_ceiling()
+            ceil, ceil_src = measured_ceiling()
+            ceil_frac = (ceil or {}).get("mutual_burst" if kname == "p2p_mutual_kernel" else "pair_burst")
             out["roofline"] = {"bound": "valu_fp32", "kernel": kname,
                                "achieved": ach, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / FP32_VECTOR_PEAK_TFLOPS,
                                "frac_of_measured_ceiling": (ach / FP32_VECTOR_PEAK_TFLOPS / ceil_frac) if ceil_frac else None,
-                               "measured_ceiling_frac": ceil_frac, "measured_ceiling_source": ceil_src,
+                               "measured_ceiling_frac": ceil_frac, "measured_ceilings": ceil, "measured_ceiling_source": ceil_src,
                                "traffic": traffic, "traffic_unit": "B/launch", "traffic_source": src,
                                "pairs_per_launch": pairs_per_eval, "avg_launch_ms": avg_s * 1e3, "flop_per_pair": FLOP_PER_PAIR}
         if args.profile_all:

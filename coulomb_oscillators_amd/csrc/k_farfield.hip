@@ -374,6 +374,7 @@ __global__ __launch_bounds__(kBlock) void l2p_gen_kernel(const float4 *__restric
 			int2 sr = sec_range[lf];
 			if (!NBCO_CHECKED_OK(sr.x >= 0 && sr.x <= sr.y, NBCO_CHK_L2P)) sr.y = sr.x;
 			if (sr.y > react_cap) sr.y = max(sr.x, react_cap);   // (the host repeats an evaluation whose list outgrew the records)
+#pragma unroll 4
 			for (int e = sr.x; e < sr.y; ++e)
 			{
 				const float4 rr = react[(size_t)e * react_stride + j];

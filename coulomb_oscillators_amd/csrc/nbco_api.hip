@@ -146,7 +146,7 @@ int nbco_opts_default(nbco_opts *o)
 	o->list_factor = 48;
 	o->list_grow = 1;
 	o->far_fp64 = 0;
-	o->p2p_mutual = 1;
+	o->p2p_mutual = 0;
 	o->track_order = 0;
 	o->stream = nullptr;
 	return NBCO_OK;

@@ -87,11 +87,14 @@ typedef struct nbco_opts {
 	                       beyond N ~ 1e5 at orders 9-10 (r^-11 19!! ~ 1e40); this mode does not.
 	                       No reference counterpart other than the -DSCAL=double build.  nbco_fmm_kdtree
 	                       rejects it (NBCO_ERR_UNSUPPORTED). */
-	int   p2p_mutual;   /* != 0 (default): nbco_fmm_kdtree evaluates every leaf pair of its near field once and applies the
-	                       force to both leaves (Newton III), as the reference's GPU pair kernel does
-	                       (fmm_cart3_kdtree.cuh:874-959) -- here without atomics: fixed-order sums, bit-reproducible.  Used when
-	                       the leaves hold 17..32 particles (orders 5 and 6 at the reference's leaf sizing); other sizes and
-	                       0 take the one-directional kernel, whose sharded results equal the single-GPU ones bit for bit. */
+	int   p2p_mutual;   /* != 0: nbco_fmm_kdtree evaluates every leaf pair of its near field once and applies the force to both
+	                       leaves (Newton III), as the reference's GPU pair kernel does (fmm_cart3_kdtree.cuh:874-959) -- here
+	                       without atomics: the second leaf's sums go to fixed-order "reaction" records, bit-reproducible.
+	                       Leaves are taken as 1, 2 or 4 halves of up to 32 particles (nbco_kd_info.p2p_halves; sizes that fill
+	                       the 16-lane rows too badly fall back to the one-directional kernel).  The pair kernel itself is 20 %
+	                       faster (0.43 against 0.36 of the fp32 peak at N = 1M, p = 6), but writing, linking and summing the
+	                       reaction records costs more than that: a step is 8 % slower.  Default 0: the one-directional kernel,
+	                       whose sharded results also equal the single-GPU ones bit for bit. */
 	int   track_order;  /* != 0: with unsort = 0 the context composes the permutations of all rebuilds since tracking started, so that
 	                       NBCO_KD_ORDER maps a position of the (tree-ordered) state to the particle's number in the state the
 	                       first tracked evaluation received: snapshots can be written in input order (the

@@ -59,8 +59,8 @@ SCRIPT = textwrap.dedent('''
     e.close()
 
     # 2. the production paths: both near-field kernels, tree reuse, caller's order, odd sizes, octree, two kd-domains
-    for (nn, pp, kw) in ((65536, 6, dict(unsort=0, tree_steps=4)), (65536, 6, dict(unsort=0, p2p_mutual=0)), (5000, 4, dict(unsort=1)),
-                         (30001, 5, dict(unsort=1)), (100000, 6, dict(unsort=0)), (4097, 3, dict(unsort=0, tree_steps=2))):
+    for (nn, pp, kw) in ((65536, 6, dict(unsort=0, tree_steps=4, p2p_mutual=1)), (65536, 6, dict(unsort=0, p2p_mutual=0)), (5000, 4, dict(unsort=1)),
+                         (30001, 5, dict(unsort=1, p2p_mutual=1)), (100000, 6, dict(unsort=0, p2p_mutual=1)), (4097, 3, dict(unsort=0, tree_steps=2))):
         b, pr = dev(o.init_reference(nn)), dev(o.params(nn))
         en = Engine(fmm_order=pp, **kw)
         en.compute_force(EVAL_FMM_KDTREE, b, nn, pr)
@@ -77,7 +77,7 @@ SCRIPT = textwrap.dedent('''
     assert torch.isfinite(acc).all()
     nn = 32768
     st = o.init_reference(nn)
-    w = LoopbackWorld([Engine(fmm_order=6, unsort=0) for _ in range(2)], nn)
+    w = LoopbackWorld([Engine(fmm_order=6, unsort=0, p2p_mutual=1) for _ in range(2)], nn)
     h = nn // 2
     w.partition([dev(st[0][:h]), dev(st[0][h:])], [dev(st[1][:h]), dev(st[1][h:])])
     w.force(dev(o.params(nn)), elastic=False)
