@@ -1,0 +1,25 @@
+#!/bin/bash
+# The round's profile set on the GPU box: kernel trace + stats, two HBM PMC passes, one SQ PMC pass (default and mutual near
+# field), the pair-body ceiling, the default bench line.  Everything lands under gpurun_out/<tag>/ ; tools/rocprof_summary.py and
+# tools/sq_summary.py condense it into profiles/<tag>_* afterwards (on either machine).
+#   tools/profile_round.sh <tag>
+tag=$1
+out=gpurun_out/$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT || exit 1
+B="bench.py --no-extra-legs --no-cpu-baseline --steps 30"
+echo "[$(date +%T)] kernel trace" | tee -a $out/progress.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o out -- python3 $B > $out/bench_under_rocprof.json 2> $out/kt.err || exit 2
+echo "[$(date +%T)] FETCH_SIZE" | tee -a $out/progress.txt
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -o out -- python3 $B > /dev/null 2> $out/fetch.err || exit 3
+echo "[$(date +%T)] WRITE_SIZE" | tee -a $out/progress.txt
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -o out -- python3 $B > /dev/null 2> $out/write.err || exit 4
+echo "[$(date +%T)] SQ counters" | tee -a $out/progress.txt
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $out/sq -o out -- python3 $B > /dev/null 2> $out/sq.err || exit 5
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $out/sq_mutual -o out -- python3 $B --engine-opt p2p_mutual=1 > /dev/null 2> $out/sq_mutual.err || exit 6
+echo "[$(date +%T)] pair ceiling" | tee -a $out/progress.txt
+timeout -k 10 200 ./build/pair_ceiling $out/pair_ceiling.json > $out/pair_ceiling.txt 2>&1 || exit 7
+echo "[$(date +%T)] default bench" | tee -a $out/progress.txt
+timeout -k 10 400 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err || exit 8
+echo "[$(date +%T)] done" | tee -a $out/progress.txt
+find $out -name "*.csv" | head -20
