@@ -2,8 +2,9 @@
 // interface, initial conditions and headerless binary state files, re-implemented for the MI355X
 // engine.  Behaviour follows main3.cu:225-883 (flags :247-623, input :629-652, Gaussian / uniform
 // init :71-137,662-666, parameter pack :685-692, -accuracy :737-788, -test :790-811, -test2 :812-831,
-// simulation loop + snapshots :832-874).  The force path is GPU only: `-cpu`, `-cpu-threads` and
-// `-cacheline` are recognised and rejected (the reference's CPU twin is out of scope).
+// simulation loop + snapshots :832-874).  `-cpu` runs the simulation loop on the host with the compensated direct sum
+// (nbco_cpu.hpp: plumbing for small N; the reference's CPU twin of the FMM is out of scope); the test / tuning modes
+// need the GPU.
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
@@ -18,6 +19,7 @@
 #include <vector>
 
 #include "nbco_reference_api.hpp"
+#include "nbco_cpu.hpp"
 
 using namespace nbco_ref;
 using namespace std::chrono;
@@ -57,7 +59,9 @@ const char *kHelp =
     "  -xi <v>, -omega0 <wx> <wy>, -x <sx> <sy> <sz>, -u <ux> <uy> <uz>   physical parameters.\n"
     "  -snapshot-order <tree|input>   order of the particles in the snapshots: tree (default, as the reference: the order the\n"
     "                    last tree rebuild left them in) or input (every particle keeps the row it had in the initial state).\n"
-    "  -cpu, -cpu-threads <n>, -cacheline <n>   not available: this build is GPU (MI355X) only.\n";
+    "  -cpu              Run the simulation on the host: compensated direct sum O(N^2) over C++20 threads (small N; the test and\n"
+    "                    tuning modes need the GPU).  -cpu-threads <n> sets the number of threads (default 8); -cacheline <n> is\n"
+    "                    accepted and ignored.\n";
 
 // device allocation that frees itself
 template <class T> struct DeviceArray
@@ -234,7 +238,7 @@ int main(int argc, const char **argv)
 	SCAL dt = (SCAL)5.e-4;
 	int nIters = 30001, nSteps = 200;
 	std::string strout("out"), strin;
-	bool in = false, test = false, test2 = false, b_accuracy = false, input_order = false;
+	bool in = false, test = false, test2 = false, b_accuracy = false, input_order = false, cpu = false;
 	SCAL accuracy = (SCAL)0.001;
 	int scheme = NBCO_INTEG_LEAPFROG;   // main3.cu:238
 	SCAL xi = (SCAL)2.e-6;
@@ -342,10 +346,18 @@ int main(int argc, const char **argv)
 			if (accuracy <= 0) { std::cerr << "Error: invalid argument to '-accuracy': " << argv[i + 1] << " (should be greater than 0)\n"; return -1; }
 			++i;
 		}
-		else if (a == "-cpu" || a == "-cpu-threads" || a == "-cacheline")
+		else if (a == "-cpu") cpu = true;
+		else if (a == "-cpu-threads")
 		{
-			std::cerr << "Error: '" << a << "' is not available: this build runs the force path on the GPU only\n";
-			return -1;
+			if (!need(i, 1, "-cpu-threads")) return -1;
+			nbco_cpu::threads() = atoi(argv[i + 1]);
+			if (nbco_cpu::threads() <= 0) { std::cerr << "Error: invalid argument to '-cpu-threads': " << argv[i + 1] << " (should be greater than 0)\n"; return -1; }
+			++i;
+		}
+		else if (a == "-cacheline")
+		{
+			if (!need(i, 1, "-cacheline")) return -1;   // (main3.cu: cache-line padding of the reference's CPU FMM; nothing to tune here)
+			++i;
 		}
 		else if (a == "-snapshot-order")
 		{
@@ -421,6 +433,33 @@ int main(int argc, const char **argv)
 	}
 
 	const SCAL par[6]{xi / (SCAL)nBodies, 0, 0, omega0.x * omega0.x, omega0.y * omega0.y, omega0.z * omega0.z};   // main3.cu:685-692
+
+	if (cpu)
+	{
+		// BASELINE config 1: the same loop and files with the host evaluator (coulombOscillatorDirect_cpu, main3.cu:53-57, :844)
+		if (test || test2 || b_accuracy) { std::cerr << "Error: '-cpu' runs the simulation only: -test, -test2 and -accuracy need the GPU\n"; return -1; }
+		if (input_order) { std::cerr << "Error: '-snapshot-order input' is what '-cpu' writes anyway (the direct sum never permutes the state)\n"; return -1; }
+		std::vector<nbco_cpu::V3> st(3 * (size_t)nBodies);
+		std::memcpy(st.data(), host.data(), state_bytes);
+		const nbco_cpu::Scheme sch = scheme == NBCO_INTEG_EULER ? nbco_cpu::Euler : scheme == NBCO_INTEG_FORESTRUTH ? nbco_cpu::ForestRuth
+		                             : scheme == NBCO_INTEG_PEFRL ? nbco_cpu::Pefrl : nbco_cpu::Leapfrog;
+		nbco_cpu::force(st.data(), nBodies, par, o.eps2);
+		for (int iter = 0; iter < nIters; ++iter)
+		{
+			nbco_cpu::integrate(sch, st.data(), nBodies, par, o.eps2, (long double)dt);
+			if (iter % nSteps != 0) continue;
+			std::cout << iter << ' ' << std::flush;
+			std::ofstream fout(strout + "/out" + std::to_string(iter) + '_' + std::to_string(dt) + ".bin", std::ios::out | std::ios::binary);
+			if (!fout)
+			{
+				std::cerr << "Error: cannot write on output location. Check that \"" << strout << "\" folder exists. Create it if not." << std::endl;
+				return -1;
+			}
+			fout.write(reinterpret_cast<const char *>(st.data()), (std::streamsize)state_bytes);
+		}
+		std::cout << std::endl;
+		return 0;
+	}
 
 	Session s(o, nBodies, host, par);
 	int rc = 0;

@@ -29,7 +29,8 @@ def test_help_and_argument_errors(nbco3):
     for args, msg in ((["-n"], "missing argument to '-n'"), (["-n", "0"], "invalid argument to '-n': 0"),
                       (["-ds", "-1"], "invalid argument to '-ds'"), (["-integ", "rk4"], "invalid argument to '-integ'"),
                       (["-eps", "1e-30"], "too small argument to '-eps'"), (["-bogus"], "unrecognised option '-bogus'"),
-                      (["-omega0", "1"], "missing argument(s) to '-omega0'"), (["-cpu"], "GPU only")):
+                      (["-omega0", "1"], "missing argument(s) to '-omega0'"), (["-cpu", "-test"], "need the GPU"),
+                      (["-cpu-threads", "0"], "invalid argument to '-cpu-threads'")):
         r = run(nbco3, *args)
         assert r.returncode != 0 and msg in r.stderr, (args, r.stderr)
 
@@ -171,3 +172,24 @@ def test_snapshots_in_input_order(nbco3, oracle32, tmp_path):
     assert (np.abs(st_in[0] - init[0]) / sig).max() < 0.25
     assert (np.abs(st_tree[0] - init[0]) / sig).max() > 1.0
     assert run(nbco3, "-snapshot-order", "sideways").returncode != 0
+
+
+def test_cpu_path_runs_config_one_without_a_gpu(nbco3, oracle32, tmp_path):
+    """`nbco3 -cpu` (BASELINE config 1: direct O(N^2), leapfrog, C++20 threads, no GPU involved): same files as the GPU run, and the
+    trajectory equals the oracle's direct3 leapfrog bit for bit (both sum in the reference's order, direct.cuh:192-226)"""
+    from oracle.pyoracle import KIND_DIRECT3, SCHEME_LEAPFROG
+    n, iters = 600, 5
+    out = tmp_path / "out"
+    out.mkdir()
+    r = run(nbco3, "-cpu", "-cpu-threads", "3", "-n", str(n), "-iters", str(iters), "-steps", str(iters), "-o", str(out))
+    assert r.returncode == 0, r.stderr
+    snap = np.fromfile(out / ("out%d_0.000500.bin" % iters), dtype=np.float32).reshape(2, n, 3)
+    buf = oracle32.init_reference(n)
+    par = oracle32.params(n)
+    oracle32.compute_force(KIND_DIRECT3, buf, par, threads=2)
+    for _ in range(iters + 1):                              # -iters n runs n + 1 iterations (main3.cu:357)
+        oracle32.integrate(SCHEME_LEAPFROG, KIND_DIRECT3, buf, par, float(np.float32(5e-4)), threads=2)
+    np.testing.assert_array_equal(snap, buf[:2])
+    # the other integrators run too
+    for integ in ("eu", "fr", "pefrl"):
+        assert run(nbco3, "-cpu", "-n", "64", "-iters", "1", "-steps", "1", "-integ", integ, "-o", str(out)).returncode == 0
