@@ -193,3 +193,42 @@ def test_cpu_path_runs_config_one_without_a_gpu(nbco3, oracle32, tmp_path):
     # the other integrators run too
     for integ in ("eu", "fr", "pefrl"):
         assert run(nbco3, "-cpu", "-n", "64", "-iters", "1", "-steps", "1", "-integ", integ, "-o", str(out)).returncode == 0
+
+
+def test_dist_host_argument_errors(nbco3):
+    tool = os.path.join(HOST, "nbco3_dist")
+    assert "Usage: nbco3_dist -gpus G" in run(tool, "-h").stdout
+    for args in (["-gpus", "3"], ["-gpus", "2", "-n", "4097"], ["-bogus"], ["-n"]):
+        assert run(tool, *args).returncode != 0, args
+
+
+@pytest.mark.gpu
+def test_dist_host_one_rank_over_rccl(nbco3, engine, oracle32, tmp_path):
+    """`nbco3_dist -gpus 1`: the C++ multi-GPU host (one process per GPU, RCCL all-gathers on a stream of their own, the
+    two-stage exchange of INTEGRATION.md section 4) with a world of one -- every collective and every nbco_dist_* stage runs.  Its
+    snapshot equals the single-GPU engine driven through the plain ABI (same tree order, same forces: the sharded evaluation
+    is the single-GPU one bit for bit with the one-directional near-field kernel)."""
+    import torch
+    from coulomb_oscillators_amd import EVAL_FMM_KDTREE, INTEG_LEAPFROG
+    tool = os.path.join(HOST, "nbco3_dist")
+    n, p, iters = 32768, 5, 3
+    out = tmp_path / "out"
+    out.mkdir()
+    r = run(tool, "-gpus", "1", "-n", str(n), "-p", str(p), "-iters", str(iters), "-steps", str(iters), "-o", str(out))
+    assert r.returncode == 0, r.stderr[-2000:]
+    snap = np.fromfile(out / ("out%d_0.000500.bin" % iters), dtype=np.float32).reshape(2, n, 3)
+    buf = oracle32.init_reference(n)
+    par = oracle32.params(n)
+    engine.set(fmm_order=p, unsort=0, tree_steps=1)
+    d = torch.from_numpy(buf.copy()).cuda()
+    prm = torch.from_numpy(par).cuda()
+    engine.compute_force(EVAL_FMM_KDTREE, d, n, prm)
+    for _ in range(iters + 1):
+        # the host composes K D F K from nbco_step calls (integrator.cuh:68-96); same arithmetic as the unfused ABI sequence
+        engine.step(d[1], d[2], 0.5 * float(np.float32(5e-4)), n)
+        engine.step(d[0], d[1], float(np.float32(5e-4)), n)
+        engine.compute_force(EVAL_FMM_KDTREE, d, n, prm)
+        engine.step(d[1], d[2], 0.5 * float(np.float32(5e-4)), n)
+    got = d.cpu().numpy()
+    np.testing.assert_array_equal(snap[0], got[0])
+    np.testing.assert_array_equal(snap[1], got[1])
