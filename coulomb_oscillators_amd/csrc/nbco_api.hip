@@ -375,6 +375,39 @@ int nbco_dist_local_mpole(nbco_ctx *c, float *buf_local, long long n_local, void
 	NBCO_TRY(kd_dist_local(c, buf_local, n_local, nullptr, nullptr, nullptr, mpole_send));
 	return maybe_sync(c);
 }
+int nbco_dist_let_local_geom(nbco_ctx *c, float *buf_local, long long n_local, void *csz_send)
+{
+	if (!c || !buf_local || !csz_send) return c ? c->fail(NBCO_ERR_ARG, "nbco_dist_let_local_geom: null pointer") : NBCO_ERR_ARG;
+	NBCO_TRY(kd_dist_local(c, buf_local, n_local, nullptr, nullptr, csz_send, nullptr, 1));
+	return maybe_sync(c);
+}
+int nbco_dist_let_local_mpole(nbco_ctx *c, float *buf_local, long long n_local)
+{
+	if (!c || !buf_local) return c ? c->fail(NBCO_ERR_ARG, "nbco_dist_let_local_mpole: null pointer") : NBCO_ERR_ARG;
+	return kd_dist_local(c, buf_local, n_local, nullptr, nullptr, nullptr, nullptr, 2);
+}
+int nbco_dist_let_select(nbco_ctx *c, const void *csz_all, long long *counts_send)
+{
+	if (!c || !csz_all || !counts_send) return c ? c->fail(NBCO_ERR_ARG, "nbco_dist_let_select: null pointer") : NBCO_ERR_ARG;
+	return kd_dist_let_select(c, csz_all, counts_send);
+}
+int nbco_dist_let_pack(nbco_ctx *c, const long long *counts_all, void *pos_send, void *mpole_send)
+{
+	if (!c || !counts_all) return c ? c->fail(NBCO_ERR_ARG, "nbco_dist_let_pack: null pointer") : NBCO_ERR_ARG;
+	return kd_dist_let_pack(c, counts_all, pos_send, mpole_send);
+}
+int nbco_dist_let_finish(nbco_ctx *c, const long long *counts_all, const void *pos_recv, const void *mpole_recv, float *buf_local, float *a_local,
+                         const float *param)
+{
+	if (!c || !counts_all || !buf_local || !a_local) return c ? c->fail(NBCO_ERR_ARG, "nbco_dist_let_finish: null pointer") : NBCO_ERR_ARG;
+	NBCO_TRY(kd_dist_let_finish(c, counts_all, pos_recv, mpole_recv, buf_local, a_local, param));
+	return maybe_sync(c);
+}
+int nbco_dist_let_check(nbco_ctx *c)
+{
+	if (!c) return NBCO_ERR_ARG;
+	return kd_dist_let_check(c);
+}
 int nbco_dist_finish_traverse(nbco_ctx *c, const void *csz_all, const void *pos_all)
 {
 	if (!c || !csz_all || !pos_all) return c ? c->fail(NBCO_ERR_ARG, "nbco_dist_finish_traverse: null pointer") : NBCO_ERR_ARG;

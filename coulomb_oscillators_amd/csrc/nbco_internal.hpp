@@ -175,6 +175,8 @@ struct nbco_ctx
 	DevBuf sel_hist, sel_nodes, sel_ties;   // selection build (k_kdselect.hip)
 	// multi-GPU kd-domain sharding: boxes / split axes of the global levels 0 .. d, the assembled global tree
 	DevBuf dist_top, dist_tree;
+	// LET exchange: need masks + per-receiver selections, arrival flags, the (sparse) global position array
+	DevBuf let_sel, let_have, dist_pos;
 	// octree-traceless evaluator (k_fmm_oct.hip)
 	DevBuf oct_tree, oct_groups;
 	OctTreeDev oct;
@@ -182,7 +184,7 @@ struct nbco_ctx
 	{
 		int world = 0, rank = 0, d = 0, L = 0;
 		long long n_global = 0, n_local = 0;
-		bool partitioned = false, build_done = false, local_done = false, rebuilt = false, traversed = false;
+		bool partitioned = false, build_done = false, local_done = false, rebuilt = false, traversed = false, let_selected = false, let_packed = false;
 		const void *pos_all = nullptr;   // gathered positions, between the two halves of the finish stage
 	} dist;
 	bool sel_three_pass = false;            // set after the first tie / bucket overflow: three radix passes per select
@@ -277,8 +279,12 @@ int oct_copy_out(nbco_ctx *c, int which, void *host_dst, long long host_bytes);
 // multi-GPU kd-domain sharding (k_fmm_kd.hip)
 int kd_dist_layout(nbco_ctx *c, long long n_global, int world, int rank, nbco_dist_layout *out);
 int kd_dist_partition(nbco_ctx *c, const float *state_all, long long n_global, int world, int rank, float *state_local);
+int kd_dist_let_select(nbco_ctx *c, const void *csz_all, long long *counts);
+int kd_dist_let_pack(nbco_ctx *c, const long long *counts_all, void *pos_send, void *mpole_send);
+int kd_dist_let_finish(nbco_ctx *c, const long long *counts_all, const void *pos_recv, const void *mpole_recv, float *buf_local, float *a_local, const float *param);
+int kd_dist_let_check(nbco_ctx *c);
 int kd_dist_local(nbco_ctx *c, float *buf_local, long long n_local, void *nodes_send, void *pos_send, void *csz_send = nullptr,
-                  void *mpole_send = nullptr);
+                  void *mpole_send = nullptr, int let_stage = 0);
 int kd_dist_finish(nbco_ctx *c, const void *nodes_all, const void *pos_all, float *buf_local, float *a_local, const float *param);
 int kd_dist_finish_traverse(nbco_ctx *c, const void *csz_all, const void *pos_all);
 int kd_dist_finish_rest(nbco_ctx *c, const void *mpole_all, float *buf_local, float *a_local, const float *param);

@@ -54,6 +54,17 @@ class TorchComm:
             return _Done()
         return self.dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True)
 
+    def all_to_all(self, out, inp, out_rows, in_rows):
+        """variable all-to-all along dim 0: in_rows[r] rows of `inp` go to rank r, out_rows[s] rows of `out` come from rank s"""
+        if self.world == 1:
+            out.copy_(inp)
+        elif self.dist.get_backend(self.group) == "gloo" and inp.is_cuda:
+            host = torch.empty(out.shape, dtype=out.dtype)
+            self.dist.all_to_all_single(host, inp.cpu(), list(out_rows), list(in_rows), group=self.group)
+            out.copy_(host)
+        else:
+            self.dist.all_to_all_single(out, inp, list(out_rows), list(in_rows), group=self.group)
+
     def all_reduce(self, t, op="sum"):
         """in-place reduction of a small tensor of scalars (energies, bounds)"""
         if self.world == 1:
@@ -79,6 +90,9 @@ class SingleComm:
         out.copy_(inp)
         return _Done()
 
+    def all_to_all(self, out, inp, out_rows, in_rows):
+        out.copy_(inp)
+
     def all_reduce(self, t, op="sum"):
         return t
 
@@ -90,7 +104,7 @@ class DomainRun:
     ctypes Engine, or a test double with the same methods for the CPU tests).
     """
 
-    def __init__(self, engine, n_global, comm, device=None, rebalance=8):
+    def __init__(self, engine, n_global, comm, device=None, rebalance=8, let=None):
         self.eng = engine
         self.comm = comm
         self.world, self.rank = comm.world, comm.rank
@@ -111,7 +125,27 @@ class DomainRun:
         self.csz_bytes = int(getattr(self.lay, "csz_bytes", 0))
         self.split = self.csz_bytes > 0 and all(hasattr(engine, m) for m in ("dist_local_geom", "dist_local_mpole", "dist_finish_traverse",
                                                                              "dist_finish_rest")) and hasattr(comm, "all_gather_start")
+        # locally-essential-tree exchange (nbco_dist_let_*): on by default when engine and transport offer it
+        can_let = self.split and all(hasattr(engine, m) for m in ("dist_let_select", "dist_let_pack", "dist_let_finish")) and hasattr(comm, "all_to_all") \
+            and int(getattr(self.lay, "let_counts", 0)) > 0
+        self.let = can_let if let is None else (bool(let) and can_let)
+        if self.let:
+            S = int(self.lay.let_counts)
+            self.counts_send = torch.zeros(S, dtype=torch.int64, device=self.device)
+            self.counts_all = torch.zeros(G * S, dtype=torch.int64, device=self.device)
+            self.rec = int(self.lay.let_node_bytes) // 4
+            self._scratch = {}
+        self.last_exchange_bytes = None
         self.evals = 0
+
+    def _rows(self, name, rows, width):
+        """(rows, width) float32 view of a grow-only scratch buffer"""
+        need = max(int(rows), 1) * width
+        t = self._scratch.get(name)
+        if t is None or t.numel() < need:
+            t = torch.empty(int(need * 1.25) + 1024, dtype=torch.float32, device=self.device)
+            self._scratch[name] = t
+        return t[: int(rows) * width].view(int(rows), width)
 
     # views of the local state
     @property
@@ -127,7 +161,13 @@ class DomainRun:
         return self.buf[6 * self.n_local:]
 
     def exchange_bytes(self):
-        """bytes this rank receives per force evaluation"""
+        """bytes this rank receives per force evaluation: of the last one with the LET exchange, else the all-gather's"""
+        if self.let and self.last_exchange_bytes is not None:
+            return self.last_exchange_bytes
+        return self.allgather_bytes()
+
+    def allgather_bytes(self):
+        """bytes received per evaluation when whole node and position blocks are all-gathered"""
         return (self.world - 1) * (int(self.lay.nodes_bytes) + int(self.lay.pos_bytes))
 
     # ---- rebalance: gather the full state, redo the top log2(G) median splits, keep the own domain ----
@@ -157,6 +197,12 @@ class DomainRun:
     def force(self, param=None, elastic=True):
         if self.rebalance > 0 and self.evals >= self.rebalance:
             self.partition()
+        if self.let:
+            self._force_let(param)
+            if elastic and param is not None:
+                self.eng.add_elastic(self.pos, self.acc, self.n_local, param[3:])
+            self.evals += 1
+            return
         if self.split:
             # Three all-gathers, each started as soon as its data exists: positions + traversal records after the subtree
             # build, multipoles after the upward pass.  The traversal (which needs no multipoles) is enqueued behind the
@@ -190,6 +236,44 @@ class DomainRun:
             self.local()
             self.exchange()
         self.finish(param, elastic)
+
+    # ---- LET exchange: one small all-gather (traversal records), the traversal, then two all-to-alls of exactly the
+    # multipoles and positions the other ranks' lists name (include/nbco.h, nbco_dist_let_*) --------------------------
+    def _let_counts(self, csz_all, gather):
+        """selection + gathered count matrix on the host, [sender][let_counts] (int64); repeats while a rank reports list overflow"""
+        G, S = self.world, int(self.lay.let_counts)
+        for _ in range(8):
+            self.eng.dist_let_select(csz_all, self.counts_send)
+            M = gather()
+            if not bool(M.view(G, S)[:, 2 * G].any()):
+                return M
+        raise RuntimeError("LET exchange: the traversal lists kept overflowing (raise list_factor)")
+
+    def _let_splits(self, M):
+        G, S, me = self.world, int(self.lay.let_counts), self.rank
+        M2 = M.view(G, S)
+        return (M2[me, 0:2 * G:2].tolist(), M2[me, 1:2 * G:2].tolist(), M2[:, 2 * me].tolist(), M2[:, 2 * me + 1].tolist())
+
+    def _force_let(self, param):
+        cb, G = self.csz_bytes, self.world
+        csz_send, csz_all = self.nodes_send[:cb], self.nodes_all[: G * cb]
+        self.eng.dist_let_local_geom(self.buf, self.n_local, csz_send)
+        h_csz = self.comm.all_gather_start(csz_all, csz_send)
+        self.eng.dist_let_local_mpole(self.buf, self.n_local)
+        h_csz.wait()
+
+        def gather():
+            self.comm.all_gather(self.counts_all, self.counts_send)
+            return self.counts_all.cpu()   # the one host synchronisation of the evaluation
+        M = self._let_counts(csz_all, gather)
+        send_n, send_p, recv_n, recv_p = self._let_splits(M)
+        pos_send, mp_send = self._rows("ps", sum(send_p), 4), self._rows("ms", sum(send_n), self.rec)
+        pos_recv, mp_recv = self._rows("pr", sum(recv_p), 4), self._rows("mr", sum(recv_n), self.rec)
+        self.eng.dist_let_pack(M, pos_send, mp_send)
+        self.comm.all_to_all(pos_recv, pos_send, recv_p, send_p)
+        self.comm.all_to_all(mp_recv, mp_send, recv_n, send_n)
+        self.eng.dist_let_finish(M, pos_recv, mp_recv, self.buf, self.acc, param)
+        self.last_exchange_bytes = (G - 1) * (cb + 8 * int(self.lay.let_counts)) + 16 * sum(recv_p) + 4 * self.rec * sum(recv_n)
 
     def _wait_far_field(self, handle):
         """Order the consumers of the gathered multipoles behind `handle`.  Only the engine's second stream reads them
@@ -251,6 +335,11 @@ class LoopbackWorld:
         def all_gather(self, out, inp):   # filled in by LoopbackWorld
             raise RuntimeError("loopback domains exchange through LoopbackWorld")
 
+        def all_gather_start(self, out, inp):
+            raise RuntimeError("loopback domains exchange through LoopbackWorld")
+
+        all_to_all = all_gather
+
     def __init__(self, engines, n_global, device=None, rebalance=0):
         G = len(engines)
         self.runs = [DomainRun(e, n_global, LoopbackWorld._Comm(G, r), device=device, rebalance=rebalance) for r, e in enumerate(engines)]
@@ -263,8 +352,52 @@ class LoopbackWorld:
             r.eng.dist_partition(r.state_all, r.n_global, r.world, r.rank, r.buf)
             r.evals = 0
 
-    def force(self, param=None, elastic=True, split=None):
-        """split=None: the two-stage exchange (records, then multipoles) when the engines offer it; False: one node block"""
+    def force_let(self, param=None, elastic=True, tamper=None):
+        """the LET exchange in lockstep; tamper(rank, pos_recv, mp_recv) may damage what a rank received (guard tests)"""
+        runs, G = self.runs, self.G
+        cb, S = runs[0].csz_bytes, int(runs[0].lay.let_counts)
+        for r in runs:
+            r.eng.dist_let_local_geom(r.buf, r.n_local, r.nodes_send[:cb])
+        csz = torch.cat([r.nodes_send[:cb] for r in runs])
+        for r in runs:
+            r.eng.dist_let_local_mpole(r.buf, r.n_local)
+            r.nodes_all[: G * cb].copy_(csz)
+        for _ in range(8):
+            for r in runs:
+                r.eng.dist_let_select(r.nodes_all[: G * cb], r.counts_send)
+            M = torch.cat([r.counts_send for r in runs]).cpu()
+            if not bool(M.view(G, S)[:, 2 * G].any()):
+                break
+        else:
+            raise RuntimeError("LET exchange: the traversal lists kept overflowing")
+        M2 = M.view(G, S)
+        sends = []
+        for r in runs:
+            send_n, send_p, _, _ = r._let_splits(M)
+            ps, ms = r._rows("ps", sum(send_p), 4), r._rows("ms", sum(send_n), r.rec)
+            r.eng.dist_let_pack(M, ps, ms)
+            sends.append((ps, ms, send_p, send_n))
+        for r in runs:
+            me = r.rank
+            pp, mm = [], []
+            for s_, (ps, ms, send_p, send_n) in enumerate(sends):
+                op, on = sum(send_p[:me]), sum(send_n[:me])
+                pp.append(ps[op: op + send_p[me]])
+                mm.append(ms[on: on + send_n[me]])
+            pos_recv, mp_recv = torch.cat(pp).contiguous(), torch.cat(mm).contiguous()
+            if tamper is not None:
+                tamper(me, pos_recv, mp_recv)
+            r.eng.dist_let_finish(M, pos_recv, mp_recv, r.buf, r.acc, param)
+            r.last_exchange_bytes = (G - 1) * (cb + 8 * S) + 16 * int(M2[:, 2 * me + 1].sum()) + 4 * r.rec * int(M2[:, 2 * me].sum())
+            if elastic and param is not None:
+                r.eng.add_elastic(r.pos, r.acc, r.n_local, param[3:])
+            r.evals += 1
+
+    def force(self, param=None, elastic=True, split=None, let=False):
+        """split=None: the two-stage exchange (records, then multipoles) when the engines offer it; False: one node block;
+        let=True: the LET exchange"""
+        if let:
+            return self.force_let(param, elastic)
         runs = self.runs
         if split is None:
             split = all(hasattr(r.eng, "dist_finish_traverse") and r.csz_bytes > 0 for r in runs)

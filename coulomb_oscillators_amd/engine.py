@@ -53,7 +53,7 @@ class DistLayout(C.Structure):
     _fields_ = [("world", C.c_int), ("rank", C.c_int), ("d", C.c_int), ("L", C.c_int), ("L_local", C.c_int),
                 ("ntot_local", C.c_int), ("order", C.c_int), ("n_global", C.c_longlong), ("n_local", C.c_longlong),
                 ("nodes_bytes", C.c_longlong), ("pos_bytes", C.c_longlong), ("csz_bytes", C.c_longlong),
-                ("mpole_bytes", C.c_longlong)]
+                ("mpole_bytes", C.c_longlong), ("let_node_bytes", C.c_longlong), ("let_counts", C.c_int)]
 
 
 def lib_path():
@@ -122,6 +122,12 @@ def _load():
         "nbco_dist_local_mpole": [P, P, LL, P],
         "nbco_dist_finish_traverse": [P, P, P],
         "nbco_dist_finish_rest": [P, P, P, P, P],
+        "nbco_dist_let_local_geom": [P, P, LL, P],
+        "nbco_dist_let_local_mpole": [P, P, LL],
+        "nbco_dist_let_select": [P, P, P],
+        "nbco_dist_let_pack": [P, P, P, P],
+        "nbco_dist_let_finish": [P, P, P, P, P, P, P],
+        "nbco_dist_let_check": [P],
         "nbco_aux_stream": [P, C.POINTER(C.c_void_p)],
         "nbco_debug_violations": [P, C.POINTER(LL)],
         "nbco_profile_enable": [P, I],
@@ -301,6 +307,26 @@ class Engine:
 
     def dist_finish_rest(self, mpole_all, buf_local, a_local, param=None):
         self._chk(self.lib.nbco_dist_finish_rest(self.ctx, _ptr(mpole_all), _ptr(buf_local), _ptr(a_local), _ptr(param)))
+
+    # the same evaluation with the LET exchange (include/nbco.h: nbco_dist_let_*)
+    def dist_let_local_geom(self, buf_local, n_local, csz_send):
+        self._chk(self.lib.nbco_dist_let_local_geom(self.ctx, _ptr(buf_local), n_local, _ptr(csz_send)))
+
+    def dist_let_local_mpole(self, buf_local, n_local):
+        self._chk(self.lib.nbco_dist_let_local_mpole(self.ctx, _ptr(buf_local), n_local))
+
+    def dist_let_select(self, csz_all, counts_send):
+        self._chk(self.lib.nbco_dist_let_select(self.ctx, _ptr(csz_all), _ptr(counts_send)))
+
+    def dist_let_pack(self, counts_all_host, pos_send, mpole_send):
+        self._chk(self.lib.nbco_dist_let_pack(self.ctx, _ptr(counts_all_host), _ptr(pos_send), _ptr(mpole_send)))
+
+    def dist_let_finish(self, counts_all_host, pos_recv, mpole_recv, buf_local, a_local, param=None):
+        self._chk(self.lib.nbco_dist_let_finish(self.ctx, _ptr(counts_all_host), _ptr(pos_recv), _ptr(mpole_recv), _ptr(buf_local), _ptr(a_local),
+                                                _ptr(param)))
+
+    def dist_let_check(self):
+        self._chk(self.lib.nbco_dist_let_check(self.ctx))
 
     def aux_stream(self):
         """raw hipStream_t of the context's second stream (see nbco_aux_stream)"""

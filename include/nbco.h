@@ -231,6 +231,8 @@ typedef struct nbco_dist_layout {
 	long long pos_bytes;   /* per-rank position block: float4[n_local], tree order */
 	long long csz_bytes;   /* the two parts of the node block on their own: traversal records (centre + squared box */
 	long long mpole_bytes; /* diagonal) of the subtree's nodes, and their multipoles; csz_bytes + mpole_bytes = nodes_bytes */
+	long long let_node_bytes; /* LET exchange: bytes of one node record {node id, multipole}, padded to 16 */
+	int let_counts;           /* LET exchange: 64-bit values in one rank's count block (2 world + 2) */
 } nbco_dist_layout;
 int nbco_dist_layout_query(nbco_ctx *c, long long n_global, int world, int rank, nbco_dist_layout *out);
 int nbco_dist_partition(nbco_ctx *c, const float *state_all, long long n_global, int world, int rank, float *state_local);
@@ -253,6 +255,32 @@ int nbco_dist_local_geom(nbco_ctx *c, float *buf_local, long long n_local, void 
 int nbco_dist_local_mpole(nbco_ctx *c, float *buf_local, long long n_local, void *mpole_send);
 int nbco_dist_finish_traverse(nbco_ctx *c, const void *csz_all, const void *pos_all);
 int nbco_dist_finish_rest(nbco_ctx *c, const void *mpole_all, float *buf_local, float *a_local, const float *param);
+/* ---- the same evaluation with a locally-essential-tree (LET) exchange: a rank receives only the multipoles and positions
+ *      its own interaction lists name, instead of every domain's whole block (north_star) ----
+ * The dual traversal is symmetric and every rank runs it over the same global geometry, so the pairs a rank emits are also the
+ * list of what the other ranks read of it: nothing is estimated.  Per evaluation:
+ *   _let_local_geom   subtree build; fills csz_send (csz_bytes)                                  -> all-gather (16 B per node)
+ *   _let_local_mpole  upward pass on the second stream (the multipoles stay on the device)
+ *   _let_select       csz_all = world x csz_bytes: global geometry, traversal, selection; writes this rank's count block to
+ *                     counts_send (DEVICE, let_counts 64-bit values: [2 r] node records / [2 r + 1] position records it
+ *                     will send to rank r, [2 world] = 1 when its traversal ran out of list room)  -> all-gather, copy to host
+ *                     If any rank's block reports overflow, every rank calls _let_select again (it repeats the traversal
+ *                     with more room where needed, is a no-op elsewhere) and the blocks are gathered again.
+ *   _let_pack         counts_all = the gathered blocks on the HOST, [sender][let_counts]; fills pos_send (16 B records
+ *                     {x, y, z, global particle index}) and mpole_send (let_node_bytes records {global node id, multipole}),
+ *                     segments in receiver order                                                  -> two all-to-alls with
+ *                     the splits counts_all[me][2 r + 1] / counts_all[me][2 r]
+ *   _let_finish       pos_recv / mpole_recv = the received records in sender order; lists, near and far field, L2P ->
+ *                     a_local, buf_local as nbco_dist_finish.  A guard checks every source of the sorted M2L and P2P lists
+ *                     against what arrived; a miss is reported by the next _let_pack and by _let_check (which synchronises).
+ * Accelerations are bit-identical to nbco_dist_finish and to the single-GPU nbco_fmm_kdtree. */
+int nbco_dist_let_local_geom(nbco_ctx *c, float *buf_local, long long n_local, void *csz_send);
+int nbco_dist_let_local_mpole(nbco_ctx *c, float *buf_local, long long n_local);
+int nbco_dist_let_select(nbco_ctx *c, const void *csz_all, long long *counts_send);
+int nbco_dist_let_pack(nbco_ctx *c, const long long *counts_all, void *pos_send, void *mpole_send);
+int nbco_dist_let_finish(nbco_ctx *c, const long long *counts_all, const void *pos_recv, const void *mpole_recv, float *buf_local,
+                         float *a_local, const float *param);
+int nbco_dist_let_check(nbco_ctx *c);
 /* The context's second stream (hipStream_t), on which the far-field chain runs and which alone reads mpole_all in
  * nbco_dist_finish_rest: a caller whose collective runs on its own stream can make THIS stream wait for the multipole
  * all-gather (hipStreamWaitEvent before calling _finish_rest) instead of the compute stream, so that the near-field

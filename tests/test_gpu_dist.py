@@ -165,6 +165,87 @@ def test_sharded_equals_single_gpu(oracle32, n, G, p, kind, mutual):
     assert all(r.eng.kd_info().L == i1.L for r in world.runs)
 
 
+@pytest.mark.parametrize("n,G,p,kind", [(32768, 2, 6, "reference"), (32768, 4, 4, "reference"), (32768, 8, 6, "clumps"), (40000, 8, 5, "uniform"),
+                                        (24576, 2, 3, "clumps"), (1 << 20, 4, 6, "reference"), (1 << 20, 8, 6, "reference"), (32768, 4, 10, "uniform")])
+@pytest.mark.parametrize("mutual", MUTUAL)
+def test_let_exchange_equals_single_gpu(oracle32, n, G, p, kind, mutual):
+    """the locally-essential-tree exchange (nbco_dist_let_*): every rank receives only the sources its lists name, the result is
+    the single-GPU one bit for bit, the guard is silent, and fewer bytes travel than with the all-gather"""
+    import torch
+    pos, vel = make_state(oracle32, n, kind)
+    par = torch.from_numpy(oracle32.params(n)).cuda()
+    opts = dict(fmm_order=p, unsort=0, tree_steps=1, p2p_mutual=mutual)
+    e1, ref = single_gpu(n, pos, vel, par, **opts)
+    world = loopback(n, G, pos, vel, **opts)
+    for _ in range(2):   # the second evaluation runs over buffers the first one has used
+        world.force(par, elastic=False, let=True)
+    for r in world.runs:
+        r.eng.dist_let_check()
+    got_acc = torch.cat([r.acc for r in world.runs])
+    assert torch.equal(torch.cat([r.pos for r in world.runs]), ref[:3 * n])
+    assert torch.equal(torch.cat([r.vel for r in world.runs]), ref[3 * n:6 * n])
+    assert same_acc(got_acc, ref[6 * n:], mutual, n), "accelerations differ from the single-GPU evaluation"
+    for r in world.runs:
+        assert r.exchange_bytes() < r.allgather_bytes()
+    if n == 1 << 20 and G == 8:
+        ratio = sum(r.allgather_bytes() for r in world.runs) / sum(r.exchange_bytes() for r in world.runs)
+        print(f"LET exchange at 8 x 128k: {ratio:.1f}x fewer bytes than the all-gather")
+        assert ratio > 2
+    # the energy pass reads the same sources through the same lists
+    e_ref = e1.energy_fmm(ref, n, par)
+    e_let = np.sum([r.eng.energy_fmm(r.buf, r.n_local, par) for r in world.runs], axis=0)
+    np.testing.assert_allclose(e_let, e_ref, rtol=1e-9)
+
+
+def test_let_guard_reports_a_source_that_did_not_arrive(oracle32):
+    """a node record or a leaf's positions lost on the way (here: overwritten by a duplicate of another record) is in some
+    interaction list of the receiver: the guard names it, nbco_dist_let_check fails"""
+    import torch
+    from coulomb_oscillators_amd import EngineError
+    n, G, p = 32768, 4, 5
+    pos, vel = make_state(oracle32, n, "reference")
+    par = torch.from_numpy(oracle32.params(n)).cuda()
+
+    def lose_node(rank, pos_recv, mp_recv):
+        if rank == 1:
+            mp_recv[3].copy_(mp_recv[4])
+
+    def lose_leaf(rank, pos_recv, mp_recv):
+        if rank == 2:
+            L = world.runs[0].lay.L
+            leaf = (pos_recv.view(torch.int32)[:, 3].long() << L) // n   # leaf of a global particle index (evalBox's ranges)
+            gone = leaf == leaf[0]
+            pos_recv[gone] = pos_recv[~gone][0]
+
+    for tamper, what in ((lose_node, "multipole of node"), (lose_leaf, "leaf")):
+        world = loopback(n, G, pos, vel, fmm_order=p, unsort=0, tree_steps=1)
+        world.force_let(par, elastic=False, tamper=tamper)
+        bad = 0
+        for r in world.runs:
+            try:
+                r.eng.dist_let_check()
+            except EngineError as e:
+                assert what in str(e)
+                bad += 1
+        assert bad == 1
+
+
+@pytest.mark.parametrize("mutual", MUTUAL)
+def test_let_lists_grow_on_demand(oracle32, mutual):
+    """list overflow in one rank's traversal is reported through the count exchange and repaired by a second selection round"""
+    import torch
+    n, G, p = 65536, 2, 6
+    pos, vel = make_state(oracle32, n, "reference")
+    par = torch.from_numpy(oracle32.params(n)).cuda()
+    e1, ref = single_gpu(n, pos, vel, par, fmm_order=p, unsort=0, tree_steps=1, p2p_mutual=mutual)
+    w = loopback(n, G, pos, vel, fmm_order=p, unsort=0, tree_steps=1, list_factor=1, list_grow=1, p2p_mutual=mutual)
+    w.force(par, elastic=False, let=True)
+    for r in w.runs:
+        r.eng.dist_let_check()
+    assert torch.equal(torch.cat([torch.cat([r.pos for r in w.runs]), torch.cat([r.vel for r in w.runs])]), ref[:6 * n])
+    assert same_acc(torch.cat([r.acc for r in w.runs]), ref[6 * n:], mutual, n)
+
+
 def test_sharded_matches_oracle(oracle32):
     """end to end against the CPU oracle (1e-5 relative, the bar of the single-GPU path)"""
     import torch
@@ -188,7 +269,8 @@ def test_sharded_matches_oracle(oracle32):
     assert force_err(acc, want) < 1e-5
 
 
-def test_sharded_leapfrog_with_tree_reuse(oracle32):
+@pytest.mark.parametrize("let", [False, True])
+def test_sharded_leapfrog_with_tree_reuse(oracle32, let):
     """several leapfrog steps with opts.tree_steps = rebalance = 3: trajectories stay identical to the single GPU"""
     import torch
     from coulomb_oscillators_amd import Engine
@@ -216,7 +298,7 @@ def test_sharded_leapfrog_with_tree_reuse(oracle32):
     def fG(k):
         if k > 0 and k % 3 == 0:
             world.partition([r.pos for r in world.runs], [r.vel for r in world.runs])
-        world.force(par, elastic=True)
+        world.force(par, elastic=True, let=let)
     fG(0)
     for s in range(steps):
         for r in world.runs:
