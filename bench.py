@@ -43,6 +43,8 @@ def parse(argv=None):
     ap.add_argument("--tree-steps", type=int, default=1)
     ap.add_argument("--rebalance", type=int, default=16,
                     help="multi-GPU: force evaluations between two re-partitions of the kd-domains (top log2(G) splits)")
+    ap.add_argument("--no-let", action="store_true",
+                    help="multi-GPU: all-gather whole node and position blocks instead of the locally-essential-tree exchange")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL (one rank per GPU); gloo = rehearsal with several ranks sharing one card")
     ap.add_argument("--workload", default="fmm_kd", choices=["fmm_kd", "fmm_oct", "direct"],
@@ -314,9 +316,25 @@ def main():
                                dens_inhom=args.dens_inhom), **extra_opts})
         run = None
         if sharded:
-            run = DomainRun(eng, n_sys, TorchComm(), rebalance=args.rebalance)
+            run = DomainRun(eng, n_sys, TorchComm(), rebalance=args.rebalance, let=not args.no_let)
             run.partition(d[0].reshape(-1), d[1].reshape(-1))
-            run.force(prm)                          # precompute accelerations (main3.cu:836-839)
+            # precompute accelerations (main3.cu:836-839).  The LET exchange is the one stage no single-card rehearsal can run over
+            # RCCL: should it fail on every rank alike, agree on that and carry on with the all-gather exchange (said in `exchange`)
+            ok = 1
+            try:
+                run.force(prm)
+                if run.let:
+                    eng.dist_let_check()
+            except Exception as e:   # noqa: BLE001
+                if not run.let:
+                    raise
+                print("rank %d: LET exchange failed (%s)" % (rank, e), file=sys.stderr)
+                ok = 0
+            if run.let and reduce(float(ok), dist.ReduceOp.MIN) < 1:
+                run.let = False
+                run.last_exchange_bytes = None
+                run.partition(d[0].reshape(-1), d[1].reshape(-1))
+                run.force(prm)
             step = lambda: run.leapfrog(prm, args.dt)
         else:
             eng.compute_force(kind, d, n_local, prm)
@@ -349,7 +367,9 @@ def main():
             extra["engine_opt"] = args.engine_opt
         if sharded:
             extra.update({"n_system": n_sys, "rebalance_every": args.rebalance,
-                          "allgather_bytes_per_eval_per_gpu": run.exchange_bytes(), "backend": args.backend})
+                          "exchange": "LET (all-gather of traversal records + variable all-to-all)" if run.let else "all-gather",
+                          "exchange_bytes_per_eval_per_gpu": run.exchange_bytes(),
+                          "allgather_bytes_per_eval_per_gpu": run.allgather_bytes(), "backend": args.backend})
     elif args.workload == "fmm_oct":
         info = eng.oct_info()
         pairs_per_eval = 0    # the octree path keeps no pair counter: no roofline entry for this workload
@@ -411,7 +431,7 @@ def main():
         e_s, eng_s, run_s, _, _, nsys_s = timed_run(n // world, args.steps, args.warmup, False)
         strong = {"scaling": "strong", "n_system": nsys_s, "n_per_gpu": n // world, "ms_per_step": 1e3 * e_s / args.steps,
                   "value": nsys_s * args.steps / e_s, "unit": "particle-steps/s",
-                  "allgather_bytes_per_eval_per_gpu": run_s.exchange_bytes()}
+                  "exchange_bytes_per_eval_per_gpu": run_s.exchange_bytes(), "allgather_bytes_per_eval_per_gpu": run_s.allgather_bytes()}
         eng_s.close()
 
     value = world * n * args.steps / elapsed
@@ -444,7 +464,7 @@ def main():
         "strong": strong,
         "config": {"workload": wl, "n_per_gpu": n, "order": args.order, "dt": args.dt,
                    "init": "reference stream mt19937_64(%d + rank), discard %d (main3.cu:662-664)" % (REF_SEED, REF_DISCARD),
-                   "parallelism": ("kd-domain sharding x%d, one all-gather of nodes + positions per evaluation" % world) if sharded
+                   "parallelism": ("kd-domain sharding x%d, %s per evaluation" % (world, "LET exchange (all-gather of traversal records, all-to-all of the listed multipoles + positions)" if run.let else "one all-gather of nodes + positions")) if sharded
                    else ("single GPU" if world == 1 else "independent replicas x%d" % world), **extra},
     }
     if rank == 0:

@@ -150,6 +150,87 @@ class NumpySplitEngine(NumpyDomainEngine):
         self.calls.pop()   # (the "finish" recorded by the base class)
 
 
+class NumpyLetEngine(NumpySplitEngine):
+    """the LET protocol of include/nbco.h (nbco_dist_let_*): counts through an all-gather, then two all-to-alls with splits that
+    differ per receiver.  The double has no tree to prune with, so it sends every particle exactly once -- the first k_r of them
+    to receiver r as position records {x, y, z, global index}, the others as "node" records {global index, x, y, z} -- and the
+    receiver checks that both streams together cover every foreign particle exactly once.  Rank 1 reports list overflow in the
+    first round of its first evaluation, which must trigger a second selection round on every rank."""
+
+    def dist_layout(self, n_global, world, rank):
+        lay = super().dist_layout(n_global, world, rank)
+        lay.let_node_bytes, lay.let_counts = 16, 2 * world + 2
+        self.rounds = 0
+        return lay
+
+    def _k(self, r):
+        return (self.lay.n_local * (r + 1)) // (self.lay.world + 1)
+
+    def dist_let_local_geom(self, buf, n_local, csz_send):
+        self.calls.append("geom")
+        csz_send.numpy().view(np.float32)[:] = (self.lay.rank, n_local, 0, 0)
+        self._own = buf.numpy()[:3 * n_local].reshape(n_local, 3).copy()
+
+    def dist_let_local_mpole(self, buf, n_local):
+        self.calls.append("mpole")
+
+    def dist_let_select(self, csz_all, counts_send):
+        self.calls.append("select")
+        G, nl, me = self.lay.world, self.lay.n_local, self.lay.rank
+        hdr = csz_all.numpy().view(np.float32).reshape(G, 4)
+        for r in range(G):
+            assert hdr[r, 0] == r and hdr[r, 1] == nl
+        c = counts_send.numpy()
+        c[:] = 0
+        for r in range(G):
+            if r != me:
+                c[2 * r], c[2 * r + 1] = nl - self._k(r), self._k(r)
+        self.rounds += 1
+        c[2 * G] = 1 if (me == 1 and self.rounds == 1) else 0
+
+    def dist_let_pack(self, M, pos_send, mp_send):
+        self.calls.append("pack")
+        G, nl, me = self.lay.world, self.lay.n_local, self.lay.rank
+        M = M.numpy().reshape(G, 2 * G + 2)
+        assert not M[:, 2 * G].any()
+        idx = (me * nl + np.arange(nl)).astype(np.int32).view(np.float32)
+        ps, ms = pos_send.numpy(), mp_send.numpy()
+        op = on = 0
+        for r in range(G):
+            if r == me:
+                continue
+            k = self._k(r)
+            assert (M[me, 2 * r], M[me, 2 * r + 1]) == (nl - k, k)
+            ps[op:op + k, :3], ps[op:op + k, 3] = self._own[:k], idx[:k]
+            ms[on:on + nl - k, 0], ms[on:on + nl - k, 1:] = idx[k:], self._own[k:]
+            op, on = op + k, on + nl - k
+        assert (op, on) == (ps.shape[0], ms.shape[0])
+
+    def dist_let_finish(self, M, pos_recv, mp_recv, buf, a_local, param=None):
+        self.calls.append("finish")
+        G, nl, me = self.lay.world, self.lay.n_local, self.lay.rank
+        M = M.numpy().reshape(G, 2 * G + 2)
+        pr, mr = pos_recv.numpy(), mp_recv.numpy()
+        assert pr.shape[0] == M[:, 2 * me + 1].sum() and mr.shape[0] == M[:, 2 * me].sum()
+        src = np.full((G * nl, 3), np.nan, dtype=np.float32)
+        src[me * nl:(me + 1) * nl] = self._own
+        seen = np.zeros(G * nl, dtype=int)
+        seen[me * nl:(me + 1) * nl] = 1
+        for ids, xyz in ((pr[:, 3].copy().view(np.int32), pr[:, :3]), (mr[:, 0].copy().view(np.int32), mr[:, 1:])):
+            np.add.at(seen, ids, 1)
+            src[ids] = xyz
+        assert (seen == 1).all()
+        # records from rank s occupy the s-th segment
+        seg = np.concatenate([np.full(M[s_, 2 * me + 1], s_) for s_ in range(G)]) if pr.shape[0] else np.zeros(0, dtype=int)
+        np.testing.assert_array_equal(pr[:, 3].copy().view(np.int32) // nl, seg)
+        own = buf.numpy()[:3 * nl].reshape(nl, 3)
+        dx = own.astype(np.float64)[:, None, :] - src.astype(np.float64)[None, :, :]
+        r2 = (dx * dx).sum(-1) + self.eps2
+        acc = (dx / r2[..., None] ** 1.5).sum(1)
+        scale = float(param[0]) if param is not None else 1.0
+        a_local.numpy()[:] = (acc * scale).astype(np.float32).reshape(-1)
+
+
 def _system(n, seed=11):
     rng = np.random.default_rng(seed)
     pos = rng.standard_normal((n, 3)).astype(np.float32)
@@ -165,7 +246,7 @@ def _drive(run, par, steps, dt):
     return torch.cat([run.pos.view(-1, 3), run.vel.view(-1, 3), run.acc.view(-1, 3)], dim=1).numpy()
 
 
-def _worker(rank, world, port, n, steps, dt, rebalance, outdir, split=False):
+def _worker(rank, world, port, n, steps, dt, rebalance, outdir, split=False, let=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -173,9 +254,11 @@ def _worker(rank, world, port, n, steps, dt, rebalance, outdir, split=False):
     try:
         pos, vel, par = _system(n)
         nl = n // world
-        eng = NumpySplitEngine() if split else NumpyDomainEngine()
+        eng = NumpyLetEngine() if let else (NumpySplitEngine() if split else NumpyDomainEngine())
         run = DomainRun(eng, n, TorchComm(), device=torch.device("cpu"), rebalance=rebalance)
-        assert (run.world, run.rank, run.n_local) == (world, rank, nl) and run.split == split
+        assert (run.world, run.rank, run.n_local) == (world, rank, nl) and run.split == split and run.let == let
+        if let:
+            assert run.exchange_bytes() == run.allgather_bytes()   # (nothing evaluated yet)
         run.partition(torch.from_numpy(pos[rank * nl:(rank + 1) * nl]).reshape(-1), torch.from_numpy(vel[rank * nl:(rank + 1) * nl]).reshape(-1))
         res = _drive(run, torch.from_numpy(par), steps, dt)
         np.save(os.path.join(outdir, "rank%d.npy" % rank), res)
@@ -198,8 +281,8 @@ def _free_port():
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world,split", [(2, False), (4, False), (2, True), (4, True)])
-def test_domain_run_over_gloo_matches_single_process(world, split):
+@pytest.mark.parametrize("world,split,let", [(2, False, False), (4, False, False), (2, True, False), (4, True, False), (2, True, True), (4, True, True)])
+def test_domain_run_over_gloo_matches_single_process(world, split, let):
     import torch.multiprocessing as mp
     n, steps, dt, rebalance = 512, 5, 1e-2, 2
     pos, vel, par = _system(n)
@@ -207,7 +290,7 @@ def test_domain_run_over_gloo_matches_single_process(world, split):
     one.partition(torch.from_numpy(pos).reshape(-1), torch.from_numpy(vel).reshape(-1))
     ref = _drive(one, torch.from_numpy(par), steps, dt)
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, _free_port(), n, steps, dt, rebalance, d, split), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), n, steps, dt, rebalance, d, split, let), nprocs=world, join=True)
         got = np.concatenate([np.load(os.path.join(d, "rank%d.npy" % r)) for r in range(world)])
         calls = [open(os.path.join(d, "calls%d.txt" % r)).read().split() for r in range(world)]
         scal = [np.load(os.path.join(d, "scal%d.npy" % r)) for r in range(world)]
@@ -227,7 +310,11 @@ def test_domain_run_over_gloo_matches_single_process(world, split):
         if ev >= rebalance:
             want.append("partition")
             ev = 0
-        want += ["geom", "mpole", "traverse", "rest"] if split else ["local", "finish"]
+        if let:
+            # (every rank repeats the selection in the round in which rank 1 reported overflow: its first evaluation)
+            want += ["geom", "mpole", "select"] + (["select"] if len(want) == 1 else []) + ["pack", "finish"]
+        else:
+            want += ["geom", "mpole", "traverse", "rest"] if split else ["local", "finish"]
         ev += 1
     assert all(c == want for c in calls), calls
 
