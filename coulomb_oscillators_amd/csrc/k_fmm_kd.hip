@@ -910,11 +910,11 @@ __device__ inline long long region_slot(const int *__restrict__ pref, long long 
 	return (long long)r * capR + (i - pref[r]);
 }
 
-__global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab_arg, const int2 *__restrict__ fin, int2 *__restrict__ fout,
-                                                          int2 *__restrict__ p2p, int2 *__restrict__ m2l, int2 *__restrict__ p2p_rank,
-                                                          int2 *__restrict__ m2l_rank, int *__restrict__ counters,
-                                                          int *__restrict__ tctr, int it, long long capR, float par, int m2l_first,
-                                                          unsigned *__restrict__ cnt_p2p, unsigned *__restrict__ cnt_m2l, const Dom dm)
+__device__ inline void traverse_body(const TreeView &t, const AdmTab &tab_arg, const int2 *fin, int2 *fout,
+                                     int2 *__restrict__ p2p, int2 *__restrict__ m2l, int2 *__restrict__ p2p_rank,
+                                     int2 *__restrict__ m2l_rank, int *__restrict__ counters,
+                                     int *tctr, int it, long long capR, float par, int m2l_first,
+                                     unsigned *__restrict__ cnt_p2p, unsigned *__restrict__ cnt_m2l, const Dom dm)
 {
 	__shared__ uint64_t sh_wave[4];
 	__shared__ int sh_base[3];
@@ -1020,6 +1020,33 @@ __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab
 			if (nch > 2) emit(k3, ch.c, r3);
 		}
 		__syncthreads();
+	}
+}
+
+__global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab_arg, const int2 *fin, int2 *fout, int2 *__restrict__ p2p, int2 *__restrict__ m2l,
+                                                          int2 *__restrict__ p2p_rank, int2 *__restrict__ m2l_rank, int *__restrict__ counters, int *tctr, int it,
+                                                          long long capR, float par, int m2l_first, unsigned *__restrict__ cnt_p2p,
+                                                          unsigned *__restrict__ cnt_m2l, const Dom dm)
+{
+	traverse_body(t, tab_arg, fin, fout, p2p, m2l, p2p_rank, m2l_rank, counters, tctr, it, capR, par, m2l_first, cnt_p2p, cnt_m2l, dm);
+}
+// The first launches of a traversal see a frontier of 1, 3, .. a few hundred pairs: each is one dependent round trip through
+// the tree arrays wrapped in a launch (10.7 us apiece at N = 1M, 16 of them in a row).  ONE workgroup runs launches
+// [it0, it1) back to back instead -- same body, same region bookkeeping, the frontier ping-pongs between fa and fb as it does
+// between launches; what one iteration wrote is made visible to the next by a device-scope fence on either side of the
+// barrier (stores are written through to L2, the fence after the barrier invalidates the CU's L1).
+__global__ __launch_bounds__(kBlock) void traverse_head_kernel(TreeView t, AdmTab tab_arg, int2 *fa, int2 *fb, int2 *__restrict__ p2p, int2 *__restrict__ m2l,
+                                                               int2 *__restrict__ p2p_rank, int2 *__restrict__ m2l_rank, int *__restrict__ counters, int *tctr, int it0,
+                                                               int it1, long long capR, float par, int m2l_first, unsigned *__restrict__ cnt_p2p,
+                                                               unsigned *__restrict__ cnt_m2l, const Dom dm)
+{
+	for (int it = it0; it < it1; ++it)
+	{
+		traverse_body(t, tab_arg, fa, fb, p2p, m2l, p2p_rank, m2l_rank, counters, tctr, it, capR, par, m2l_first, cnt_p2p, cnt_m2l, dm);
+		__threadfence();
+		__syncthreads();
+		__threadfence();
+		int2 *x = fa; fa = fb; fb = x;
 	}
 }
 
@@ -1732,7 +1759,16 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		                   c->list_cnt.as<unsigned>(), (long long)(2 * (np_ + nm_)), (long long)self0, (long long)(c->o.coll ? nself : 0));
 		// (counters[110] is the selection-build flag)
 		const int iters = L + NBCO_TRAV_EXTRA;   // every launch performs two traversal steps; traverse_finish_kernel checks that none is left
-		for (int it = 0; it < iters; ++it)
+		// the first launches (frontiers of up to a few hundred pairs) inside one workgroup
+		const int head = std::min(iters, c->trav_head);
+		if (head > 1)
+		{
+			hipLaunchKernelGGL(traverse_head_kernel, dim3(1), dim3(kBlock), 0, st, tv, tab, fa, fb, c->p2p_list.as<int2>(), c->m2l_list.as<int2>(),
+			                   c->p2p_list.as<int2>() + cap, c->m2l_list.as<int2>() + cap, ctr, tctr, 0, head, capR, c->o.tree_radius, c->o.m2l_first, cnt_p2p,
+			                   cnt_m2l, dm);
+			if (head & 1) std::swap(fa, fb);
+		}
+		for (int it = head > 1 ? head : 0; it < iters; ++it)
 		{
 			hipLaunchKernelGGL(traverse_kernel, dim3(1024), dim3(kBlock), 0, st, tv, tab, (const int2 *)fa, fb, c->p2p_list.as<int2>(),
 			                   c->m2l_list.as<int2>(), c->p2p_list.as<int2>() + cap, c->m2l_list.as<int2>() + cap, ctr, tctr, it, capR,

@@ -177,6 +177,7 @@ int nbco_create(nbco_ctx **out, const nbco_opts *o)
 	if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
 	c->stream = (hipStream_t)c->o.stream;
 	c->poison = getenv("NBCO_POISON") && atoi(getenv("NBCO_POISON")) != 0;
+	if (getenv("NBCO_TRAV_HEAD")) c->trav_head = std::max(0, atoi(getenv("NBCO_TRAV_HEAD")));
 	if (hipMalloc(&c->small.ptr, 4096) != hipSuccess) { delete c; return NBCO_ERR_HIP; }
 	c->small.bytes = 4096;
 	*out = c;

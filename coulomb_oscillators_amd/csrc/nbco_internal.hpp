@@ -196,6 +196,7 @@ struct nbco_ctx
 		return false;
 	}
 	long long list_cap = 0;
+	int trav_head = 8;   // traversal launches run by one workgroup (traverse_head_kernel); NBCO_TRAV_HEAD overrides
 	// the last kd-tree evaluation, for nbco_energy_fmm (pointers into the context's buffers; valid while tree_valid)
 	struct LastEval
 	{
