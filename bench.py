@@ -53,6 +53,7 @@ def parse(argv=None):
     ap.add_argument("--dens-inhom", type=float, default=1.0, help="the reference's -i option (deeper trees for clustered inputs)")
     ap.add_argument("--dt", type=float, default=5e-4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--step-calls", action="store_true", help="one nbco_integrate call per step instead of one nbco_integrate_steps call for the timed region")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the tree-reuse, strong-scaling, octree and nbco3 CLI legs after the timed region")
     ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--profile-all", action="store_true", help="record HIP events around every phase (perturbs value)")
@@ -336,27 +337,33 @@ def main():
                 run.partition(d[0].reshape(-1), d[1].reshape(-1))
                 run.force(prm)
             step = lambda: run.leapfrog(prm, args.dt)
+
+            def run_steps(k):
+                for _ in range(k):
+                    step()
         else:
             eng.compute_force(kind, d, n_local, prm)
             step = lambda: eng.integrate(INTEG_LEAPFROG, kind, d, n_local, prm, args.dt)
-        for _ in range(warmup):
-            step()
+            # K steps = one nbco_integrate_steps call (the reference's loop between two snapshots, main3.cu:840-870): same final
+            # state as K calls of nbco_integrate, bit for bit (tests/test_gpu_integrate_steps.py)
+            run_steps = (lambda k: eng.integrate_steps(INTEG_LEAPFROG, kind, d, n_local, prm, args.dt, k)) if not args.step_calls else \
+                (lambda k: [step() for _ in range(k)])
+        run_steps(warmup)
         if profile:
             eng.profile(True if args.profile_all else [dom])
             eng.profile_reset()
         barrier()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
+        run_steps(steps)
         barrier()
         elapsed = reduce(time.perf_counter() - t0, dist.ReduceOp.MAX)
         prof = eng.profile_get() if profile else None
         eng.profile(False)
         state = run.buf if sharded else d
         assert torch.isfinite(state).all(), "non-finite state after the timed steps"
-        return elapsed, eng, run, step, prof, n_sys
+        return elapsed, eng, run, run_steps, prof, n_sys
 
-    elapsed, eng, run, step, prof, n_sys = timed_run(n, args.steps, args.warmup, True)
+    elapsed, eng, run, run_steps, prof, n_sys = timed_run(n, args.steps, args.warmup, True)
 
     if args.workload == "fmm_kd":
         info = eng.kd_info()
@@ -386,13 +393,11 @@ def main():
     reuse = None
     if legs and world == 1 and args.workload == "fmm_kd" and args.tree_steps == 1:
         eng.set(tree_steps=8)
-        for _ in range(8):
-            step()
+        run_steps(8)
         barrier()
         t1 = time.perf_counter()
         k8 = max(8, (args.steps // 8) * 8)
-        for _ in range(k8):
-            step()
+        run_steps(k8)
         barrier()
         e8 = time.perf_counter() - t1
         reuse = {"tree_steps": 8, "steps": k8, "ms_per_step": 1e3 * e8 / k8, "value": n * k8 / e8, "unit": "particle-steps/s"}
@@ -403,15 +408,13 @@ def main():
     mutual = None
     if legs and world == 1 and args.workload == "fmm_kd" and not any(o.startswith("p2p_mutual") for o in args.engine_opt):
         eng.set(p2p_mutual=1)
-        for _ in range(max(2, args.warmup)):
-            step()
+        run_steps(max(2, args.warmup))
         if eng.kd_info().p2p_halves:
             eng.profile([dom])
             eng.profile_reset()
             barrier()
             tm = time.perf_counter()
-            for _ in range(args.steps):
-                step()
+            run_steps(args.steps)
             barrier()
             em = time.perf_counter() - tm
             pm = eng.profile_get()[dom]

@@ -166,6 +166,91 @@ __global__ __launch_bounds__(kPrepBlock) void kd_prep_kernel(const float *__rest
 	t.index[0] = 0;
 }
 
+// ---- between two leapfrog steps of nbco_integrate_steps: one pass instead of four ---------------------------------------------
+// After the force evaluation of step s the state is: accelerations in tree order (a3), and -- when the tree was rebuilt --
+// positions in tree order only as float4 (pos4) with the caller's arrays still in the order before the rebuild.  What follows
+// in the step-by-step sequence is  tree order for x, v (reorder_state_kernel)  ->  a -= k o x, v += a ks (finish_kick_kernel)
+// -> [step s + 1]  v += a ks, x += v ds (kick_drift_kernel)  ->  pack x, identity permutation, bounding box, root node,
+// cleared selection state (kd_prep_kernel).  Here every particle goes through exactly those operations, in that order and
+// with the same roundings, in registers.  GATHER: the evaluation rebuilt the tree (velocities come through `unsort`, v_out
+// must not be v_in); PREP: 1 = the next evaluation rebuilds (full build prologue), 0 = it reuses the tree (positions packed only).
+template <bool GATHER>
+__global__ __launch_bounds__(kPrepBlock) void kd_turnaround_kernel(float4 *__restrict__ pos4, int *__restrict__ unsort, float *__restrict__ x3,
+                                                                   const float *v_in, float *v_out, const float *__restrict__ a3,
+                                                                   const float *__restrict__ param, float ks, float ds, int elastic, long long n, int prep,
+                                                                   uint32_t *__restrict__ zero_a, long long words_a, uint32_t *__restrict__ zero_b,
+                                                                   long long words_b, int *__restrict__ flag, unsigned *__restrict__ state, TreeView t)
+{
+	float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+	const long long stride = (long long)gridDim.x * kPrepBlock, tid = (long long)blockIdx.x * kPrepBlock + threadIdx.x;
+	const float k3[3] = {param[3], param[4], param[5]};
+	for (long long i = tid; i < n; i += stride)
+	{
+		float x[3], v[3];
+		long long src = i;
+		if (GATHER)
+		{
+			const float4 q = pos4[i];
+			x[0] = q.x; x[1] = q.y; x[2] = q.z;
+			src = unsort[i];
+		}
+		else { x[0] = x3[3 * i]; x[1] = x3[3 * i + 1]; x[2] = x3[3 * i + 2]; }
+#pragma unroll
+		for (int c = 0; c < 3; ++c)
+		{
+			float ai = a3[3 * i + c];                                  // finish_kick_kernel (no rescale: the evaluator did it)
+			if (elastic) ai = fmaf(-k3[c], x[c], ai);
+			float vi = fmaf(ks, ai, v_in[3 * src + c]);
+			vi = fmaf(ks, ai, vi);                                     // kick_drift_kernel
+			x[c] = fmaf(ds, vi, x[c]);
+			v[c] = vi;
+		}
+		x3[3 * i] = x[0]; x3[3 * i + 1] = x[1]; x3[3 * i + 2] = x[2];
+		v_out[3 * i] = v[0]; v_out[3 * i + 1] = v[1]; v_out[3 * i + 2] = v[2];
+		pos4[i] = make_float4(x[0], x[1], x[2], 0.f);                  // kd_prep_kernel / pack4
+		if (prep) unsort[i] = (int)i;
+#pragma unroll
+		for (int c = 0; c < 3; ++c) { mn[c] = fminf(mn[c], x[c]); mx[c] = fmaxf(mx[c], x[c]); }
+	}
+	if (tid == 0) *flag = 0;
+	if (!prep) return;
+	for (long long i = tid; i < words_a; i += stride) zero_a[i] = 0u;
+	for (long long i = tid; i < words_b; i += stride) zero_b[i] = 0u;
+	__shared__ float sh[kPrepBlock / 64][6];
+	__shared__ unsigned last;
+	const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+	for (int c = 0; c < 3; ++c)
+		for (int o = 32; o > 0; o >>= 1) { mn[c] = fminf(mn[c], __shfl_xor(mn[c], o)); mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o)); }
+	if (lane == 0)
+#pragma unroll
+		for (int c = 0; c < 3; ++c) { sh[w][c] = mn[c]; sh[w][3 + c] = mx[c]; }
+	__syncthreads();
+	if (threadIdx.x < 6)
+	{
+		float v = sh[0][threadIdx.x];
+		for (int k = 1; k < kPrepBlock / 64; ++k) v = threadIdx.x < 3 ? fminf(v, sh[k][threadIdx.x]) : fmaxf(v, sh[k][threadIdx.x]);
+		if (threadIdx.x < 3) atomicMin(&state[threadIdx.x], ordered_bits(v));
+		else atomicMax(&state[threadIdx.x], ordered_bits(v));
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	if (threadIdx.x == 0) last = atomicAdd(&state[6], 1u) == gridDim.x - 1 ? 1u : 0u;
+	__syncthreads();
+	if (!last || threadIdx.x != 0) return;
+	float b[6];
+	for (int c = 0; c < 6; ++c)
+	{
+		b[c] = unordered_bits(__hip_atomic_load(&state[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+		__hip_atomic_store(&state[c], c < 3 ? 0xFFFFFFFFu : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+	__hip_atomic_store(&state[6], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	t.lbound[0] = b[0]; t.lbound[1] = b[1]; t.lbound[2] = b[2];
+	t.rbound[0] = b[3]; t.rbound[1] = b[4]; t.rbound[2] = b[5];
+	t.splitdim[0] = longest_axis(b[3] - b[0], b[4] - b[1], b[5] - b[2]);
+	t.index[0] = 0;
+}
+
 // composite keys of level l (fmm_cart3_kdtree.cuh:167-187): node j = floor(2^l i / n)
 __global__ __launch_bounds__(kBlock) void kd_keys_kernel(const float4 *__restrict__ pos, const int *__restrict__ splitdim_l, long long n,
                                                          int l, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
@@ -856,6 +941,31 @@ __device__ inline int classify_pair(const TreeView &t, const AdmTab *tab, int2 n
 	return (leaf1 || (!leaf2 && c1.w <= c2.w)) ? 4 : 5;
 }
 
+// the same on preloaded traversal records (centre + size, multiplicity): the traversal kernel fetches the records of a pair's
+// nodes AND of their children in one round trip, before it knows how the pair splits
+struct NodeRec { float4 c; int m; };
+__device__ inline bool kd_admissible_rec(const NodeRec a, const NodeRec b, int n1, int n2, const AdmTab *tabp, float par)
+{
+	float dx = b.c.x - a.c.x, dy = b.c.y - a.c.y, dz = b.c.z - a.c.z;
+	float dist2 = dx * dx + dy * dy + dz * dz;
+	int nb = a.m >= b.m ? n1 : n2, mb = a.m >= b.m ? a.m : b.m;
+	int lev = 31 - __clz(nb + 1);
+	float M = (mb == tabp->lo[lev]) ? tabp->Mlo[lev] : tabp->Mhi[lev];
+	float parM = par * M;
+	float sz = fmaxf(a.c.w, b.c.w);
+	return parM * parM * sz < dist2;
+}
+__device__ inline int classify_rec(int ntot, const AdmTab *tab, int2 np, const NodeRec a, const NodeRec b, float par, int m2l_first, const Dom dm)
+{
+	if (dm.d > 0 && !dom_touch(dm, np.x) && !dom_touch(dm, np.y)) return 0;   // nothing below this pair reaches the domain
+	const bool leaf1 = 2 * np.x + 1 >= ntot, leaf2 = 2 * np.y + 1 >= ntot;
+	if (!m2l_first && leaf1 && leaf2) return (np.x != np.y) ? 1 : 0;
+	if (np.x == np.y) return leaf1 ? 0 : 3;
+	if (kd_admissible_rec(a, b, np.x, np.y, tab, par)) return 2;
+	if (leaf1 && leaf2) return 1;
+	return (leaf1 || (!leaf2 && a.c.w <= b.c.w)) ? 4 : 5;
+}
+
 // children of a split pair, by value (an int2[] written through a pointer ends up in scratch memory, i.e. in extra
 // round trips on the traversal's dependency chain)
 struct PairKids
@@ -910,11 +1020,11 @@ __device__ inline long long region_slot(const int *__restrict__ pref, long long 
 	return (long long)r * capR + (i - pref[r]);
 }
 
-__device__ inline void traverse_body(const TreeView &t, const AdmTab &tab_arg, const int2 *fin, int2 *fout,
-                                     int2 *__restrict__ p2p, int2 *__restrict__ m2l, int2 *__restrict__ p2p_rank,
-                                     int2 *__restrict__ m2l_rank, int *__restrict__ counters,
-                                     int *tctr, int it, long long capR, float par, int m2l_first,
-                                     unsigned *__restrict__ cnt_p2p, unsigned *__restrict__ cnt_m2l, const Dom dm)
+__global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab_arg, const int2 *__restrict__ fin, int2 *__restrict__ fout,
+                                                          int2 *__restrict__ p2p, int2 *__restrict__ m2l, int2 *__restrict__ p2p_rank,
+                                                          int2 *__restrict__ m2l_rank, int *__restrict__ counters,
+                                                          int *__restrict__ tctr, int it, long long capR, float par, int m2l_first,
+                                                          unsigned *__restrict__ cnt_p2p, unsigned *__restrict__ cnt_m2l, const Dom dm)
 {
 	__shared__ uint64_t sh_wave[4];
 	__shared__ int sh_base[3];
@@ -949,11 +1059,19 @@ __device__ inline void traverse_body(const TreeView &t, const AdmTab &tab_arg, c
 		{
 			p0 = fin[region_slot(in_pref, capR, i)];
 			if (!NBCO_CHECKED_OK((unsigned)p0.x < (unsigned)t.ntot && (unsigned)p0.y < (unsigned)t.ntot, NBCO_CHK_FRONTIER)) p0 = make_int2(0, 0);
-			k0 = classify_pair(t, &tab, p0, par, m2l_first, dm);
+			// records of x, y and of their children, all in flight together (a leaf's "children" are clamped and never used)
+			const int last = t.ntot - 1;
+			const int ix1 = min(2 * p0.x + 1, last), ix2 = min(2 * p0.x + 2, last), iy1 = min(2 * p0.y + 1, last), iy2 = min(2 * p0.y + 2, last);
+			const NodeRec X{t.csz[p0.x], t.mult[p0.x]}, Y{t.csz[p0.y], t.mult[p0.y]};
+			const NodeRec X1{t.csz[ix1], t.mult[ix1]}, X2{t.csz[ix2], t.mult[ix2]}, Y1{t.csz[iy1], t.mult[iy1]}, Y2{t.csz[iy2], t.mult[iy2]};
+			k0 = classify_rec(t.ntot, &tab, p0, X, Y, par, m2l_first, dm);
 			ch = pair_children(k0, p0);
-			if (ch.n > 0) k1 = classify_pair(t, &tab, ch.a, par, m2l_first, dm);
-			if (ch.n > 1) k2 = classify_pair(t, &tab, ch.b, par, m2l_first, dm);
-			if (ch.n > 2) k3 = classify_pair(t, &tab, ch.c, par, m2l_first, dm);
+			// children (pair_children): 3 -> (x1,x1) (x1,x2) (x2,x2); 4 -> (x,y1) (x,y2); 5 -> (x1,y) (x2,y)
+			const NodeRec A1 = k0 == 4 ? X : X1, A2 = k0 == 5 ? Y : (k0 == 4 ? Y1 : X1);
+			const NodeRec B1 = k0 == 4 ? X : (k0 == 5 ? X2 : X1), B2 = k0 == 5 ? Y : (k0 == 4 ? Y2 : X2);
+			if (ch.n > 0) k1 = classify_rec(t.ntot, &tab, ch.a, A1, A2, par, m2l_first, dm);
+			if (ch.n > 1) k2 = classify_rec(t.ntot, &tab, ch.b, B1, B2, par, m2l_first, dm);
+			if (ch.n > 2) k3 = classify_rec(t.ntot, &tab, ch.c, X2, X2, par, m2l_first, dm);
 		}
 		const int nch = ch.n;
 		auto weight = [](int q) { return (uint64_t)(q == 3 ? 3 : (q >= 4 ? 2 : 0)) | ((uint64_t)(q == 1) << 20) | ((uint64_t)(q == 2) << 40); };
@@ -965,6 +1083,28 @@ __device__ inline void traverse_body(const TreeView &t, const AdmTab &tab_arg, c
 		if (threadIdx.x == 0) sh_base[0] = tf ? atomicAdd(&tctr[kTcFrontier + (it + 1) * kTravK + rout], tf) : 0;
 		if (threadIdx.x == 64) sh_base[1] = tp ? atomicAdd(&tctr[kTcP2P + rout], tp) : 0;
 		if (threadIdx.x == 128) sh_base[2] = tm ? atomicAdd(&tctr[kTcM2L + rout], tm) : 0;
+		// the per-target entry counts of the directed lists are accumulated here, under the traversal's latency; the value
+		// an atomic returns is the entry's slot inside its target's range, kept beside the pair so that filling the
+		// directed lists needs no second round of atomics (device-scope atomics retire at ~17 G/s on this part: two
+		// per entry were 60 us of every evaluation).  -1: the node belongs to another domain.  All atomics of a thread
+		// are issued before any of their results is used, and before the barrier that publishes the block's reservations, so
+		// they share that round trip.  (They count even when a region turns out to be full: traverse_finish_kernel clears
+		// the per-target counts of an overflowed traversal.)
+		auto slots = [&](int q, int2 np, bool ok) {
+			int2 r = make_int2(-1, -1);
+			if (q == 1 && ok)
+			{
+				if (dm.d == 0 || dom_touch(dm, np.x)) r.x = (int)atomicAdd(&cnt_p2p[np.x - lbeg], 1u);
+				if (dm.d == 0 || dom_touch(dm, np.y)) r.y = (int)atomicAdd(&cnt_p2p[np.y - lbeg], 1u);
+			}
+			if (q == 2 && ok)
+			{
+				if (dm.d == 0 || dom_touch(dm, np.x)) r.x = (int)atomicAdd(&cnt_m2l[np.x], 1u);
+				if (dm.d == 0 || dom_touch(dm, np.y)) r.y = (int)atomicAdd(&cnt_m2l[np.y], 1u);
+			}
+			return r;
+		};
+		const int2 r0 = slots(k0, p0, nch == 0 && i < nin), r1 = slots(k1, ch.a, nch > 0), r2 = slots(k2, ch.b, nch > 1), r3 = slots(k3, ch.c, nch > 2);
 		__syncthreads();
 		long long bf = sh_base[0], bp = sh_base[1], bm = sh_base[2];
 		const bool okf = bf + tf <= capR, okp = bp + tp <= capR, okm = bm + tm <= capR;
@@ -977,25 +1117,6 @@ __device__ inline void traverse_body(const TreeView &t, const AdmTab &tab_arg, c
 		if (!okf && bf < capR)
 			for (long long k = bf + threadIdx.x; k < capR; k += kBlock) fout[obase + k] = make_int2(0, 0);
 		bf += (long long)(off & 0xFFFFF); bp += (long long)((off >> 20) & 0xFFFFF); bm += (long long)(off >> 40);
-		// the per-target entry counts of the directed lists are accumulated here, under the traversal's latency; the value
-		// an atomic returns is the entry's slot inside its target's range, kept beside the pair so that filling the
-		// directed lists needs no second round of atomics (device-scope atomics retire at ~17 G/s on this part: two
-		// per entry were 60 us of every evaluation).  -1: the node belongs to another domain.  All atomics of a thread
-		// are issued before any of their results is used, so they share one round trip.
-		auto slots = [&](int q, int2 np, bool ok) {
-			int2 r = make_int2(-1, -1);
-			if (q == 1 && ok && okp)
-			{
-				if (dm.d == 0 || dom_touch(dm, np.x)) r.x = (int)atomicAdd(&cnt_p2p[np.x - lbeg], 1u);
-				if (dm.d == 0 || dom_touch(dm, np.y)) r.y = (int)atomicAdd(&cnt_p2p[np.y - lbeg], 1u);
-			}
-			if (q == 2 && ok && okm)
-			{
-				if (dm.d == 0 || dom_touch(dm, np.x)) r.x = (int)atomicAdd(&cnt_m2l[np.x], 1u);
-				if (dm.d == 0 || dom_touch(dm, np.y)) r.y = (int)atomicAdd(&cnt_m2l[np.y], 1u);
-			}
-			return r;
-		};
 		auto emit = [&](int q, int2 np, int2 r) {
 			if (q == 1 && okp) { p2p[obase + bp] = np; p2p_rank[obase + bp] = r; }
 			if (q == 2 && okm) { m2l[obase + bm] = np; m2l_rank[obase + bm] = r; }
@@ -1011,7 +1132,6 @@ __device__ inline void traverse_body(const TreeView &t, const AdmTab &tab_arg, c
 			bm += q == 2 ? 1 : 0;
 			bf += g.n;
 		};
-		const int2 r0 = slots(k0, p0, nch == 0 && i < nin), r1 = slots(k1, ch.a, nch > 0), r2 = slots(k2, ch.b, nch > 1), r3 = slots(k3, ch.c, nch > 2);
 		if (nch == 0) emit(k0, p0, r0);
 		else
 		{
@@ -1020,33 +1140,6 @@ __device__ inline void traverse_body(const TreeView &t, const AdmTab &tab_arg, c
 			if (nch > 2) emit(k3, ch.c, r3);
 		}
 		__syncthreads();
-	}
-}
-
-__global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab_arg, const int2 *fin, int2 *fout, int2 *__restrict__ p2p, int2 *__restrict__ m2l,
-                                                          int2 *__restrict__ p2p_rank, int2 *__restrict__ m2l_rank, int *__restrict__ counters, int *tctr, int it,
-                                                          long long capR, float par, int m2l_first, unsigned *__restrict__ cnt_p2p,
-                                                          unsigned *__restrict__ cnt_m2l, const Dom dm)
-{
-	traverse_body(t, tab_arg, fin, fout, p2p, m2l, p2p_rank, m2l_rank, counters, tctr, it, capR, par, m2l_first, cnt_p2p, cnt_m2l, dm);
-}
-// The first launches of a traversal see a frontier of 1, 3, .. a few hundred pairs: each is one dependent round trip through
-// the tree arrays wrapped in a launch (10.7 us apiece at N = 1M, 16 of them in a row).  ONE workgroup runs launches
-// [it0, it1) back to back instead -- same body, same region bookkeeping, the frontier ping-pongs between fa and fb as it does
-// between launches; what one iteration wrote is made visible to the next by a device-scope fence on either side of the
-// barrier (stores are written through to L2, the fence after the barrier invalidates the CU's L1).
-__global__ __launch_bounds__(kBlock) void traverse_head_kernel(TreeView t, AdmTab tab_arg, int2 *fa, int2 *fb, int2 *__restrict__ p2p, int2 *__restrict__ m2l,
-                                                               int2 *__restrict__ p2p_rank, int2 *__restrict__ m2l_rank, int *__restrict__ counters, int *tctr, int it0,
-                                                               int it1, long long capR, float par, int m2l_first, unsigned *__restrict__ cnt_p2p,
-                                                               unsigned *__restrict__ cnt_m2l, const Dom dm)
-{
-	for (int it = it0; it < it1; ++it)
-	{
-		traverse_body(t, tab_arg, fa, fb, p2p, m2l, p2p_rank, m2l_rank, counters, tctr, it, capR, par, m2l_first, cnt_p2p, cnt_m2l, dm);
-		__threadfence();
-		__syncthreads();
-		__threadfence();
-		int2 *x = fa; fa = fb; fb = x;
 	}
 }
 
@@ -1635,6 +1728,8 @@ static int kd_build_upward(nbco_ctx *c, const float *p, long long n, int L, cons
 				c->perm_primed_n = n;
 			}
 			// pack + identity permutation + bounding box + root node + cleared selection state: one launch
+			// (nbco_integrate_steps: the pass between two steps has done all of it, kd_turnaround)
+			if (c->skip_prep != 1)
 			hipLaunchKernelGGL(kd_prep_kernel, dim3(kPrepGrid), dim3(kPrepBlock), 0, st, p, n, pos, unsort, c->sel_hist.as<uint32_t>(), words_a,
 			                   c->sel_nodes.as<uint32_t>(), words_b, c->counters.as<int>() + 110, c->prep_state.as<unsigned>(), tv, root6);
 			NBCO_TRY(kd_build_top(c, tv, pos, pos_alt, unsort, unsort_alt, n, l0, use_select, true));
@@ -1651,9 +1746,13 @@ static int kd_build_upward(nbco_ctx *c, const float *p, long long n, int L, cons
 		else
 		{
 			// tree reused: the caller's positions are already in tree order
-			NBCO_TRY(launch_pack4(c, pos, p, n));
-			NBCO_HIP(hipMemsetAsync(c->counters.as<int>() + 110, 0, sizeof(int), st));
+			if (c->skip_prep == 0)
+			{
+				NBCO_TRY(launch_pack4(c, pos, p, n));
+				NBCO_HIP(hipMemsetAsync(c->counters.as<int>() + 110, 0, sizeof(int), st));
+			}
 		}
+		c->skip_prep = 0;
 		if (!rebuild) hipLaunchKernelGGL(kd_leaf_kernel, dim3(grid1d(nleaf)), dim3(kBlock), 0, st, tv, pos, n);   // (a rebuild's subtree kernel did it)
 		// centres and traversal records of all nodes first (2 launches): that is all the traversal needs, so the multipole
 		// chain (P2M + M2M, generated register-resident bodies of k_farfield.hip) runs beside it on the second stream
@@ -1759,16 +1858,7 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		                   c->list_cnt.as<unsigned>(), (long long)(2 * (np_ + nm_)), (long long)self0, (long long)(c->o.coll ? nself : 0));
 		// (counters[110] is the selection-build flag)
 		const int iters = L + NBCO_TRAV_EXTRA;   // every launch performs two traversal steps; traverse_finish_kernel checks that none is left
-		// the first launches (frontiers of up to a few hundred pairs) inside one workgroup
-		const int head = std::min(iters, c->trav_head);
-		if (head > 1)
-		{
-			hipLaunchKernelGGL(traverse_head_kernel, dim3(1), dim3(kBlock), 0, st, tv, tab, fa, fb, c->p2p_list.as<int2>(), c->m2l_list.as<int2>(),
-			                   c->p2p_list.as<int2>() + cap, c->m2l_list.as<int2>() + cap, ctr, tctr, 0, head, capR, c->o.tree_radius, c->o.m2l_first, cnt_p2p,
-			                   cnt_m2l, dm);
-			if (head & 1) std::swap(fa, fb);
-		}
-		for (int it = head > 1 ? head : 0; it < iters; ++it)
+		for (int it = 0; it < iters; ++it)
 		{
 			hipLaunchKernelGGL(traverse_kernel, dim3(1024), dim3(kBlock), 0, st, tv, tab, (const int2 *)fa, fb, c->p2p_list.as<int2>(),
 			                   c->m2l_list.as<int2>(), c->p2p_list.as<int2>() + cap, c->m2l_list.as<int2>() + cap, ctr, tctr, it, capR,
@@ -2104,6 +2194,54 @@ int kd_energy_fmm(nbco_ctx *c, long long n_own, double *half_phi_sum)
 namespace {
 } // namespace
 
+// the re-ordering an evaluation with defer_order set has left undone (nbco_integrate_steps, last step)
+int kd_finish_pending_order(nbco_ctx *c, float *p, long long n)
+{
+	if (!c->order_pending) return NBCO_OK;
+	c->order_pending = false;
+	return kd_finish_order(c, p, n);
+}
+
+// nbco_integrate_steps, between the force evaluation of one leapfrog step and that of the next (kd_turnaround_kernel).  v_in: where
+// the current velocities are (the caller's array or the scratch copy of the turnaround before); returns where they are now.
+int kd_turnaround(nbco_ctx *c, float *p, const float *v_in, const float **v_now, const float *param, float ks, float ds, bool elastic, long long n)
+{
+	const bool gather = c->order_pending;
+	c->order_pending = false;
+	float *x = p, *v = p + 3 * n, *a = p + 6 * n;
+	const int L = c->kd.L;
+	// will the next evaluation rebuild?  (kd_build_upward's rule; the options cannot change inside nbco_integrate_steps)
+	const bool next_rebuild = (c->eval_counter % c->o.tree_steps) == 0;
+	long long words_a = 0, words_b = 0;
+	if (next_rebuild)
+	{
+		int l0 = 0;
+		while (l0 < L && (n + (1LL << l0) - 1) / (1LL << l0) > kSubS) ++l0;
+		if (!c->force_sort_build && l0 > 0) NBCO_TRY(kd_select_begin(c, l0, false, &words_a, &words_b));
+	}
+	float *v_out = v;
+	if (gather)
+	{
+		NBCO_TRY(c->reserve(c->tmp3, sizeof(float) * 3 * (size_t)n));
+		NBCO_TRY(c->reserve(c->tmp3b, sizeof(float) * 3 * (size_t)n));
+		v_out = v_in == c->tmp3.as<float>() ? c->tmp3b.as<float>() : c->tmp3.as<float>();
+	}
+	else if (v_in != v) v_out = const_cast<float *>(v_in);   // in place, wherever they are
+	PhaseScope ph(c, NBCO_PH_AXPY);
+	TreeView tv = view_of(c->kd);
+	hipStream_t st = c->stream;
+#define NBCO_TURN_ARGS c->pos4.as<float4>(), c->unsort.as<int>(), x, v_in, v_out, (const float *)a, param, ks, ds, elastic ? 1 : 0, n, next_rebuild ? 1 : 0, \
+	c->sel_hist.as<uint32_t>(), words_a, c->sel_nodes.as<uint32_t>(), words_b, c->counters.as<int>() + 110, c->prep_state.as<unsigned>(), tv
+	if (gather) hipLaunchKernelGGL(kd_turnaround_kernel<true>, dim3(kPrepGrid), dim3(kPrepBlock), 0, st, NBCO_TURN_ARGS);
+	else hipLaunchKernelGGL(kd_turnaround_kernel<false>, dim3(kPrepGrid), dim3(kPrepBlock), 0, st, NBCO_TURN_ARGS);
+#undef NBCO_TURN_ARGS
+	NBCO_HIP(hipGetLastError());
+	c->skip_prep = next_rebuild ? 1 : 2;
+	c->order_n = -1;
+	*v_now = v_out;
+	return NBCO_OK;
+}
+
 int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *param)
 {
 	if (n <= 0) return c->fail(NBCO_ERR_ARG, "nbco_fmm_kdtree: n must be positive");
@@ -2137,7 +2275,12 @@ int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 		c->tree_valid = false;
 		return fmm_kdtree_eval(c, p, a, n, param);
 	}
-	if (!c->o.unsort && rebuild) NBCO_TRY(kd_finish_order(c, p, n));
+	c->order_pending = false;
+	if (!c->o.unsort && rebuild)
+	{
+		if (c->defer_order) c->order_pending = true;   // nbco_integrate_steps folds the re-ordering into its pass between two steps
+		else NBCO_TRY(kd_finish_order(c, p, n));
+	}
 
 	c->tree_valid = true;
 	c->tree_n = n;

@@ -177,7 +177,6 @@ int nbco_create(nbco_ctx **out, const nbco_opts *o)
 	if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
 	c->stream = (hipStream_t)c->o.stream;
 	c->poison = getenv("NBCO_POISON") && atoi(getenv("NBCO_POISON")) != 0;
-	if (getenv("NBCO_TRAV_HEAD")) c->trav_head = std::max(0, atoi(getenv("NBCO_TRAV_HEAD")));
 	if (hipMalloc(&c->small.ptr, 4096) != hipSuccess) { delete c; return NBCO_ERR_HIP; }
 	c->small.bytes = 4096;
 	*out = c;
@@ -545,6 +544,68 @@ int nbco_integrate(nbco_ctx *c, int scheme, int kind, float *buf, long long n, c
 	}
 	default:
 		return c->fail(NBCO_ERR_ARG, "unknown integrator scheme");
+	}
+	return maybe_sync(c);
+}
+
+// `steps` steps of the scheme in one call.  Leapfrog over the kd-tree evaluator (tree order kept, opts.unsort = 0) fuses what lies
+// between two force evaluations -- tree order for x and v, elastic term, the two half kicks, the drift and the next build's
+// prologue: four passes over the state -- into one (kd_turnaround); every particle sees the same operations with the same
+// roundings as in `steps` calls of nbco_integrate, and the final state is bit-identical to theirs.  Everything else loops.
+int nbco_integrate_steps(nbco_ctx *c, int scheme, int kind, float *buf, long long n, const float *param, double dt_, double scale_, int elastic,
+                         int steps)
+{
+	if (!c || !buf || !param || n <= 0 || steps < 0) return c ? c->fail(NBCO_ERR_ARG, "nbco_integrate_steps: bad arguments") : NBCO_ERR_ARG;
+	const bool fuse = scheme == NBCO_INTEG_LEAPFROG && kind == NBCO_EVAL_FMM_KDTREE && !c->o.unsort && !c->o.track_order && steps >= 2;
+	if (!fuse)
+	{
+		const int sync = c->o.sync;
+		c->o.sync = 0;
+		int rc = NBCO_OK;
+		for (int s = 0; s < steps && rc == NBCO_OK; ++s) rc = nbco_integrate(c, scheme, kind, buf, n, param, dt_, scale_, elastic);
+		c->o.sync = sync;
+		if (rc != NBCO_OK) return rc;
+		return maybe_sync(c);
+	}
+	float *x = buf, *v = buf + 3 * n, *a = buf + 6 * n;
+	const long long n3 = 3 * n;
+	const long double dt = dt_, scale = scale_;
+	const float ds = (float)(dt * scale * 0.5L), dtf = (float)dt;
+	{
+		PhaseScope ph(c, NBCO_PH_AXPY);
+		NBCO_TRY(launch_kick_drift(c, x, v, a, ds, dtf, n3));
+	}
+	const float *v_now = v;
+	auto home = [&]() {   // the velocities back into the caller's array
+		if (v_now != v) hipMemcpyAsync(v, v_now, sizeof(float) * (size_t)n3, hipMemcpyDeviceToDevice, c->stream);
+		v_now = v;
+	};
+	c->defer_order = true;
+	for (int s = 0; s < steps; ++s)
+	{
+		int rc = eval_kind(c, kind, x, a, n, param);
+		if (rc == NBCO_OK && s + 1 < steps) rc = kd_turnaround(c, buf, v_now, &v_now, param, ds, dtf, elastic != 0, n);
+		if (rc != NBCO_OK)
+		{
+			c->defer_order = false;
+			home();
+			kd_finish_pending_order(c, x, n);   // leave a whole state behind
+			return rc;
+		}
+	}
+	c->defer_order = false;
+	home();
+	// tail of the last step, as in nbco_integrate: tree order, then a -= k o x, v += a ds
+	c->defer_v_copy = true;
+	c->v_deferred = nullptr;
+	const int rc = kd_finish_pending_order(c, x, n);
+	c->defer_v_copy = false;
+	const float *v_in = c->v_deferred ? c->v_deferred : v;
+	c->v_deferred = nullptr;
+	if (rc != NBCO_OK) return rc;
+	{
+		PhaseScope ph(c, NBCO_PH_AXPY);
+		NBCO_TRY(launch_finish_kick(c, x, v_in, v, a, param, ds, n, elastic != 0));
 	}
 	return maybe_sync(c);
 }

@@ -128,6 +128,11 @@ struct nbco_ctx
 		return true;
 	}
 	bool defer_v_copy = false;
+	// nbco_integrate_steps: leave the re-ordering of the caller's state after a rebuild to the pass between two steps
+	// (order_pending: such a re-ordering is due); skip_prep: that pass has already done the next build's prologue (1) or
+	// packed the positions for a reused tree (2)
+	bool defer_order = false, order_pending = false;
+	int skip_prep = 0;
 	const float *v_deferred = nullptr;
 	long long perm_primed_n = -1;   // particle count for which both permutation buffers were last filled with valid indices
 	double host_wait_s = 0, host_call_s = 0;   // diagnostics (NBCO_HOST_TIMING): time blocked on the flags event / inside nbco_integrate
@@ -156,7 +161,7 @@ struct nbco_ctx
 	DevBuf pos4_alt;      // second buffer for gathers
 	DevBuf part;          // partial results of reductions / direct j-splits
 	DevBuf small;         // a few hundred bytes of device scalars
-	DevBuf tmp3;          // float[3n] scratch for gathers of xyz triplets
+	DevBuf tmp3, tmp3b;   // float[3n] scratch for gathers of xyz triplets (tmp3b: second velocity copy of nbco_integrate_steps)
 	// kd-tree build
 	DevBuf keys, keys_alt, idx, idx_alt, unsort, unsort_alt, sort_tmp;
 	DevBuf treebuf;
@@ -196,7 +201,6 @@ struct nbco_ctx
 		return false;
 	}
 	long long list_cap = 0;
-	int trav_head = 8;   // traversal launches run by one workgroup (traverse_head_kernel); NBCO_TRAV_HEAD overrides
 	// the last kd-tree evaluation, for nbco_energy_fmm (pointers into the context's buffers; valid while tree_valid)
 	struct LastEval
 	{
@@ -280,6 +284,8 @@ int oct_copy_out(nbco_ctx *c, int which, void *host_dst, long long host_bytes);
 // multi-GPU kd-domain sharding (k_fmm_kd.hip)
 int kd_dist_layout(nbco_ctx *c, long long n_global, int world, int rank, nbco_dist_layout *out);
 int kd_dist_partition(nbco_ctx *c, const float *state_all, long long n_global, int world, int rank, float *state_local);
+int kd_finish_pending_order(nbco_ctx *c, float *p, long long n);
+int kd_turnaround(nbco_ctx *c, float *p, const float *v_in, const float **v_now, const float *param, float ks, float ds, bool elastic, long long n);
 int kd_dist_let_select(nbco_ctx *c, const void *csz_all, long long *counts);
 int kd_dist_let_pack(nbco_ctx *c, const long long *counts_all, void *pos_send, void *mpole_send);
 int kd_dist_let_finish(nbco_ctx *c, const long long *counts_all, const void *pos_recv, const void *mpole_recv, float *buf_local, float *a_local, const float *param);

@@ -103,6 +103,7 @@ def _load():
         "nbco_fmm_symmetric": [P, P, P, LL, P],
         "nbco_force": [P, I, P, LL, P, I],
         "nbco_integrate": [P, I, I, P, LL, P, D, D, I],
+        "nbco_integrate_steps": [P, I, I, P, LL, P, D, D, I, I],
         "nbco_minmax": [P, P, LL, P],
         "nbco_mean_relerr": [P, P, P, LL, C.POINTER(F)],
         "nbco_pow_sum": [P, P, I, LL, C.POINTER(D)],
@@ -249,6 +250,10 @@ class Engine:
 
     def integrate(self, scheme, kind, buf, n, param, dt, scale=1.0, elastic=True):
         self._chk(self.lib.nbco_integrate(self.ctx, scheme, kind, _ptr(buf), n, _ptr(param), dt, scale, int(elastic)))
+
+    def integrate_steps(self, scheme, kind, buf, n, param, dt, steps, scale=1.0, elastic=True):
+        """`steps` steps in one call (nbco_integrate_steps): same final state as `steps` calls of integrate()"""
+        self._chk(self.lib.nbco_integrate_steps(self.ctx, scheme, kind, _ptr(buf), n, _ptr(param), dt, scale, int(elastic), int(steps)))
 
     # ---- reductions -----------------------------------------------------------------------------
     def minmax(self, p, n):

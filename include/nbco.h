@@ -137,6 +137,12 @@ int nbco_force(nbco_ctx *c, int kind, float *buf, long long n, const float *para
  * dt and scale are the reference's long double arguments narrowed to double. */
 int nbco_integrate(nbco_ctx *c, int scheme, int kind, float *buf, long long n, const float *param,
                    double dt, double scale, int elastic);
+/* `steps` steps in one call: the loop body of main3.cu:840-870 between two snapshots.  The final state is bit-identical to
+ * `steps` calls of nbco_integrate; leapfrog over the kd-tree evaluator (opts.unsort = 0, no order tracking) runs what lies
+ * between two force evaluations -- tree order of x and v, elastic term, both half kicks, the drift, the next build's
+ * prologue -- as ONE pass over the state instead of four.  Intermediate states are not observable. */
+int nbco_integrate_steps(nbco_ctx *c, int scheme, int kind, float *buf, long long n, const float *param,
+                         double dt, double scale, int elastic, int steps);
 
 /* ---- reductions (reductions.cuh) -------------------------------------------------------------- */
 int nbco_minmax(nbco_ctx *c, const float *p, long long n, float *minmax6_dev);           /* reductions.cuh:67 minmaxReduce2 */
