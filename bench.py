@@ -266,7 +266,7 @@ def main():
     import torch
     import torch.distributed as dist
     from coulomb_oscillators_amd import (Engine, EVAL_DIRECT, EVAL_FMM_KDTREE, EVAL_FMM_TRACELESS, INTEG_LEAPFROG, DomainRun,
-                                         TorchComm)
+                                         SlabRun, TorchComm)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -283,6 +283,7 @@ def main():
         torch.cuda.set_device(0)
     n = args.n
     sharded = world > 1 and args.workload == "fmm_kd"
+    slabbed = world > 1 and args.workload == "fmm_oct"      # ONE system of --particles, slabs of the cell order (strong scaling)
     kind = {"fmm_kd": EVAL_FMM_KDTREE, "fmm_oct": EVAL_FMM_TRACELESS, "direct": EVAL_DIRECT}[args.workload]
     if args.far_fp64 and args.workload != "fmm_oct":
         raise SystemExit("--far-fp64 needs --workload fmm_oct")
@@ -306,7 +307,7 @@ def main():
         n_sys = world * n_local if sharded else n_local      # particles of ONE physical system
         # every rank draws n_local particles of the same Gaussian ball from its own stream; sharded run: their union is the
         # N = world * n_local system, the kd-domains are cut by the first partition
-        buf = gaussian_ball(n_local, rank)
+        buf = gaussian_ball(n_local, 0 if slabbed else rank)
         d = torch.from_numpy(buf).cuda()
         prm = torch.from_numpy(coulomb_params(n_sys)).cuda()
         extra_opts = {}
@@ -341,6 +342,15 @@ def main():
             def run_steps(k):
                 for _ in range(k):
                     step()
+        elif slabbed:
+            run = SlabRun(eng, n_local, TorchComm())
+            run.set_state(d[0], d[1])
+            run.force(prm)
+            step = lambda: run.leapfrog(prm, args.dt)
+
+            def run_steps(k):
+                for _ in range(k):
+                    step()
         else:
             eng.compute_force(kind, d, n_local, prm)
             step = lambda: eng.integrate(INTEG_LEAPFROG, kind, d, n_local, prm, args.dt)
@@ -359,7 +369,7 @@ def main():
         elapsed = reduce(time.perf_counter() - t0, dist.ReduceOp.MAX)
         prof = eng.profile_get() if profile else None
         eng.profile(False)
-        state = run.buf if sharded else d
+        state = run.buf if (sharded or slabbed) else d
         assert torch.isfinite(state).all(), "non-finite state after the timed steps"
         return elapsed, eng, run, run_steps, prof, n_sys
 
@@ -382,6 +392,10 @@ def main():
         pairs_per_eval = 0    # the octree path keeps no pair counter: no roofline entry for this workload
         extra = {"L": info.L, "m2l_entries": int(info.m2l_entries), "p2p_chunks": int(info.p2p_chunks),
                  "far_field": "fp64" if info.real_bytes == 8 else "fp32"}
+        if slabbed:
+            extra.update({"parallelism": "slabs of the sorted cell keys x%d (state replicated, targets partitioned), one padded all-gather of the acceleration slabs per evaluation" % world,
+                          "exchange_bytes_per_eval_per_gpu": run.exchange_bytes(), "slab_particles": [int(y - x) for x, y in zip(run.bounds[:-1], run.bounds[1:])],
+                          "backend": args.backend})
     else:
         pairs_per_eval = n * n
         extra = {}
@@ -437,14 +451,14 @@ def main():
                   "exchange_bytes_per_eval_per_gpu": run_s.exchange_bytes(), "allgather_bytes_per_eval_per_gpu": run_s.allgather_bytes()}
         eng_s.close()
 
-    value = world * n * args.steps / elapsed
+    value = (n if slabbed else world * n) * args.steps / elapsed
     if args.workload == "fmm_kd":
         wl = ("FMM-3D kd-tree p=%d, N=%d per GPU (one system of %d), leapfrog, Gaussian ball, tree rebuilt every %d step(s)"
               % (args.order, n, n_sys, args.tree_steps))
         metric = "particle-steps/sec (+ Gpair-interactions/sec), N=%d FMM-3D kd-tree p=%d, %d GPU(s)" % (n_sys, args.order, world)
     elif args.workload == "fmm_oct":
-        wl = "FMM-3D uniform octree, traceless multipoles p=%d, N=%d per GPU, leapfrog, Gaussian ball" % (args.order, n)
-        metric = "particle-steps/sec, N=%d FMM-3D cartesian traceless (octree) p=%d, %d replica(s)" % (n, args.order, world)
+        wl = "FMM-3D uniform octree, traceless multipoles p=%d, ONE system of N=%d, leapfrog, Gaussian ball" % (args.order, n)
+        metric = "particle-steps/sec, N=%d FMM-3D cartesian traceless (octree) p=%d, %d GPU(s)" % (n, args.order, world)
     else:
         wl = "direct O(N^2) 3D, N=%d per GPU, leapfrog" % n
         metric = "particle-steps/sec (+ Gpair-interactions/sec), N=%d direct O(N^2), %d replica(s)" % (n, world)
@@ -457,7 +471,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if slabbed else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",

@@ -10,9 +10,9 @@ from .engine import (Engine, EngineError, lib_path, build_library, default_opts,
                      EVAL_DIRECT, EVAL_DIRECT_KAHAN, EVAL_FMM_KDTREE, EVAL_FMM_TRACELESS, EVAL_FMM_SYMMETRIC,
                      INTEG_EULER, INTEG_PRE_EULER, INTEG_LEAPFROG, INTEG_FORESTRUTH, INTEG_PEFRL,
                      PHASES)
-from .dist import DomainRun, TorchComm, SingleComm, LoopbackWorld
+from .dist import DomainRun, TorchComm, SingleComm, LoopbackWorld, SlabRun, LoopbackSlabs
 
 __all__ = ["Engine", "EngineError", "lib_path", "build_library", "default_opts",
            "EVAL_DIRECT", "EVAL_DIRECT_KAHAN", "EVAL_FMM_KDTREE", "EVAL_FMM_TRACELESS", "EVAL_FMM_SYMMETRIC",
            "INTEG_EULER", "INTEG_PRE_EULER", "INTEG_LEAPFROG", "INTEG_FORESTRUTH", "INTEG_PEFRL", "PHASES",
-           "DomainRun", "TorchComm", "SingleComm", "LoopbackWorld"]
+           "DomainRun", "TorchComm", "SingleComm", "LoopbackWorld", "SlabRun", "LoopbackSlabs"]

@@ -112,6 +112,45 @@ __global__ __launch_bounds__(kBlock) void oct_index_kernel(OctView<T> t, const u
 	}
 }
 
+// ---- multi-GPU: slabs of the sorted cell keys ---------------------------------------------------------------
+// The cell keys are row-major (x slowest), so a contiguous range of leaf cells in key order is a slab of x-layers.  Rank r of G
+// serves the cells [c_r, c_r+1), c_r = the first cell whose first particle is >= n r / G: its particles are the contiguous range
+// [index[c_r], index[c_r+1]) of the cell order.  Every rank builds the whole tree and the whole upward pass (O(N), a few per
+// cent of a step); M2L / L2L run for the nodes whose x-range meets the slab's layers, P2P and L2P for the slab's cells only.
+// slab (device, 6 ints): {c0, c1, x0, x1, p0, p1} -- leaf cells, leaf x-layers (inclusive), particles; a null pointer = everything.
+template <typename T>
+__global__ void oct_slab_kernel(OctView<T> t, int world, int rank, int *__restrict__ slab, long long *__restrict__ pbounds)
+{
+	const int r = threadIdx.x;
+	if (blockIdx.x != 0 || r > world) return;
+	const int m = oct_cnt(t.L), beg = oct_beg(t.L);
+	const long long b = (t.n * r) / world;
+	int lo = 0, hi = m;   // smallest c in [0, m] with index[beg + c] >= b   (index[beg + m] = n)
+	while (lo < hi)
+	{
+		const int mid = (lo + hi) >> 1;
+		if (t.index[beg + mid] < b) lo = mid + 1; else hi = mid;
+	}
+	__shared__ int cb[65];
+	cb[r] = lo;
+	pbounds[r] = t.index[beg + lo];
+	__syncthreads();
+	if (r == rank)
+	{
+		const int c0 = cb[r], c1 = cb[r + 1], ss = t.side * t.side;
+		slab[0] = c0; slab[1] = c1;
+		slab[2] = c0 / ss; slab[3] = c1 > c0 ? (c1 - 1) / ss : c0 / ss - 1;
+		slab[4] = t.index[beg + c0]; slab[5] = t.index[beg + c1];
+	}
+}
+// does the node (level l, x index i at that level) lie above or inside one of the slab's x-layers?
+__device__ inline bool oct_in_slab(const int *__restrict__ slab, int L, int l, int i)
+{
+	if (!slab) return true;
+	const int lo = i << (L - l), hi = ((i + 1) << (L - l)) - 1;
+	return lo <= slab[3] && hi >= slab[2];
+}
+
 // ---- leaves: multLeaves + centerLeaves + P2M, one wave per cell ------------------------------------------------
 // SYM: symmetric multipoles of orders 0..P about the centroid (fmm_multipoleLeaves3, fmm_cart3_symmetric.cuh:71-99): the kd-tree
 // flavour's generated P2M of order P + 1, whose tuple holds orders 0..P
@@ -262,7 +301,7 @@ __device__ inline int oct_level_of(int node)
 // FILL = false: cnt[node] = number of non-empty sources; FILL = true: keys[start[node] ..] = target << shift | source
 template <bool FILL, typename T>
 __global__ __launch_bounds__(kBlock) void oct_m2l_list_kernel(OctView<T> t, int radius, int first, int *__restrict__ cnt, const int *__restrict__ start,
-                                                              int shift, uint64_t *__restrict__ keys)
+                                                              int shift, uint64_t *__restrict__ keys, const int *__restrict__ slab)
 {
 	for (int node = blockIdx.x * kBlock + threadIdx.x; node < t.ntot; node += gridDim.x * kBlock)
 	{
@@ -271,6 +310,7 @@ __global__ __launch_bounds__(kBlock) void oct_m2l_list_kernel(OctView<T> t, int 
 		{
 			const int l = oct_level_of(node), sl = 1 << l, lb = oct_beg(l), c = node - lb;
 			const int i = c / (sl * sl), jk = c - i * sl * sl, j = jk / sl, k = jk - j * sl;
+			if (!oct_in_slab(slab, t.L, l, i)) { if (!FILL) cnt[node] = 0; continue; }
 			const int im = (i / 2) * 2, jm = (j / 2) * 2, km = (k / 2) * 2;
 			const int f0 = max(im - 2 * radius, 0), f1 = min(im + 2 * radius + 1, sl - 1);
 			const int g0 = max(jm - 2 * radius, 0), g1 = min(jm + 2 * radius + 1, sl - 1);
@@ -294,7 +334,7 @@ __global__ __launch_bounds__(kBlock) void oct_m2l_list_kernel(OctView<T> t, int 
 
 // ---- L2L: one thread per child cell (fmm_cart3_symmetric.cuh:293-334) ---------------------------------------------
 template <int P, typename T>
-__global__ __launch_bounds__(kBlock) void oct_l2l_kernel(OctView<T> t, int lchild)
+__global__ __launch_bounds__(kBlock) void oct_l2l_kernel(OctView<T> t, int lchild, const int *__restrict__ slab)
 {
 	constexpr int offL = NBCO_OFFL(P);
 	const int c = blockIdx.x * kBlock + threadIdx.x;
@@ -303,6 +343,7 @@ __global__ __launch_bounds__(kBlock) void oct_l2l_kernel(OctView<T> t, int lchil
 	if (t.mult[node] == 0) return;
 	const int sl = 1 << lchild, sp = sl >> 1;
 	const int i = c / (sl * sl), jk = c - i * sl * sl, j = jk / sl, k = jk - j * sl;
+	if (!oct_in_slab(slab, t.L, lchild, i)) return;
 	const int parent = oct_beg(lchild - 1) + ((i >> 1) * sp + (j >> 1)) * sp + (k >> 1);
 	T Lp[offL], O[offL];
 #pragma unroll
@@ -318,13 +359,13 @@ __global__ __launch_bounds__(kBlock) void oct_l2l_kernel(OctView<T> t, int lchil
 // per leaf cell: number of target groups, of source descriptors and of chunks
 template <typename T>
 __global__ __launch_bounds__(kBlock) void oct_p2p_count_kernel(OctView<T> t, int radius, int tpl, int *__restrict__ ngroup, int *__restrict__ ndesc,
-                                                               int *__restrict__ nchunk)
+                                                               int *__restrict__ nchunk, const int *__restrict__ slab)
 {
 	const int m = oct_cnt(t.L), beg = oct_beg(t.L), side = t.side;
 	for (int c = blockIdx.x * kBlock + threadIdx.x; c <= m; c += gridDim.x * kBlock)
 	{
 		int ng = 0, nd = 0;
-		if (c < m && t.mult[beg + c] > 0)
+		if (c < m && t.mult[beg + c] > 0 && (!slab || (c >= slab[0] && c < slab[1])))
 		{
 			ng = (t.mult[beg + c] + tpl - 1) / tpl;
 			const int i = c / (side * side), jk = c - i * side * side, j = jk / side, k = jk - j * side;
@@ -346,13 +387,14 @@ __global__ __launch_bounds__(kBlock) void oct_p2p_count_kernel(OctView<T> t, int
 template <typename T>
 __global__ __launch_bounds__(kBlock) void oct_p2p_fill_kernel(OctView<T> t, int radius, int tpl, const int *__restrict__ group_off,
                                                               const int *__restrict__ desc_off, int *__restrict__ grp_index,
-                                                              int *__restrict__ grp_mult, int *__restrict__ grp_cell, int2 *__restrict__ desc)
+                                                              int *__restrict__ grp_mult, int *__restrict__ grp_cell, int2 *__restrict__ desc,
+                                                              const int *__restrict__ slab)
 {
 	const int m = oct_cnt(t.L), beg = oct_beg(t.L), side = t.side;
 	for (int c = blockIdx.x * kBlock + threadIdx.x; c < m; c += gridDim.x * kBlock)
 	{
 		const int mlt = t.mult[beg + c];
-		if (mlt == 0) continue;
+		if (mlt == 0 || (slab && (c < slab[0] || c >= slab[1]))) continue;
 		const int i0 = t.index[beg + c], g0 = group_off[c], ng = group_off[c + 1] - g0;
 		for (int g = 0; g < ng; ++g)
 		{
@@ -396,11 +438,12 @@ template <int P, typename T>
 __global__ __launch_bounds__(kBlock) void oct_l2p_kernel(OctView<T> t, const float4 *__restrict__ pos, const uint32_t *__restrict__ keys,
                                                          const float4 *__restrict__ near, const int *__restrict__ group_off,
                                                          const int *__restrict__ desc_off, const int *__restrict__ chunk_off, int tpl,
-                                                         int have_near, const float *__restrict__ param, float *__restrict__ a_out)
+                                                         int have_near, const float *__restrict__ param, float *__restrict__ a_out,
+                                                         const int *__restrict__ slab)
 {
 	constexpr int offL = NBCO_OFFL(P);
 	const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
-	if (i >= t.n) return;
+	if (i >= t.n || (slab && (i < slab[4] || i >= slab[5]))) return;
 	const int c = (int)keys[i], leaf = oct_beg(t.L) + c;
 	const float4 p = pos[i], cc = t.csz[leaf];
 	T Lp[offL];
@@ -451,8 +494,9 @@ static int m2l_lanes(nbco_ctx *c, int P, const float4 *csz, const double *mpole,
 	return launch_m2l_lanes_f64(c, P, csz, mpole, local, keys, start, shift, ntot, mstride);
 }
 
+// world > 1: this rank's slab of the cell order only (oct_slab_kernel); pbounds_host[world + 1] = the particle boundaries of all slabs
 template <int P, typename T, bool SYM>
-static int oct_eval(nbco_ctx *c, float *p, float *a, long long n, const float *param)
+static int oct_eval(nbco_ctx *c, float *p, float *a, long long n, const float *param, int world = 1, int rank = 0, long long *pbounds_host = nullptr)
 {
 	// SYM: fmm_cart3 (fmm_cart3_symmetric.cuh:413-580) -- multipole tuples in the symmetric layout, orders 0..P (offMP reals);
 	// the M2L kernel reads their first offM reals (orders 0..P-1: an order-P multipole only meets the order-0 local, which is not
@@ -495,6 +539,9 @@ static int oct_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 	int *group_off = nchunk + (m + 1), *desc_off = group_off + (m + 1), *chunk_off = desc_off + (m + 1);
 	int *m2l_cnt = chunk_off + (m + 1), *m2l_start = m2l_cnt + (ntot + 2);
 
+	int *slab = nullptr;            // device: this rank's slab, null = the whole cell order
+	long long *pbounds = nullptr;   // device: particle boundaries of all slabs
+	if (world > 64 || world < 1 || rank < 0 || rank >= world) return c->fail(NBCO_ERR_ARG, "nbco_fmm_oct_shard: 1 <= world <= 64, 0 <= rank < world");
 	float4 *pos_in = c->pos4_alt.as<float4>(), *pos = c->pos4.as<float4>();
 	uint32_t *keys_in = c->keys.as<uint32_t>(), *keys = keys_in + n;
 	uint32_t *idx_in = c->idx.as<uint32_t>(), *idx = c->idx_alt.as<uint32_t>();
@@ -514,6 +561,12 @@ static int oct_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 		NBCO_HIP(rocprim::radix_sort_pairs(c->sort_tmp.ptr, bytes, keys_in, keys, idx_in, idx, (size_t)n, 0u, (unsigned)(3 * L), st));
 		hipLaunchKernelGGL(oct_gather4_kernel, dim3(grid1d(n)), dim3(kBlock), 0, st, (const float4 *)pos_in, (const uint32_t *)idx, pos, n);
 		hipLaunchKernelGGL(oct_index_kernel<T>, dim3(grid1d(m + 1)), dim3(kBlock), 0, st, t, (const uint32_t *)keys);
+		if (world > 1)
+		{
+			slab = c->counters.as<int>() + 64;
+			pbounds = reinterpret_cast<long long *>(c->small.as<float>() + 128);
+			hipLaunchKernelGGL(oct_slab_kernel<T>, dim3(1), dim3(128), 0, st, t, world, rank, slab, pbounds);
+		}
 		NBCO_HIP(hipGetLastError());
 	}
 	// ---- P2M, M2M ----------------------------------------------------------------------------------------
@@ -537,11 +590,11 @@ static int oct_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 	{
 		PhaseScope ph(c, NBCO_PH_LISTS);
 		hipLaunchKernelGGL((oct_m2l_list_kernel<false, T>), dim3(grid1d(ntot)), dim3(kBlock), 0, st, t, radius, first, m2l_cnt, (const int *)nullptr, shift,
-		                   (uint64_t *)nullptr);
+		                   (uint64_t *)nullptr, (const int *)slab);
 		NBCO_TRY(scan_ints(c, m2l_cnt, m2l_start, (size_t)ntot + 1));
 		if (c->o.coll)
 		{
-			hipLaunchKernelGGL(oct_p2p_count_kernel<T>, dim3(grid1d(m + 1)), dim3(kBlock), 0, st, t, radius, tpl, ngroup, ndesc, nchunk);
+			hipLaunchKernelGGL(oct_p2p_count_kernel<T>, dim3(grid1d(m + 1)), dim3(kBlock), 0, st, t, radius, tpl, ngroup, ndesc, nchunk, (const int *)slab);
 			NBCO_TRY(scan_ints(c, ngroup, group_off, (size_t)m + 1));
 			NBCO_TRY(scan_ints(c, ndesc, desc_off, (size_t)m + 1));
 			NBCO_TRY(scan_ints(c, nchunk, chunk_off, (size_t)m + 1));
@@ -553,13 +606,14 @@ static int oct_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 			NBCO_HIP(hipMemcpyAsync(&h_tot[2], desc_off + m, sizeof(int), hipMemcpyDeviceToHost, st));
 			NBCO_HIP(hipMemcpyAsync(&h_tot[3], chunk_off + m, sizeof(int), hipMemcpyDeviceToHost, st));
 		}
+		if (pbounds_host && world > 1) NBCO_HIP(hipMemcpyAsync(pbounds_host, pbounds, sizeof(long long) * (size_t)(world + 1), hipMemcpyDeviceToHost, st));
 		NBCO_HIP(hipStreamSynchronize(st));   // the one host round trip of the evaluation: sizes of the work lists
 		const long long nm2l = h_tot[0], ngr = h_tot[1], nds = h_tot[2], nck = h_tot[3];
 		if (nm2l < 0 || nck < 0) return c->fail(NBCO_ERR_CAPACITY, "nbco_fmm_traceless: work list size overflows 32 bits");
 		NBCO_TRY(c->reserve(c->m2l_keys_alt, sizeof(uint64_t) * (size_t)(nm2l + 1)));
 		if (nm2l > 0)
 			hipLaunchKernelGGL((oct_m2l_list_kernel<true, T>), dim3(grid1d(ntot)), dim3(kBlock), 0, st, t, radius, first, (int *)nullptr, (const int *)m2l_start,
-			                   shift, c->m2l_keys_alt.as<uint64_t>());
+			                   shift, c->m2l_keys_alt.as<uint64_t>(), (const int *)slab);
 		if (c->o.coll)
 		{
 			NBCO_TRY(c->reserve(c->oct_groups, sizeof(int) * 3 * (size_t)(ngr + 1)));
@@ -568,7 +622,7 @@ static int oct_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 			NBCO_TRY(c->reserve(c->part, sizeof(float4) * (size_t)nck * (size_t)tpl + 256));
 			int *grp_index = c->oct_groups.as<int>(), *grp_mult = grp_index + (ngr + 1), *grp_cell = grp_mult + (ngr + 1);
 			hipLaunchKernelGGL(oct_p2p_fill_kernel<T>, dim3(grid1d(m)), dim3(kBlock), 0, st, t, radius, tpl, (const int *)group_off, (const int *)desc_off,
-			                   grp_index, grp_mult, grp_cell, c->p2p_keys.as<int2>());
+			                   grp_index, grp_mult, grp_cell, c->p2p_keys.as<int2>(), (const int *)slab);
 			hipLaunchKernelGGL(oct_p2p_chunk_kernel, dim3(grid1d(std::max<long long>(ngr, 1))), dim3(kBlock), 0, st, (const int *)(group_off + m),
 			                   (const int *)grp_cell, (const int *)group_off, (const int *)desc_off, (const int *)chunk_off, (const int *)grp_index,
 			                   (const int *)grp_mult, c->p2p_chunks.as<int4>());
@@ -599,14 +653,16 @@ static int oct_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 	}
 	{
 		PhaseScope ph(c, NBCO_PH_L2L);
-		for (int lc = 3; lc <= L; ++lc) hipLaunchKernelGGL((oct_l2l_kernel<P, T>), dim3((oct_cnt(lc) + kBlock - 1) / kBlock), dim3(kBlock), 0, st, t, lc);
+		for (int lc = 3; lc <= L; ++lc)
+			hipLaunchKernelGGL((oct_l2l_kernel<P, T>), dim3((oct_cnt(lc) + kBlock - 1) / kBlock), dim3(kBlock), 0, st, t, lc, (const int *)slab);
 		NBCO_HIP(hipGetLastError());
 	}
 	// ---- L2P + near field + rescale -------------------------------------------------------------------------
 	{
 		PhaseScope ph(c, NBCO_PH_L2P);
 		hipLaunchKernelGGL((oct_l2p_kernel<P, T>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, t, (const float4 *)pos, (const uint32_t *)keys,
-		                   (const float4 *)near, (const int *)group_off, (const int *)desc_off, (const int *)chunk_off, tpl, have_near ? 1 : 0, param, a);
+		                   (const float4 *)near, (const int *)group_off, (const int *)desc_off, (const int *)chunk_off, tpl, have_near ? 1 : 0, param, a,
+		                   (const int *)slab);
 		NBCO_HIP(hipGetLastError());
 	}
 	// ---- positions and velocities in cell order (fmm_cart3_traceless.cuh:386-392, :530-535) ------------------------
@@ -618,6 +674,7 @@ static int oct_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 		NBCO_HIP(hipMemcpyAsync(p + 3 * n, c->tmp3.ptr, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToDevice, st));
 		NBCO_HIP(hipGetLastError());
 	}
+	if (pbounds_host && world == 1) { pbounds_host[0] = 0; pbounds_host[1] = n; }
 	OctTreeDev &o = c->oct;
 	o.L = L; o.ntot = ntot; o.order = P; o.n = n; o.csz = t.csz; o.mpole = t.mpole; o.local = t.local; o.mult = t.mult; o.index = t.index;
 	o.keys = keys; o.perm = idx; o.m2l_entries = nm2l; o.p2p_groups = ngr; o.p2p_desc = h_tot[2]; o.p2p_chunks = nck; o.tpl = tpl;
@@ -629,7 +686,7 @@ static int oct_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 
 } // namespace
 
-int fmm_oct_traceless_eval(nbco_ctx *c, float *p, float *a, long long n, const float *param, bool symmetric)
+int fmm_oct_traceless_eval(nbco_ctx *c, float *p, float *a, long long n, const float *param, bool symmetric, int world, int rank, long long *pbounds_host)
 {
 	if (n <= 0) return c->fail(NBCO_ERR_ARG, "nbco_fmm_traceless: n must be positive");
 	if (n > 0x7fffffffLL / 4) return c->fail(NBCO_ERR_UNSUPPORTED, "nbco_fmm_traceless: n too large for 32-bit indices");
@@ -637,7 +694,7 @@ int fmm_oct_traceless_eval(nbco_ctx *c, float *p, float *a, long long n, const f
 	if (symmetric)
 	{
 		// symmetric multipoles of orders 0..p come from the generated operators of order p + 1: p <= 9
-#define NBCO_OCT_CASE(PP) case PP: return f64 ? oct_eval<PP, double, true>(c, p, a, n, param) : oct_eval<PP, float, true>(c, p, a, n, param);
+#define NBCO_OCT_CASE(PP) case PP: return f64 ? oct_eval<PP, double, true>(c, p, a, n, param, world, rank, pbounds_host) : oct_eval<PP, float, true>(c, p, a, n, param, world, rank, pbounds_host);
 		switch (c->o.fmm_order)
 		{
 		NBCO_OCT_CASE(1) NBCO_OCT_CASE(2) NBCO_OCT_CASE(3) NBCO_OCT_CASE(4) NBCO_OCT_CASE(5)
@@ -646,7 +703,7 @@ int fmm_oct_traceless_eval(nbco_ctx *c, float *p, float *a, long long n, const f
 		}
 #undef NBCO_OCT_CASE
 	}
-#define NBCO_OCT_CASE(PP) case PP: return f64 ? oct_eval<PP, double, false>(c, p, a, n, param) : oct_eval<PP, float, false>(c, p, a, n, param);
+#define NBCO_OCT_CASE(PP) case PP: return f64 ? oct_eval<PP, double, false>(c, p, a, n, param, world, rank, pbounds_host) : oct_eval<PP, float, false>(c, p, a, n, param, world, rank, pbounds_host);
 	switch (c->o.fmm_order)
 	{
 	NBCO_OCT_CASE(1) NBCO_OCT_CASE(2) NBCO_OCT_CASE(3) NBCO_OCT_CASE(4) NBCO_OCT_CASE(5)

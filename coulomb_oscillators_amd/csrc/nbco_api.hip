@@ -194,7 +194,8 @@ int nbco_destroy(nbco_ctx *c)
 	                  &c->unsort, &c->unsort_alt, &c->sort_tmp, &c->treebuf, &c->frontier_a, &c->frontier_b, &c->p2p_list,
 	                  &c->m2l_list, &c->counters, &c->p2p_keys, &c->p2p_keys_alt, &c->m2l_keys, &c->m2l_keys_alt,
 	                  &c->p2p_start, &c->m2l_start, &c->p2p_chunk_off, &c->p2p_chunks, &c->sel_hist, &c->sel_nodes, &c->sel_ties, &c->list_cnt,
-	                  &c->dist_top, &c->dist_tree, &c->oct_tree, &c->oct_groups, &c->scan_tmp_aux, &c->p2p_desc, &c->trav_ctr, &c->prep_state, &c->p2p_sec, &c->p2p_react, &c->order, &c->order_alt};
+	                  &c->dist_top, &c->dist_tree, &c->oct_tree, &c->oct_groups, &c->scan_tmp_aux, &c->p2p_desc, &c->trav_ctr, &c->prep_state, &c->p2p_sec, &c->p2p_react, &c->order, &c->order_alt,
+	                  &c->let_sel, &c->let_have, &c->dist_pos, &c->tmp3b};
 	if (c->aux && !c->aux_is_main) { hipStreamSynchronize(c->aux); hipStreamDestroy(c->aux); }
 	if (c->ev_fork) hipEventDestroy(c->ev_fork);
 	if (c->ev_join) hipEventDestroy(c->ev_join);
@@ -444,6 +445,15 @@ static int eval_kind(nbco_ctx *c, int kind, float *p, float *a, long long n, con
 	case NBCO_EVAL_FMM_SYMMETRIC: return fmm_oct_traceless_eval(c, p, a, n, param, true);
 	default: return c->fail(NBCO_ERR_ARG, "unknown evaluator kind");
 	}
+}
+
+// the uniform-octree evaluators on `world` GPUs: every rank holds the whole state and builds the whole tree, and evaluates the
+// accelerations of its slab of the cell order only (k_fmm_oct.hip, oct_slab_kernel)
+int nbco_fmm_oct_shard(nbco_ctx *c, float *p, float *a, long long n, const float *param, int symmetric, int world, int rank, long long *bounds_host)
+{
+	if (!c || !p || !a || !bounds_host) return c ? c->fail(NBCO_ERR_ARG, "nbco_fmm_oct_shard: null pointer") : NBCO_ERR_ARG;
+	NBCO_TRY(fmm_oct_traceless_eval(c, p, a, n, param, symmetric != 0, world, rank, bounds_host));
+	return maybe_sync(c);
 }
 
 int nbco_force(nbco_ctx *c, int kind, float *buf, long long n, const float *param, int elastic)

@@ -279,7 +279,8 @@ int kd_count_pairs(nbco_ctx *c, long long *out);
 int kd_energy_fmm(nbco_ctx *c, long long n_own, double *half_phi_sum);
 int launch_energy_kin_ela(nbco_ctx *c, const float *buf, long long n, const float *param, double *out2_host);
 // k_fmm_oct.hip
-int fmm_oct_traceless_eval(nbco_ctx *c, float *p, float *a, long long n, const float *param, bool symmetric = false);
+int fmm_oct_traceless_eval(nbco_ctx *c, float *p, float *a, long long n, const float *param, bool symmetric = false, int world = 1, int rank = 0,
+                           long long *pbounds_host = nullptr);
 int oct_copy_out(nbco_ctx *c, int which, void *host_dst, long long host_bytes);
 // multi-GPU kd-domain sharding (k_fmm_kd.hip)
 int kd_dist_layout(nbco_ctx *c, long long n_global, int world, int rank, nbco_dist_layout *out);

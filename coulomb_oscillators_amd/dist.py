@@ -429,3 +429,105 @@ class LoopbackWorld:
             if elastic and param is not None:
                 r.eng.add_elastic(r.pos, r.acc, r.n_local, param[3:])
             r.evals += 1
+
+
+class SlabRun:
+    """The uniform-octree evaluators (nbco_fmm_traceless / nbco_fmm_symmetric) on G GPUs: slabs of the sorted cell keys.
+
+    Every rank holds the whole state [pos | vel | acc] and builds the whole tree; rank r evaluates the accelerations of its slab
+    of the cell order (``nbco_fmm_oct_shard``), one all-gather of the slabs (padded to the largest) completes the array on every
+    rank, and every rank integrates all particles.  The result equals the single-GPU evaluation bit for bit.
+    """
+
+    def __init__(self, engine, n, comm, device=None, symmetric=False):
+        self.eng, self.comm = engine, comm
+        self.world, self.rank = comm.world, comm.rank
+        self.n = int(n)
+        self.symmetric = bool(symmetric)
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.buf = torch.zeros(9 * self.n, dtype=torch.float32, device=self.device)
+        self._pad = None
+        self.bounds = None
+
+    @property
+    def pos(self):
+        return self.buf[: 3 * self.n]
+
+    @property
+    def vel(self):
+        return self.buf[3 * self.n: 6 * self.n]
+
+    @property
+    def acc(self):
+        return self.buf[6 * self.n:]
+
+    def set_state(self, pos, vel):
+        self.pos.copy_(pos.reshape(-1))
+        self.vel.copy_(vel.reshape(-1))
+
+    def exchange_bytes(self):
+        """bytes this rank receives per evaluation (the padded all-gather of the acceleration slabs)"""
+        if self.bounds is None:
+            return 0
+        mx = max(b - a for a, b in zip(self.bounds[:-1], self.bounds[1:]))
+        return (self.world - 1) * 12 * mx
+
+    def slab(self, param):
+        """this rank's part of the evaluation; returns (send block, largest slab, boundaries)"""
+        b = self.eng.fmm_oct_shard(self.buf, self.acc, self.n, param, self.world, self.rank, symmetric=self.symmetric)
+        self.bounds = b
+        mx = max(max(y - x for x, y in zip(b[:-1], b[1:])), 1)
+        if self._pad is None or self._pad[0].numel() < 3 * mx:
+            cap = int(3 * mx * 1.25) + 64
+            self._pad = (torch.zeros(cap, dtype=torch.float32, device=self.device), torch.zeros(self.world * cap, dtype=torch.float32, device=self.device))
+        send = self._pad[0][: 3 * mx]
+        lo, hi = b[self.rank], b[self.rank + 1]
+        send[: 3 * (hi - lo)].copy_(self.acc[3 * lo: 3 * hi])
+        return send, mx, b
+
+    def assemble(self, recv, mx, b):
+        for r in range(self.world):
+            if r != self.rank and b[r + 1] > b[r]:
+                self.acc[3 * b[r]: 3 * b[r + 1]].copy_(recv[3 * mx * r: 3 * mx * r + 3 * (b[r + 1] - b[r])])
+
+    def force(self, param=None, elastic=True):
+        send, mx, b = self.slab(param)
+        if self.world > 1:
+            recv = self._pad[1][: self.world * 3 * mx]
+            self.comm.all_gather(recv, send)
+            self.assemble(recv, mx, b)
+        if elastic and param is not None:
+            self.eng.add_elastic(self.pos, self.acc, self.n, param[3:])
+
+    def leapfrog(self, param, dt, elastic=True):
+        n = self.n
+        self.eng.step(self.vel, self.acc, 0.5 * dt, n)
+        self.eng.step(self.pos, self.vel, dt, n)
+        self.force(param, elastic)
+        self.eng.step(self.vel, self.acc, 0.5 * dt, n)
+
+
+class LoopbackSlabs:
+    """G SlabRuns in lockstep on one card (tests): the all-gather becomes a concatenation"""
+
+    class _Comm:
+        def __init__(self, world, rank):
+            self.world, self.rank = world, rank
+
+    def __init__(self, engines, n, device=None, symmetric=False):
+        G = len(engines)
+        self.runs = [SlabRun(e, n, LoopbackSlabs._Comm(G, r), device=device, symmetric=symmetric) for r, e in enumerate(engines)]
+
+    def set_state(self, pos, vel):
+        for r in self.runs:
+            r.set_state(pos, vel)
+
+    def force(self, param=None, elastic=True):
+        parts = [r.slab(param) for r in self.runs]
+        mx, b = parts[0][1], parts[0][2]
+        assert all(p[1] == mx and p[2] == b for p in parts), "the ranks disagree on the slab boundaries"
+        recv = torch.cat([p[0] for p in parts])
+        for r in self.runs:
+            r.assemble(recv, mx, b)
+            if elastic and param is not None:
+                r.eng.add_elastic(r.pos, r.acc, r.n, param[3:])

@@ -101,6 +101,7 @@ def _load():
         "nbco_fmm_kdtree": [P, P, P, LL, P],
         "nbco_fmm_traceless": [P, P, P, LL, P],
         "nbco_fmm_symmetric": [P, P, P, LL, P],
+        "nbco_fmm_oct_shard": [P, P, P, LL, P, I, I, I, C.POINTER(LL)],
         "nbco_force": [P, I, P, LL, P, I],
         "nbco_integrate": [P, I, I, P, LL, P, D, D, I],
         "nbco_integrate_steps": [P, I, I, P, LL, P, D, D, I, I],
@@ -244,6 +245,12 @@ class Engine:
     def fmm_cart3(self, p, a, n, param=None):
         """the uniform-octree evaluator with symmetric multipoles (fmm_cart3_symmetric.cuh:413)"""
         self._chk(self.lib.nbco_fmm_symmetric(self.ctx, _ptr(p), _ptr(a), n, _ptr(param)))
+
+    def fmm_oct_shard(self, p, a, n, param, world, rank, symmetric=False):
+        """this rank's slab of the uniform-octree evaluation (nbco_fmm_oct_shard); returns the particle boundaries of all slabs"""
+        b = (C.c_longlong * (world + 1))()
+        self._chk(self.lib.nbco_fmm_oct_shard(self.ctx, _ptr(p), _ptr(a), n, _ptr(param), int(symmetric), world, rank, b))
+        return list(b)
 
     def compute_force(self, kind, buf, n, param, elastic=True):
         self._chk(self.lib.nbco_force(self.ctx, kind, _ptr(buf), n, _ptr(param), int(elastic)))

@@ -208,6 +208,18 @@ enum {
 };
 int nbco_oct_copy(nbco_ctx *c, int which, void *host_dst, long long host_bytes);
 
+/* ---- multi-GPU, uniform-octree evaluators: slabs of the sorted cell keys (fmm_cart3_traceless.cuh:196-254 and
+ *      appel.cuh:320-381 are the single-GPU passes) ----
+ * Every rank holds the whole state buf = [pos | vel | ..] and calls this with the same arguments but its own rank: the tree
+ * and the upward pass are built redundantly (O(N)), M2L / L2L / P2P / L2P only for the rank's slab -- the leaf cells
+ * [c_r, c_r+1) of the key order (x-layers), c_r = the first cell whose first particle is >= n r / world.  p and the
+ * velocities behind it are re-ordered into cell order exactly as by nbco_fmm_traceless (identically on every rank);
+ * a[3 i], i in [bounds_host[rank], bounds_host[rank + 1]) are written, the other accelerations are left alone --
+ * bounds_host[0 .. world] (host) are the particle boundaries of all slabs, so the caller can all-gather the pieces.
+ * Each written acceleration is bit-identical to the single-GPU nbco_fmm_traceless / nbco_fmm_symmetric. */
+int nbco_fmm_oct_shard(nbco_ctx *c, float *p, float *a, long long n, const float *param, int symmetric, int world, int rank,
+                       long long *bounds_host);
+
 /* ---- multi-GPU: kd-domain sharding (the reference is single-GPU, the sharded tree is the
  *      balanced kd-tree of fmm_cart3_kdtree.cuh:109-137 whose level-log2(G) nodes hold N/G particles each) ----
  * One process per GPU, each with its own nbco_ctx.  This library never communicates: the caller moves
