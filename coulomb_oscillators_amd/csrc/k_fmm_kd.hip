@@ -2415,6 +2415,26 @@ int kd_dist_layout(nbco_ctx *c, long long n_global, int world, int rank, nbco_di
 	return NBCO_OK;
 }
 
+// the top-tree arrays for k_dpart.hip (levels 0 .. d)
+int kd_dist_top_arrays(nbco_ctx *c, int ntop, float **lb, float **rb, int **sd, int **index)
+{
+	NBCO_TRY(c->reserve(c->dist_top, (size_t)ntop * 32 + 64));
+	const TopView v = top_view(c, ntop);
+	*lb = v.lbound; *rb = v.rbound; *sd = v.splitdim; *index = v.index;
+	return NBCO_OK;
+}
+// what nbco_dist_partition leaves behind besides the domain's state and the top boxes
+int kd_dist_set_partitioned(nbco_ctx *c, long long n_global, int world, int rank)
+{
+	nbco_dist_layout lay;
+	NBCO_TRY(kd_dist_layout(c, n_global, world, rank, &lay));
+	c->dist.world = world; c->dist.rank = rank; c->dist.d = lay.d; c->dist.n_global = n_global; c->dist.n_local = lay.n_local; c->dist.L = lay.L;
+	c->dist.partitioned = true;
+	c->dist.build_done = c->dist.local_done = c->dist.traversed = c->dist.let_selected = c->dist.let_packed = false;
+	c->tree_valid = false;
+	return NBCO_OK;
+}
+
 // state_all = [pos N x 3 | vel N x 3] (every rank passes the same gathered state), state_local = [pos | vel] of
 // the rank's domain in partition order.
 int kd_dist_partition(nbco_ctx *c, const float *state_all, long long n_global, int world, int rank, float *state_local)

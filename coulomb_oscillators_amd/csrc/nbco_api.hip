@@ -195,7 +195,7 @@ int nbco_destroy(nbco_ctx *c)
 	                  &c->m2l_list, &c->counters, &c->p2p_keys, &c->p2p_keys_alt, &c->m2l_keys, &c->m2l_keys_alt,
 	                  &c->p2p_start, &c->m2l_start, &c->p2p_chunk_off, &c->p2p_chunks, &c->sel_hist, &c->sel_nodes, &c->sel_ties, &c->list_cnt,
 	                  &c->dist_top, &c->dist_tree, &c->oct_tree, &c->oct_groups, &c->scan_tmp_aux, &c->p2p_desc, &c->trav_ctr, &c->prep_state, &c->p2p_sec, &c->p2p_react, &c->order, &c->order_alt,
-	                  &c->let_sel, &c->let_have, &c->dist_pos, &c->tmp3b};
+	                  &c->let_sel, &c->let_have, &c->dist_pos, &c->tmp3b, &c->dpart_buf};
 	if (c->aux && !c->aux_is_main) { hipStreamSynchronize(c->aux); hipStreamDestroy(c->aux); }
 	if (c->ev_fork) hipEventDestroy(c->ev_fork);
 	if (c->ev_join) hipEventDestroy(c->ev_join);
@@ -408,6 +408,21 @@ int nbco_dist_let_check(nbco_ctx *c)
 {
 	if (!c) return NBCO_ERR_ARG;
 	return kd_dist_let_check(c);
+}
+int nbco_dist_repartition_workspace(nbco_ctx *c, long long n_global, int world, long long *bytes)
+{
+	if (!c || !bytes) return c ? c->fail(NBCO_ERR_ARG, "nbco_dist_repartition_workspace: null pointer") : NBCO_ERR_ARG;
+	return dpart_workspace(c, n_global, world, bytes);
+}
+int nbco_dist_repartition_begin(nbco_ctx *c, float *state_local, long long n_global, int world, int rank, void *work, long long work_bytes, nbco_dist_step *next)
+{
+	if (!c || !state_local || !work || !next) return c ? c->fail(NBCO_ERR_ARG, "nbco_dist_repartition_begin: null pointer") : NBCO_ERR_ARG;
+	return dpart_begin(c, state_local, n_global, world, rank, work, work_bytes, next);
+}
+int nbco_dist_repartition_next(nbco_ctx *c, nbco_dist_step *next)
+{
+	if (!c || !next) return c ? c->fail(NBCO_ERR_ARG, "nbco_dist_repartition_next: null pointer") : NBCO_ERR_ARG;
+	return dpart_next(c, next);
 }
 int nbco_dist_finish_traverse(nbco_ctx *c, const void *csz_all, const void *pos_all)
 {

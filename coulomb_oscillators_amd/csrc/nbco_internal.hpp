@@ -201,6 +201,18 @@ struct nbco_ctx
 		return false;
 	}
 	long long list_cap = 0;
+	// distributed re-partition in progress (k_dpart.hip)
+	struct DPart
+	{
+		int stage = 0, level = 0, pass = 0, world = 0, rank = 0, d = 0;
+		long long n_global = 0, n_local = 0;
+		float *state = nullptr;
+		void *work = nullptr;
+		size_t tie_bytes = 0;
+		bool seg_flip = false, pos_flip = false;
+		long long rows_send[64] = {}, rows_recv[64] = {};
+	} dpart;
+	DevBuf dpart_buf;
 	// the last kd-tree evaluation, for nbco_energy_fmm (pointers into the context's buffers; valid while tree_valid)
 	struct LastEval
 	{
@@ -285,6 +297,9 @@ int oct_copy_out(nbco_ctx *c, int which, void *host_dst, long long host_bytes);
 // multi-GPU kd-domain sharding (k_fmm_kd.hip)
 int kd_dist_layout(nbco_ctx *c, long long n_global, int world, int rank, nbco_dist_layout *out);
 int kd_dist_partition(nbco_ctx *c, const float *state_all, long long n_global, int world, int rank, float *state_local);
+int dpart_workspace(nbco_ctx *c, long long n_global, int world, long long *bytes);
+int dpart_begin(nbco_ctx *c, float *state_local, long long n_global, int world, int rank, void *work, long long work_bytes, nbco_dist_step *out);
+int dpart_next(nbco_ctx *c, nbco_dist_step *out);
 int kd_finish_pending_order(nbco_ctx *c, float *p, long long n);
 int kd_turnaround(nbco_ctx *c, float *p, const float *v_in, const float **v_now, const float *param, float ks, float ds, bool elastic, long long n);
 int kd_dist_let_select(nbco_ctx *c, const void *csz_all, long long *counts);

@@ -54,6 +54,18 @@ class TorchComm:
             return _Done()
         return self.dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True)
 
+    def all_reduce_i32(self, t, op):
+        """in-place MIN / SUM of an int32 tensor"""
+        if self.world == 1:
+            return
+        rop = self.dist.ReduceOp.MIN if op == "min" else self.dist.ReduceOp.SUM
+        if self.dist.get_backend(self.group) == "gloo" and t.is_cuda:
+            host = t.cpu()
+            self.dist.all_reduce(host, op=rop, group=self.group)
+            t.copy_(host)
+        else:
+            self.dist.all_reduce(t, op=rop, group=self.group)
+
     def all_to_all(self, out, inp, out_rows, in_rows):
         """variable all-to-all along dim 0: in_rows[r] rows of `inp` go to rank r, out_rows[s] rows of `out` come from rank s"""
         if self.world == 1:
@@ -93,8 +105,28 @@ class SingleComm:
     def all_to_all(self, out, inp, out_rows, in_rows):
         out.copy_(inp)
 
+    def all_reduce_i32(self, t, op):
+        return
+
     def all_reduce(self, t, op="sum"):
         return t
+
+
+def run_dist_step(comm, work, st):
+    """the collective a nbco_dist_step describes, on the uint8 workspace tensor `work` (include/nbco.h)"""
+    G = comm.world
+    if st.op in (1, 2):
+        comm.all_reduce_i32(work[st.send_off: st.send_off + 4 * st.count].view(torch.int32), "min" if st.op == 1 else "sum")
+    elif st.op == 3:
+        comm.all_gather(work[st.recv_off: st.recv_off + G * st.count], work[st.send_off: st.send_off + st.count])
+    elif st.op == 4:
+        w = st.row_bytes // 4
+        rs, rr = [int(st.rows_send[r]) for r in range(G)], [int(st.rows_recv[r]) for r in range(G)]
+        inp = work[st.send_off: st.send_off + st.row_bytes * sum(rs)].view(torch.float32).view(-1, w)
+        out = work[st.recv_off: st.recv_off + st.row_bytes * sum(rr)].view(torch.float32).view(-1, w)
+        comm.all_to_all(out, inp, rr, rs)
+    else:
+        raise ValueError("unknown nbco_dist_step op %d" % st.op)
 
 
 class DomainRun:
@@ -104,7 +136,7 @@ class DomainRun:
     ctypes Engine, or a test double with the same methods for the CPU tests).
     """
 
-    def __init__(self, engine, n_global, comm, device=None, rebalance=8, let=None):
+    def __init__(self, engine, n_global, comm, device=None, rebalance=8, let=None, gather_partition=None):
         self.eng = engine
         self.comm = comm
         self.world, self.rank = comm.world, comm.rank
@@ -116,7 +148,14 @@ class DomainRun:
         f32, u8 = torch.float32, torch.uint8
         nl, G = self.n_local, self.world
         self.buf = torch.zeros(9 * nl, dtype=f32, device=self.device)          # [pos | vel | acc], float3 AoS each
-        self.state_all = torch.empty(6 * self.n_global, dtype=f32, device=self.device)
+        # re-partition: distributed (no rank gathers the state) when engine and transport offer it; gather_partition=True keeps
+        # the all-gather + redundant selection (nbco_dist_partition)
+        can_dpart = all(hasattr(engine, m) for m in ("dist_repartition_begin", "dist_repartition_next")) and hasattr(comm, "all_reduce_i32") \
+            and hasattr(comm, "all_to_all") and self.world <= 32
+        self.dpart = can_dpart and not gather_partition
+        self.state_all = None if self.dpart else torch.empty(6 * self.n_global, dtype=f32, device=self.device)
+        self.work = torch.empty(engine.dist_repartition_workspace(self.n_global, self.world), dtype=u8, device=self.device) if self.dpart else None
+        self.partition_bytes = None
         self.nodes_send = torch.empty(int(self.lay.nodes_bytes), dtype=u8, device=self.device)
         self.pos_send = torch.empty(int(self.lay.pos_bytes), dtype=u8, device=self.device)
         self.nodes_all = torch.empty(G * int(self.lay.nodes_bytes), dtype=u8, device=self.device)
@@ -175,6 +214,28 @@ class DomainRun:
         nl, N = self.n_local, self.n_global
         pos_mine = self.pos if pos_mine is None else pos_mine
         vel_mine = self.vel if vel_mine is None else vel_mine
+        if self.dpart:
+            # no rank ever holds more than its own particles: histograms, ties and bounds through small collectives, then one
+            # all-to-all of [pos | vel] by destination (nbco_dist_repartition_*)
+            if pos_mine.data_ptr() != self.pos.data_ptr():
+                self.pos.copy_(pos_mine.reshape(-1))
+            if vel_mine.data_ptr() != self.vel.data_ptr():
+                self.vel.copy_(vel_mine.reshape(-1))
+            moved = 0
+            st = self.eng.dist_repartition_begin(self.buf, N, self.world, self.rank, self.work)
+            while st.op != 0:
+                run_dist_step(self.comm, self.work, st)
+                if st.op == 4:
+                    moved = st.row_bytes * (sum(int(st.rows_recv[r]) for r in range(self.world)) - int(st.rows_recv[self.rank]))
+                elif st.op == 3:
+                    moved += (self.world - 1) * st.count
+                else:
+                    moved += 2 * 4 * st.count   # (an all-reduce moves about twice its payload per rank)
+                st = self.eng.dist_repartition_next()
+            self.partition_bytes = moved
+            self.evals = 0
+            return
+        self.partition_bytes = (self.world - 1) * 24 * nl
         self.comm.all_gather(self.state_all[: 3 * N], pos_mine.contiguous().view(-1))
         self.comm.all_gather(self.state_all[3 * N:], vel_mine.contiguous().view(-1))
         self.eng.dist_partition(self.state_all, N, self.world, self.rank, self.buf)
@@ -338,18 +399,58 @@ class LoopbackWorld:
         def all_gather_start(self, out, inp):
             raise RuntimeError("loopback domains exchange through LoopbackWorld")
 
-        all_to_all = all_gather
+        all_to_all = all_reduce_i32 = all_gather
 
-    def __init__(self, engines, n_global, device=None, rebalance=0):
+    def __init__(self, engines, n_global, device=None, rebalance=0, gather_partition=None):
         G = len(engines)
-        self.runs = [DomainRun(e, n_global, LoopbackWorld._Comm(G, r), device=device, rebalance=rebalance) for r, e in enumerate(engines)]
+        self.runs = [DomainRun(e, n_global, LoopbackWorld._Comm(G, r), device=device, rebalance=rebalance, gather_partition=gather_partition)
+                     for r, e in enumerate(engines)]
         self.G = G
 
     def partition(self, pos_parts, vel_parts):
+        if all(r.dpart for r in self.runs):
+            return self._repartition(pos_parts, vel_parts)
         state = torch.cat([torch.cat([p.reshape(-1) for p in pos_parts]), torch.cat([v.reshape(-1) for v in vel_parts])])
         for r in self.runs:
             r.state_all.copy_(state)
             r.eng.dist_partition(r.state_all, r.n_global, r.world, r.rank, r.buf)
+            r.evals = 0
+
+    def _repartition(self, pos_parts, vel_parts):
+        """nbco_dist_repartition_* in lockstep: every collective becomes arithmetic over the ranks' workspaces"""
+        runs, G = self.runs, self.G
+        for r, p, v in zip(runs, pos_parts, vel_parts):
+            if p.data_ptr() != r.pos.data_ptr():
+                r.pos.copy_(p.reshape(-1))
+            if v.data_ptr() != r.vel.data_ptr():
+                r.vel.copy_(v.reshape(-1))
+        sts = [r.eng.dist_repartition_begin(r.buf, r.n_global, G, r.rank, r.work) for r in runs]
+        while sts[0].op != 0:
+            op = sts[0].op
+            assert all(s_.op == op and s_.count == sts[0].count for s_ in sts)
+            st = sts[0]
+            if op in (1, 2):
+                views = [r.work[st.send_off: st.send_off + 4 * st.count].view(torch.int32) for r in runs]
+                stack = torch.stack(views)
+                red = stack.min(0).values if op == 1 else stack.sum(0, dtype=torch.int32)
+                for v in views:
+                    v.copy_(red)
+            elif op == 3:
+                allb = torch.cat([r.work[st.send_off: st.send_off + st.count] for r in runs])
+                for r in runs:
+                    r.work[st.recv_off: st.recv_off + G * st.count].copy_(allb)
+            elif op == 4:
+                w = st.row_bytes
+                for r, sr in zip(runs, sts):
+                    parts = []
+                    for s_, ss in zip(runs, sts):
+                        off = ss.send_off + w * sum(int(ss.rows_send[q]) for q in range(r.rank))
+                        assert int(ss.rows_send[r.rank]) == int(sr.rows_recv[s_.rank])
+                        parts.append(s_.work[off: off + w * int(ss.rows_send[r.rank])])
+                    got = torch.cat(parts)
+                    r.work[sr.recv_off: sr.recv_off + got.numel()].copy_(got)
+            sts = [r.eng.dist_repartition_next() for r in runs]
+        for r in runs:
             r.evals = 0
 
     def force_let(self, param=None, elastic=True, tamper=None):

@@ -56,6 +56,15 @@ class DistLayout(C.Structure):
                 ("mpole_bytes", C.c_longlong), ("let_node_bytes", C.c_longlong), ("let_counts", C.c_int)]
 
 
+class DistStep(C.Structure):
+    """nbco_dist_step: the collective a distributed re-partition asks its caller to run next (include/nbco.h)"""
+    _fields_ = [("op", C.c_int), ("row_bytes", C.c_int), ("send_off", C.c_longlong), ("recv_off", C.c_longlong), ("count", C.c_longlong),
+                ("rows_send", C.c_longlong * 64), ("rows_recv", C.c_longlong * 64)]
+
+
+COLL_DONE, COLL_ALLREDUCE_MIN_I32, COLL_ALLREDUCE_SUM_I32, COLL_ALLGATHER, COLL_ALLTOALL = range(5)
+
+
 def lib_path():
     return _LIB
 
@@ -124,6 +133,9 @@ def _load():
         "nbco_dist_local_mpole": [P, P, LL, P],
         "nbco_dist_finish_traverse": [P, P, P],
         "nbco_dist_finish_rest": [P, P, P, P, P],
+        "nbco_dist_repartition_workspace": [P, LL, I, C.POINTER(LL)],
+        "nbco_dist_repartition_begin": [P, P, LL, I, I, P, LL, C.POINTER(DistStep)],
+        "nbco_dist_repartition_next": [P, C.POINTER(DistStep)],
         "nbco_dist_let_local_geom": [P, P, LL, P],
         "nbco_dist_let_local_mpole": [P, P, LL],
         "nbco_dist_let_select": [P, P, P],
@@ -319,6 +331,23 @@ class Engine:
 
     def dist_finish_rest(self, mpole_all, buf_local, a_local, param=None):
         self._chk(self.lib.nbco_dist_finish_rest(self.ctx, _ptr(mpole_all), _ptr(buf_local), _ptr(a_local), _ptr(param)))
+
+    # the re-partition without gathering the state (include/nbco.h: nbco_dist_repartition_*)
+    def dist_repartition_workspace(self, n_global, world):
+        b = C.c_longlong()
+        self._chk(self.lib.nbco_dist_repartition_workspace(self.ctx, n_global, world, C.byref(b)))
+        return int(b.value)
+
+    def dist_repartition_begin(self, state_local, n_global, world, rank, work):
+        st = DistStep()
+        self._chk(self.lib.nbco_dist_repartition_begin(self.ctx, _ptr(state_local), n_global, world, rank, _ptr(work), work.numel() * work.element_size(),
+                                                       C.byref(st)))
+        return st
+
+    def dist_repartition_next(self):
+        st = DistStep()
+        self._chk(self.lib.nbco_dist_repartition_next(self.ctx, C.byref(st)))
+        return st
 
     # the same evaluation with the LET exchange (include/nbco.h: nbco_dist_let_*)
     def dist_let_local_geom(self, buf_local, n_local, csz_send):

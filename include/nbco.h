@@ -255,6 +255,34 @@ typedef struct nbco_dist_layout {
 int nbco_dist_layout_query(nbco_ctx *c, long long n_global, int world, int rank, nbco_dist_layout *out);
 int nbco_dist_partition(nbco_ctx *c, const float *state_all, long long n_global, int world, int rank, float *state_local);
 int nbco_dist_local(nbco_ctx *c, float *buf_local, long long n_local, void *nodes_send, void *pos_send);
+/* The same re-partition WITHOUT gathering the state (no rank ever holds more than its own n_local particles): per level the
+ * exact medians by a radix select whose histograms are summed across the ranks, pivot ties ordered by the stable-sort chain's
+ * remaining keys, evalBox for the children, local partition; then one all-to-all of [pos | vel] by destination.  Top boxes,
+ * split axes and the particle set of every domain equal nbco_dist_partition's (the order inside a domain is arbitrary in both).
+ * The library never communicates: _begin / _next run the local stages and describe, in *next, the collective the caller runs
+ * on its workspace (device memory, _workspace bytes) before calling _next again, until op == NBCO_COLL_DONE:
+ *   ALLREDUCE_MIN_I32 / ALLREDUCE_SUM_I32   in place, `count` int32 at work + send_off
+ *   ALLGATHER                               `count` bytes at work + send_off -> world x count bytes at work + recv_off (rank order)
+ *   ALLTOALL                                records of row_bytes: rows_send[r] rows for rank r, consecutive from work + send_off;
+ *                                           rows_recv[s] rows from rank s, consecutive at work + recv_off
+ * state_local = [pos n_local x 3 | vel n_local x 3] is replaced by the rank's new domain.  world <= 32.  More than 64 particles
+ * of one rank tying with a pivot: NBCO_ERR_UNSUPPORTED (nbco_dist_partition handles any input). */
+enum {
+	NBCO_COLL_DONE = 0,
+	NBCO_COLL_ALLREDUCE_MIN_I32 = 1,
+	NBCO_COLL_ALLREDUCE_SUM_I32 = 2,
+	NBCO_COLL_ALLGATHER = 3,
+	NBCO_COLL_ALLTOALL = 4
+};
+typedef struct nbco_dist_step {
+	int op, row_bytes;
+	long long send_off, recv_off, count;
+	long long rows_send[64], rows_recv[64];
+} nbco_dist_step;
+int nbco_dist_repartition_workspace(nbco_ctx *c, long long n_global, int world, long long *bytes);
+int nbco_dist_repartition_begin(nbco_ctx *c, float *state_local, long long n_global, int world, int rank, void *work,
+                                long long work_bytes, nbco_dist_step *next);
+int nbco_dist_repartition_next(nbco_ctx *c, nbco_dist_step *next);
 /* nbco_dist_local in two halves, so that the all-gather of the positions can run beside the upward pass:
  * _build fills pos_send (subtree build), _upward fills nodes_send (multipoles). */
 int nbco_dist_local_build(nbco_ctx *c, float *buf_local, long long n_local, void *pos_send);

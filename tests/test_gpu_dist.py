@@ -125,11 +125,12 @@ def test_far_field_waits_on_the_second_stream(oracle32):
     assert torch.equal(got, want)
 
 
-def loopback(n, G, pos, vel, **opts):
+def loopback(n, G, pos, vel, gather_partition=None, **opts):
+    """(the domains are cut by the distributed re-partition, nbco_dist_repartition_*, unless gather_partition is set)"""
     import torch
     from coulomb_oscillators_amd import Engine, LoopbackWorld
     engines = [Engine(**opts) for _ in range(G)]
-    world = LoopbackWorld(engines, n)
+    world = LoopbackWorld(engines, n, gather_partition=gather_partition)
     nl = n // G
     # the initial ownership is arbitrary: contiguous slices of the caller's order
     world.partition([torch.from_numpy(pos[r * nl:(r + 1) * nl]).cuda() for r in range(G)],
@@ -244,6 +245,71 @@ def test_let_lists_grow_on_demand(oracle32, mutual):
         r.eng.dist_let_check()
     assert torch.equal(torch.cat([torch.cat([r.pos for r in w.runs]), torch.cat([r.vel for r in w.runs])]), ref[:6 * n])
     assert same_acc(torch.cat([r.acc for r in w.runs]), ref[6 * n:], mutual, n)
+
+
+def _rows(t, n):
+    """rows [x y z vx vy vz] of a domain's state, sorted: the particle SET"""
+    a = np.concatenate([t[:3 * n].cpu().numpy().reshape(n, 3), t[3 * n:6 * n].cpu().numpy().reshape(n, 3)], axis=1)
+    return a[np.lexsort(a.T[::-1])]
+
+
+@pytest.mark.parametrize("n,G,kind", [(32768, 2, "reference"), (65536, 8, "clumps"), (40000, 4, "uniform"), (1 << 20, 8, "reference"), (32768, 1, "uniform"),
+                                      (131072, 16, "reference")])
+def test_distributed_repartition_equals_gathered_partition(oracle32, n, G, kind):
+    """nbco_dist_repartition_* (no rank gathers the state) and nbco_dist_partition (all-gather + redundant selection) cut the same
+    domains: same particle sets, and after one evaluation the same tree-ordered state bit for bit"""
+    import torch
+    pos, vel = make_state(oracle32, n, kind)
+    par = torch.from_numpy(oracle32.params(n)).cuda()
+    opts = dict(fmm_order=4, unsort=0, tree_steps=1)
+    a = loopback(n, G, pos, vel, gather_partition=True, **opts)
+    b = loopback(n, G, pos, vel, **opts)
+    assert all(r.dpart for r in b.runs) and not any(r.dpart for r in a.runs)
+    nl = n // G
+    for ra, rb in zip(a.runs, b.runs):
+        np.testing.assert_array_equal(_rows(ra.buf, nl), _rows(rb.buf, nl))
+        assert rb.partition_bytes is not None
+    if G > 1:
+        assert sum(r.partition_bytes for r in b.runs) < sum(r.partition_bytes for r in a.runs)
+    a.force(par, elastic=False)
+    b.force(par, elastic=False)
+    torch.cuda.synchronize()
+    for ra, rb in zip(a.runs, b.runs):
+        assert torch.equal(ra.buf, rb.buf)
+    # a second cut from the evolved, domain-ordered state: few particles move
+    for w in (a, b):
+        for r in w.runs:
+            r.eng.step(r.pos, r.vel, 0.05, nl)
+        w.partition([r.pos for r in w.runs], [r.vel for r in w.runs])
+    for ra, rb in zip(a.runs, b.runs):
+        np.testing.assert_array_equal(_rows(ra.buf, nl), _rows(rb.buf, nl))
+    if G > 1:
+        assert sum(r.partition_bytes for r in b.runs) < 0.5 * sum(r.partition_bytes for r in a.runs)
+
+
+def test_distributed_repartition_orders_pivot_ties_like_the_sort_chain(oracle32):
+    """particles that tie with a pivot on the split axis, spread over several ranks: the first `need` of them in the order
+    (next ancestor axes, original index) go left -- same domains as the gathered selection"""
+    import torch
+    n, G = 32768, 4
+    pos, vel = make_state(oracle32, n, "uniform")
+    rng = np.random.default_rng(3)
+    # the root splits along its longest axis; give 40 particles scattered over the input exactly the median coordinate of that axis,
+    # and another 30 the median of the left half along ITS axis
+    ax = int(np.argmax(pos.max(0) - pos.min(0)))
+    med = np.sort(pos[:, ax])[n // 2 - 1]
+    pos[rng.choice(n, 40, replace=False), ax] = med
+    left = np.flatnonzero(pos[:, ax] < med)
+    ext = pos[left].max(0) - pos[left].min(0)
+    ax2 = int(np.argmax(ext))
+    med2 = np.sort(pos[left, ax2])[len(left) // 2]
+    pos[rng.choice(left, 30, replace=False), ax2] = med2
+    opts = dict(fmm_order=3, unsort=0, tree_steps=1)
+    a = loopback(n, G, pos, vel, gather_partition=True, **opts)
+    b = loopback(n, G, pos, vel, **opts)
+    nl = n // G
+    for ra, rb in zip(a.runs, b.runs):
+        np.testing.assert_array_equal(_rows(ra.buf, nl), _rows(rb.buf, nl))
 
 
 def test_sharded_matches_oracle(oracle32):
