@@ -15,6 +15,8 @@
 #include "nbco_internal.hpp"
 #include "kd_common.hpp"
 #include <climits>
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 
 namespace {
@@ -99,6 +101,17 @@ __global__ void dp_root_kernel(const int *__restrict__ mm, TopArrays t)
 	t.index[0] = 0;
 }
 
+// A particle as a whole.  With `axis_of(P[i], axis)` the compiler narrows the 16-byte load to one dword at a SELECTED ADDRESS, and
+// the code it emitted for that select (hipcc 7.2, gfx950) leaves the address register unset when axis == 2: a wild load, i.e. a
+// GPU memory fault as soon as a node splits along z (found on the first uniform test input).  The empty asm makes all four
+// components live, so the load stays a dwordx4 and the select happens on values.
+__device__ inline float4 load_particle(const float4 *__restrict__ P, long long i)
+{
+	float4 v = P[i];
+	asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+	return v;
+}
+
 __device__ inline uint32_t window_key(const float4 p, const DpNode &n) { return (ordered_bits(axis_of(p, n.axis)) - n.kmin) << n.shl; }
 
 // local histogram of one radix pass; blockIdx.y = node, the node's local particles are P[seg[j] .. seg[j + 1])
@@ -113,7 +126,7 @@ __global__ __launch_bounds__(kB) void dp_hist_kernel(const float4 *__restrict__ 
 	const DpNode n = nd[j];
 	for (long long i = s + (long long)blockIdx.x * kB + threadIdx.x; i < e; i += (long long)gridDim.x * kB)
 	{
-		const uint32_t key = window_key(P[i], n);
+		const uint32_t key = window_key(load_particle(P, i), n);
 		bool ok = true;
 		uint32_t d = key >> 21;
 		if (pass == 1) { ok = (key >> 21) == n.prefix; d = (key >> 10) & 0x7FFu; }
@@ -163,7 +176,7 @@ __global__ __launch_bounds__(kB) void dp_ties_kernel(const float4 *__restrict__ 
 	for (long long i = s + (long long)blockIdx.x * kB + threadIdx.x; i < e; i += (long long)gridDim.x * kB)
 	{
 		unsigned char c = 0;
-		const float4 p = P[i];
+		const float4 p = load_particle(P, i);
 		if (n.need != n.neq && ordered_bits(axis_of(p, n.axis)) == n.pivot)
 		{
 			const int slot = atomicAdd(&cnt[j], 1);
@@ -245,7 +258,7 @@ __global__ __launch_bounds__(kB) void dp_count_kernel(const float4 *__restrict__
 	for (long long i = s + (long long)blockIdx.x * kB + threadIdx.x; i < e; i += (long long)gridDim.x * kB)
 	{
 		uint32_t key;
-		const int side = dp_side(P[i], n, j, cand[i], dec, key);
+		const int side = dp_side(load_particle(P, i), n, j, cand[i], dec, key);
 		left += side == 0;
 		if (side == 1) mr = min(mr, skey(key));
 	}
@@ -300,7 +313,7 @@ __global__ __launch_bounds__(kB) void dp_scatter_kernel(const float4 *__restrict
 		const long long i = base + threadIdx.x;
 		int side = -1;
 		float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-		if (i < e) { uint32_t key; p = P[i]; side = dp_side(p, n, j, cand[i], dec, key); }
+		if (i < e) { uint32_t key; p = load_particle(P, i); side = dp_side(p, n, j, cand[i], dec, key); }
 		const unsigned long long bl = __ballot(side == 0), br = __ballot(side == 1), below = (1ull << lane) - 1ull;
 		const int lr = side == 0 ? __popcll(bl & below) : __popcll(br & below);
 		if (lane == 0) { wc[w][0] = __popcll(bl); wc[w][1] = __popcll(br); }
@@ -382,6 +395,7 @@ int dpart_workspace(nbco_ctx *c, long long n_global, int world, long long *bytes
 // runs the local stages that follow the collective just completed (or the first ones) and describes the next collective
 static int dpart_advance(nbco_ctx *c, nbco_dist_step *out)
 {
+	static const bool trace = getenv("NBCO_DPART_TRACE") != nullptr;
 	nbco_ctx::DPart &s = c->dpart;
 	hipStream_t st = c->stream;
 	const int G = s.world, d = s.d;
@@ -409,6 +423,7 @@ static int dpart_advance(nbco_ctx *c, nbco_dist_step *out)
 	auto start_hist = [&]() {
 		const int m = 1 << s.level;
 		NBCO_HIP(hipMemsetAsync(coll, 0, sizeof(int) * (size_t)m * kBins, st));
+		if (trace) fprintf(stderr, "   memset: %s\n", hipGetErrorString(hipStreamSynchronize(st)));
 		hipLaunchKernelGGL(dp_hist_kernel, dim3(kGX, m), dim3(kB), 0, st, (const float4 *)P, (const int *)seg, (const DpNode *)nd, s.pass, coll);
 		NBCO_HIP(hipGetLastError());
 		s.stage = ST_HIST;
@@ -420,15 +435,26 @@ static int dpart_advance(nbco_ctx *c, nbco_dist_step *out)
 		s.stage = ST_COUNTS;
 		return step(NBCO_COLL_ALLGATHER, 0, L.coll_send, (long long)(sizeof(int) * G));
 	};
+	if (trace)
+	{
+		const hipError_t e = hipStreamSynchronize(st);
+		fprintf(stderr, "[dpart rank %d] stage %d level %d pass %d (%s)\n", s.rank, s.stage, s.level, s.pass, hipGetErrorString(e));
+		fprintf(stderr, "   W %p coll_recv %p send %p recv %p | P %p Palt %p nd %p seg %p seg_next %p cntL %p cursor %p flag %p cand %p dec %p | lb %p rb %p sd %p idx %p | nl %lld G %d d %d state %p\n",
+		        (void *)W, (void *)coll_recv, (void *)sendbuf, (void *)recvbuf, (void *)P, (void *)Palt, (void *)nd, (void *)seg, (void *)seg_next, (void *)cntL, (void *)cursor,
+		        (void *)flag, (void *)cand, (void *)dec, (void *)t.lb, (void *)t.rb, (void *)t.sd, (void *)t.index, nl, G, d, (void *)s.state);
+		if (getenv("NBCO_DPART_DRY")) { s.stage = ST_IDLE; return c->fail(NBCO_ERR_UNSUPPORTED, "dry run"); }
+	}
 	switch (s.stage)
 	{
 	case ST_BOUNDS:
 	{
 		hipLaunchKernelGGL(dp_root_kernel, dim3(1), dim3(64), 0, st, (const int *)coll, t);
 		NBCO_HIP(hipGetLastError());
+		if (trace) fprintf(stderr, "   root: %s\n", hipGetErrorString(hipStreamSynchronize(st)));
 		s.level = 0; s.pass = 0;
 		if (d == 0) return start_counts();
 		hipLaunchKernelGGL(dp_nodes_kernel, dim3(1), dim3(64), 0, st, t, 0, s.n_global, nd);
+		if (trace) fprintf(stderr, "   nodes: %s\n", hipGetErrorString(hipStreamSynchronize(st)));
 		return start_hist();
 	}
 	case ST_HIST:

@@ -226,7 +226,7 @@ class DomainRun:
             while st.op != 0:
                 run_dist_step(self.comm, self.work, st)
                 if st.op == 4:
-                    moved = st.row_bytes * (sum(int(st.rows_recv[r]) for r in range(self.world)) - int(st.rows_recv[self.rank]))
+                    moved += st.row_bytes * (sum(int(st.rows_recv[r]) for r in range(self.world)) - int(st.rows_recv[self.rank]))
                 elif st.op == 3:
                     moved += (self.world - 1) * st.count
                 else:
@@ -413,6 +413,7 @@ class LoopbackWorld:
         state = torch.cat([torch.cat([p.reshape(-1) for p in pos_parts]), torch.cat([v.reshape(-1) for v in vel_parts])])
         for r in self.runs:
             r.state_all.copy_(state)
+            r.partition_bytes = (r.world - 1) * 24 * r.n_local
             r.eng.dist_partition(r.state_all, r.n_global, r.world, r.rank, r.buf)
             r.evals = 0
 
@@ -425,6 +426,7 @@ class LoopbackWorld:
             if v.data_ptr() != r.vel.data_ptr():
                 r.vel.copy_(v.reshape(-1))
         sts = [r.eng.dist_repartition_begin(r.buf, r.n_global, G, r.rank, r.work) for r in runs]
+        moved = [0] * G
         while sts[0].op != 0:
             op = sts[0].op
             assert all(s_.op == op and s_.count == sts[0].count for s_ in sts)
@@ -449,8 +451,16 @@ class LoopbackWorld:
                         parts.append(s_.work[off: off + w * int(ss.rows_send[r.rank])])
                     got = torch.cat(parts)
                     r.work[sr.recv_off: sr.recv_off + got.numel()].copy_(got)
+            for r, sr in zip(runs, sts):   # bytes received, as DomainRun.partition counts them
+                if op == 4:
+                    moved[r.rank] += sr.row_bytes * (sum(int(sr.rows_recv[q]) for q in range(G)) - int(sr.rows_recv[r.rank]))
+                elif op == 3:
+                    moved[r.rank] += (G - 1) * sr.count
+                else:
+                    moved[r.rank] += 2 * 4 * sr.count
             sts = [r.eng.dist_repartition_next() for r in runs]
         for r in runs:
+            r.partition_bytes = moved[r.rank]
             r.evals = 0
 
     def force_let(self, param=None, elastic=True, tamper=None):

@@ -194,14 +194,19 @@ struct Session
 		std::vector<int> order(input_order ? (size_t)n : 0);
 		std::vector<float> rows(input_order ? host.size() : 0);
 		check(nbco_force(ctx(), NBCO_EVAL_FMM_KDTREE, state.ptr, n, par.ptr, 1), "compute_force");
-		for (int iter = 0; iter < nIters; ++iter)
+		// snapshots follow the iterations 0, nSteps, 2 nSteps, ..: the steps in between are ONE nbco_integrate_steps call (same final
+		// state as step-by-step calls; leapfrog fuses what lies between two force evaluations into one pass)
+		for (int iter = 0; iter < nIters;)
 		{
-			check(nbco_integrate(ctx(), scheme, NBCO_EVAL_FMM_KDTREE, state.ptr, n, par.ptr, (double)dt, 1.0, 1), "integrate");
-			if (iter % nSteps != 0) continue;
-			std::cout << iter << ' ' << std::flush;
+			const int run = iter % nSteps == 0 ? 1 : std::min(nSteps - iter % nSteps, nIters - iter);
+			check(nbco_integrate_steps(ctx(), scheme, NBCO_EVAL_FMM_KDTREE, state.ptr, n, par.ptr, (double)dt, 1.0, 1, run), "integrate");
+			iter += run;
+			if ((iter - 1) % nSteps != 0) continue;
+			const int snap = iter - 1;
+			std::cout << snap << ' ' << std::flush;
 			check(nbco_sync(ctx()), "sync");
 			HIPCHK(hipMemcpy(host.data(), state.ptr, state_bytes, hipMemcpyDeviceToHost));   // acc not copied
-			std::ofstream fout(folder + "/out" + std::to_string(iter) + '_' + std::to_string(dt) + ".bin", std::ios::out | std::ios::binary);
+			std::ofstream fout(folder + "/out" + std::to_string(snap) + '_' + std::to_string(dt) + ".bin", std::ios::out | std::ios::binary);
 			if (!fout)
 			{
 				std::cerr << "Error: cannot write on output location. Check that \"" << folder << "\" folder exists. Create it if not." << std::endl;
