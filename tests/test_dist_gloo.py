@@ -231,6 +231,79 @@ class NumpyLetEngine(NumpySplitEngine):
         a_local.numpy()[:] = (acc * scale).astype(np.float32).reshape(-1)
 
 
+class _Step:
+    """nbco_dist_step as the ctypes Engine returns it"""
+    def __init__(self, op=0, send_off=0, recv_off=0, count=0, row_bytes=0, rows_send=(), rows_recv=()):
+        self.op, self.send_off, self.recv_off, self.count, self.row_bytes = op, send_off, recv_off, count, row_bytes
+        self.rows_send, self.rows_recv = list(rows_send), list(rows_recv)
+
+
+class NumpyRepartEngine(NumpySplitEngine):
+    """the re-partition protocol of include/nbco.h (nbco_dist_repartition_begin / _next: the engine names a collective on the
+    caller's workspace, the caller runs it).  The double walks through all four kinds -- MIN and SUM all-reduce, all-gather,
+    all-to-all with uneven rows -- and cuts the same domains as NumpyDomainEngine.dist_partition: global bounds by MIN (the
+    maxima inverted), the particle count by SUM, every rank's [pos | vel] by all-gather, then each rank keeps what it owns and
+    receives the rest through the all-to-all."""
+
+    def dist_repartition_workspace(self, n_global, world):
+        nl = n_global // world
+        return 64 + 24 * nl + 24 * n_global + 2 * 24 * nl
+
+    def dist_repartition_begin(self, state_local, n_global, world, rank, work):
+        self.calls.append("partition")
+        self._rp = dict(state=state_local, N=n_global, G=world, me=rank, work=work, stage=0)
+        nl = n_global // world
+        p = state_local.numpy()[:3 * nl].reshape(nl, 3)
+        w = work.numpy()
+        key = (p.min(0) * 1e6).astype(np.int32), (-p.max(0) * 1e6).astype(np.int32)
+        w[:24].view(np.int32)[:] = np.concatenate(key)
+        return _Step(op=1, send_off=0, count=6)
+
+    def dist_repartition_next(self):
+        rp = self._rp
+        N, G, me, w = rp["N"], rp["G"], rp["me"], rp["work"].numpy()
+        nl = N // G
+        st = rp["state"].numpy()
+        rp["stage"] += 1
+        if rp["stage"] == 1:
+            b = w[:24].view(np.int32)
+            p = st[:3 * nl].reshape(nl, 3)
+            assert (b[:3] <= (p.min(0) * 1e6).astype(np.int32)).all() and (b[3:] <= (-p.max(0) * 1e6).astype(np.int32)).all()
+            w[32:36].view(np.int32)[:] = nl
+            return _Step(op=2, send_off=32, count=1)
+        if rp["stage"] == 2:
+            assert w[32:36].view(np.int32)[0] == N
+            w[64:64 + 24 * nl].view(np.float32)[:] = st[:6 * nl]
+            return _Step(op=3, send_off=64, recv_off=64 + 24 * nl, count=24 * nl)
+        if rp["stage"] == 3:
+            allst = w[64 + 24 * nl: 64 + 24 * nl + 24 * N].view(np.float32).reshape(G, 2, nl, 3)
+            full = torch.from_numpy(np.concatenate([allst[:, 0].reshape(-1), allst[:, 1].reshape(-1)]))
+            # destination of every particle: the domain the gathered selection puts it in
+            dest = np.empty(N, dtype=int)
+            pos_all, vel_all = full.numpy()[:3 * N].reshape(N, 3), full.numpy()[3 * N:].reshape(N, 3)
+            for g in range(G):
+                out = torch.zeros(6 * nl)
+                NumpyDomainEngine.dist_partition(self, full, N, G, g, out)
+                self.calls.pop()
+                mine = out.numpy()[:3 * nl].reshape(nl, 3)
+                idx = {tuple(r): i for i, r in enumerate(map(tuple, pos_all))}
+                dest[[idx[tuple(r)] for r in map(tuple, mine)]] = g
+            mydest = dest[me * nl:(me + 1) * nl]
+            order = np.argsort(mydest, kind="stable")
+            send = np.concatenate([pos_all[me * nl:(me + 1) * nl][order], vel_all[me * nl:(me + 1) * nl][order]], axis=1).astype(np.float32)
+            off_s = 64 + 24 * nl + 24 * N
+            w[off_s: off_s + 24 * nl].view(np.float32)[:] = send.reshape(-1)
+            rows_send = [int((mydest == g).sum()) for g in range(G)]
+            rows_recv = [int((dest[s_ * nl:(s_ + 1) * nl] == me).sum()) for s_ in range(G)]
+            assert sum(rows_recv) == nl
+            rp["off_r"] = off_s + 24 * nl
+            return _Step(op=4, send_off=off_s, recv_off=rp["off_r"], count=nl, row_bytes=24, rows_send=rows_send, rows_recv=rows_recv)
+        rec = w[rp["off_r"]: rp["off_r"] + 24 * nl].view(np.float32).reshape(nl, 6)
+        st[:3 * nl] = rec[:, :3].reshape(-1)
+        st[3 * nl:6 * nl] = rec[:, 3:].reshape(-1)
+        return _Step(op=0)
+
+
 def _system(n, seed=11):
     rng = np.random.default_rng(seed)
     pos = rng.standard_normal((n, 3)).astype(np.float32)
@@ -246,7 +319,7 @@ def _drive(run, par, steps, dt):
     return torch.cat([run.pos.view(-1, 3), run.vel.view(-1, 3), run.acc.view(-1, 3)], dim=1).numpy()
 
 
-def _worker(rank, world, port, n, steps, dt, rebalance, outdir, split=False, let=False):
+def _worker(rank, world, port, n, steps, dt, rebalance, outdir, split=False, let=False, repart=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -254,9 +327,9 @@ def _worker(rank, world, port, n, steps, dt, rebalance, outdir, split=False, let
     try:
         pos, vel, par = _system(n)
         nl = n // world
-        eng = NumpyLetEngine() if let else (NumpySplitEngine() if split else NumpyDomainEngine())
+        eng = NumpyRepartEngine() if repart else (NumpyLetEngine() if let else (NumpySplitEngine() if split else NumpyDomainEngine()))
         run = DomainRun(eng, n, TorchComm(), device=torch.device("cpu"), rebalance=rebalance)
-        assert (run.world, run.rank, run.n_local) == (world, rank, nl) and run.split == split and run.let == let
+        assert (run.world, run.rank, run.n_local) == (world, rank, nl) and run.split == split and run.let == let and run.dpart == repart
         if let:
             assert run.exchange_bytes() == run.allgather_bytes()   # (nothing evaluated yet)
         run.partition(torch.from_numpy(pos[rank * nl:(rank + 1) * nl]).reshape(-1), torch.from_numpy(vel[rank * nl:(rank + 1) * nl]).reshape(-1))
@@ -281,8 +354,9 @@ def _free_port():
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world,split,let", [(2, False, False), (4, False, False), (2, True, False), (4, True, False), (2, True, True), (4, True, True)])
-def test_domain_run_over_gloo_matches_single_process(world, split, let):
+@pytest.mark.parametrize("world,split,let,repart", [(2, False, False, False), (4, False, False, False), (2, True, False, False), (4, True, False, False),
+                                                    (2, True, True, False), (4, True, True, False), (2, True, False, True), (4, True, False, True)])
+def test_domain_run_over_gloo_matches_single_process(world, split, let, repart):
     import torch.multiprocessing as mp
     n, steps, dt, rebalance = 512, 5, 1e-2, 2
     pos, vel, par = _system(n)
@@ -290,7 +364,7 @@ def test_domain_run_over_gloo_matches_single_process(world, split, let):
     one.partition(torch.from_numpy(pos).reshape(-1), torch.from_numpy(vel).reshape(-1))
     ref = _drive(one, torch.from_numpy(par), steps, dt)
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, _free_port(), n, steps, dt, rebalance, d, split, let), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), n, steps, dt, rebalance, d, split, let, repart), nprocs=world, join=True)
         got = np.concatenate([np.load(os.path.join(d, "rank%d.npy" % r)) for r in range(world)])
         calls = [open(os.path.join(d, "calls%d.txt" % r)).read().split() for r in range(world)]
         scal = [np.load(os.path.join(d, "scal%d.npy" % r)) for r in range(world)]
