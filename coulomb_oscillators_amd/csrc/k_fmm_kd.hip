@@ -1635,7 +1635,7 @@ static int kd_carve(nbco_ctx *c, DevBuf &buf, KdTreeDev &k, int ntot, int offM, 
 // overflow, one global stable radix sort per level.  The root's box / split axis must be in place; on return
 // pos / unsort point at the buffers holding the result and the boxes of level l0 are written.
 static int kd_build_top(nbco_ctx *c, const TreeView &tv, float4 *&pos, float4 *&pos_alt, int *&unsort, int *&unsort_alt, long long n, int l0,
-                        bool use_select, bool select_ready = false)
+                        bool use_select, bool select_ready = false, bool warm = false)
 {
 	hipStream_t st = c->stream;
 	if (use_select && l0 > 0 && !select_ready) NBCO_TRY(kd_select_begin(c, l0));
@@ -1643,7 +1643,7 @@ static int kd_build_top(nbco_ctx *c, const TreeView &tv, float4 *&pos, float4 *&
 	{
 		if (use_select)
 			NBCO_TRY(kd_select_level(c, l, n, pos, unsort, pos_alt, unsort_alt, tv.lbound, tv.rbound, tv.splitdim, tv.index,
-			                         c->counters.as<int>() + 110));
+			                         c->counters.as<int>() + 110, warm));
 		else
 		{
 			if (l > 0) hipLaunchKernelGGL(kd_box_kernel, dim3(grid1d(kd_cnt(l))), dim3(kBlock), 0, st, tv, pos, n, l);
@@ -1732,7 +1732,11 @@ static int kd_build_upward(nbco_ctx *c, const float *p, long long n, int L, cons
 			if (c->skip_prep != 1)
 			hipLaunchKernelGGL(kd_prep_kernel, dim3(kPrepGrid), dim3(kPrepBlock), 0, st, p, n, pos, unsort, c->sel_hist.as<uint32_t>(), words_a,
 			                   c->sel_nodes.as<uint32_t>(), words_b, c->counters.as<int>() + 110, c->prep_state.as<unsigned>(), tv, root6);
-			NBCO_TRY(kd_build_top(c, tv, pos, pos_alt, unsort, unsort_alt, n, l0, use_select, true));
+			// the previous build's boxes are still in the tree arrays: select around its pivots (one pass per level instead of two)
+			const bool warm = use_select && l0 > 0 && c->sel_warm_enabled && c->tree_valid && !root6 && !c->sel_three_pass;
+			c->sel_warm_used = warm;
+			if (warm) ++c->sel_warm_builds;
+			NBCO_TRY(kd_build_top(c, tv, pos, pos_alt, unsort, unsort_alt, n, l0, use_select, true, warm));
 			// the rest of every level-l0 subtree inside one workgroup's LDS
 			hipLaunchKernelGGL(kd_subtree_kernel, dim3(kd_cnt(l0)), dim3(kSubT), 0, st, tv, (const float4 *)pos, (const int *)unsort, pos_alt, unsort_alt, n, l0,
 			                   use_select ? 1 : 0, c->sel_three_pass ? 0 : 1, c->counters.as<int>() + 110);
@@ -1746,6 +1750,7 @@ static int kd_build_upward(nbco_ctx *c, const float *p, long long n, int L, cons
 		else
 		{
 			// tree reused: the caller's positions are already in tree order
+			c->sel_warm_used = false;
 			if (c->skip_prep == 0)
 			{
 				NBCO_TRY(launch_pack4(c, pos, p, n));
@@ -2268,6 +2273,16 @@ int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 		c->tree_valid = false;
 		return fmm_kdtree_eval(c, p, a, n, param);
 	}
+	if (cnt.sel_overflow && c->sel_warm_used)
+	{
+		// the one-pass select missed a median (or what it left behind tripped the tie flag): the same evaluation with the cold
+		// two-pass select, nothing escalated
+		++c->sel_warm_misses;
+		if (++c->sel_warm_strikes >= 3) c->sel_warm_enabled = false;
+		c->tree_valid = false;
+		return fmm_kdtree_eval(c, p, a, n, param);
+	}
+	if (rebuild && c->sel_warm_used) c->sel_warm_strikes = 0;
 	if (cnt.sel_overflow)
 	{
 		// next more conservative build: three radix passes, then the sorting build

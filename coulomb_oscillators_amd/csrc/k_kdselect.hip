@@ -42,6 +42,7 @@ struct SelNode
 	uint32_t done_part; // blocks that have finished their part of the partition
 	uint32_t cntL, cntR, tiecnt;
 	uint32_t minR;     // smallest ordered key of the right child, stored inverted (~key) so that zero = "none yet"
+	uint32_t below;    // warm select: elements whose bucket lies below the histogram window
 };
 
 struct SelPivot { uint32_t prefix, r, neq, need; };
@@ -203,6 +204,139 @@ __global__ __launch_bounds__(BLOCK) void sel_hist_kernel(const float4 *__restric
 	}
 }
 
+// ---- warm select: ONE histogram pass per level instead of two ---------------------------------------------------------------------
+// Between two builds of a simulation the particles move by ~1e-5 of a box, and so do the medians.  The previous build's pivot of
+// node j is still in the tree arrays when level l is selected -- it is the upper face, along the split axis, of the left child's
+// OLD box, which this level's partition overwrites only at its very end.  The pass histograms only a WINDOW of kWarmBins buckets
+// of the box-linear key (bucket = key >> drop, drop chosen per level so that a bucket holds well under one element on average)
+// centred on that prediction, and counts what lies below it; the partition finds the pivot's bucket in it exactly as it does in
+// the second pass's histogram.  A window that misses the median (first build after a jump, a changed split axis, ..) raises
+// flag 2: the partition leaves the node untouched -- exactly what it does with a tie overflow -- and the host repeats the
+// evaluation with the two-pass select.
+constexpr int kWarmBins = 3 * kBins;
+__device__ inline uint32_t warm_window_start(const float *__restrict__ lbound, const float *__restrict__ rbound, const int *__restrict__ sd_l, int l,
+                                             long long j, float lo, float scale, int drop)
+{
+	const int left = (2 << l) - 1 + 2 * (int)j, a = sd_l[j];
+	const uint32_t c = lin_key(rbound[3 * left + a], lo, scale) >> drop;   // bucket of the previous pivot under the current box
+	return c > (uint32_t)(kWarmBins / 2) ? c - (uint32_t)(kWarmBins / 2) : 0u;
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void sel_hist_warm_kernel(const float4 *__restrict__ pos, const int *__restrict__ sd_l, uint32_t *__restrict__ hist,
+                                                               SelNode *__restrict__ nodes, const float *__restrict__ lbound,
+                                                               const float *__restrict__ rbound, long long n, int l, int drop)
+{
+	constexpr int CHUNK = 8 * BLOCK;
+	__shared__ uint32_t h[2][kWarmBins];
+	__shared__ uint32_t below[2];
+	const long long m = 1LL << l;
+	const long long i0 = (long long)blockIdx.x * CHUNK;
+	constexpr int PER = CHUNK / BLOCK;
+	float4 p[PER];
+#pragma unroll
+	for (int e = 0; e < PER; ++e)
+	{
+		const long long i = i0 + e * BLOCK + threadIdx.x;
+		if (i < n) p[e] = pos[i];
+	}
+	for (int t = threadIdx.x; t < 2 * kWarmBins; t += BLOCK) (&h[0][0])[t] = 0;
+	if (threadIdx.x < 2) below[threadIdx.x] = 0;
+	const long long ilast = (i0 + CHUNK < n ? i0 + CHUNK : n) - 1;
+	const long long j0 = (m * i0) / n, j1 = (m * ilast) / n;
+	float lo[2] = {0.f, 0.f}, scale[2] = {0.f, 0.f};
+	uint32_t w0[2] = {0, 0};
+	for (int jj = 0; jj < 2; ++jj)
+		if (j0 + jj <= j1)
+		{
+			lin_window(lbound, rbound, sd_l, l, j0 + jj, lo[jj], scale[jj]);
+			w0[jj] = warm_window_start(lbound, rbound, sd_l, l, j0 + jj, lo[jj], scale[jj], drop);
+		}
+	__syncthreads();
+	const long long split = j1 > j0 ? range_start(n, j1, m) : n;
+	const int sd[2] = {sd_l[j0], sd_l[j1]};
+	uint32_t nb[2] = {0, 0};
+#pragma unroll
+	for (int e = 0; e < PER; ++e)
+	{
+		const long long i = i0 + e * BLOCK + threadIdx.x;
+		if (i < n)
+		{
+			const int jj = i >= split ? 1 : 0;
+			const uint32_t b = lin_key(axis_of(p[e], sd[jj]), lo[jj], scale[jj]) >> drop;
+			if (b < w0[jj]) nb[jj] += 1;
+			else if (b - w0[jj] < (uint32_t)kWarmBins) atomicAdd(&h[jj][b - w0[jj]], 1u);
+		}
+	}
+#pragma unroll
+	for (int q = 0; q < 2; ++q)
+	{
+		uint32_t v = nb[q];
+		for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+		if ((threadIdx.x & 63) == 0 && v) atomicAdd(&below[q], v);
+	}
+	__syncthreads();
+	for (int t = threadIdx.x; t < 2 * kWarmBins; t += BLOCK)
+	{
+		const uint32_t v = (&h[0][0])[t];
+		const long long j = j0 + (t / kWarmBins);
+		const int bin = t % kWarmBins;
+		// window part w = bin / kBins of node j lives where pass w's histogram would (same storage, zeroed by the build prologue)
+		if (v && j <= j1) atomicAdd(&hist[((size_t)(bin / kBins) * m + j) * kBins + (bin % kBins)], v);
+	}
+	if (threadIdx.x < 2 && j0 + threadIdx.x <= j1 && below[threadIdx.x]) atomicAdd(&nodes[j0 + threadIdx.x].below, below[threadIdx.x]);
+}
+
+// the window histogram of node j -> the pivot's bucket; pv.need == 0 reports a window that does not hold the median
+template <int BLOCK>
+__device__ inline SelPivot resolve_warm(const uint32_t *__restrict__ hist, const SelNode *__restrict__ nodes, long long n, int l, long long j, uint32_t w0,
+                                        uint32_t *sh /* [BLOCK/64 + 4] */)
+{
+	constexpr int R = BLOCK / 64, PER = kWarmBins / BLOCK;
+	const long long m = 1LL << l;
+	SelPivot pv;
+	pv.prefix = 0; pv.neq = 0; pv.need = 0;
+	const long long rank = range_start(n, 2 * j + 1, 2 * m) - range_start(n, j, m) - 1 - (long long)ld_agent_u32(&nodes[j].below);
+	uint32_t v[PER], s = 0;
+#pragma unroll
+	for (int q = 0; q < PER; ++q)
+	{
+		const int bin = threadIdx.x * PER + q;
+		v[q] = ld_agent_u32(&hist[((size_t)(bin / kBins) * m + j) * kBins + (bin % kBins)]);
+		s += v[q];
+	}
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	uint32_t incl = s;
+	for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+	__syncthreads();
+	if (lane == 63) sh[w] = incl;
+	if (threadIdx.x == 0) sh[R + 3] = 0;
+	__syncthreads();
+	uint32_t base = 0;
+	for (int q = 0; q < w; ++q) base += sh[q];
+	uint32_t cum = base + incl - s;
+	if (rank >= 0)
+	{
+		const uint32_t r = (uint32_t)rank;
+#pragma unroll
+		for (int q = 0; q < PER; ++q)
+		{
+			if (r >= cum && r < cum + v[q]) { sh[R] = threadIdx.x * PER + q; sh[R + 1] = cum; sh[R + 2] = v[q]; sh[R + 3] = 1; }
+			cum += v[q];
+		}
+	}
+	__syncthreads();
+	if (sh[R + 3])
+	{
+		pv.prefix = w0 + sh[R];
+		pv.r = (uint32_t)rank - sh[R + 1];
+		pv.neq = sh[R + 2];
+		pv.need = pv.r + 1;
+	}
+	__syncthreads();
+	return pv;
+}
+
 // exclusive scan over the block of four 16-bit counters packed in a uint64 (each block total <= CHUNK < 2^16)
 template <int BLOCK>
 __device__ inline uint64_t block_scan4(uint64_t v, uint64_t *sh_wave, uint64_t &total)
@@ -293,7 +427,8 @@ __device__ inline void ties_and_boxes(const float4 *__restrict__ pos_in, const i
 		const int c = 2 * j + lane, child = 2 * m - 1 + c;
 		float lb[3] = {lbound[3 * node], lbound[3 * node + 1], lbound[3 * node + 2]};
 		float rb[3] = {rbound[3 * node], rbound[3 * node + 1], rbound[3 * node + 2]};
-		if (c & 1)
+		if (pv.need == 0) { /* warm select, window missed: nothing was moved; the children inherit the box (flag 2 is up) */ }
+		else if (c & 1)
 		{
 			const uint32_t inv = ld_agent_u32(&nodes[j].minR);   // inverted, 0 = no element above the candidates
 			const uint32_t above = inv ? ~inv : 0xFFFFFFFFu;
@@ -316,13 +451,14 @@ __device__ inline void ties_and_boxes(const float4 *__restrict__ pos_in, const i
 // Unordered partition of every node into [keys below the pivot | keys above the pivot]; elements equal to the
 // pivot go left when all of them belong there and to the tie list otherwise.  All loads of a thread's 8 elements
 // are issued up front, slots are reserved with one packed block scan and four concurrent global atomics.
-template <int BLOCK, int NP>
+// WARM: the select was one windowed pass (sel_hist_warm_kernel), buckets are key >> drop; otherwise drop = 10 (two passes of 11 bits)
+template <int BLOCK, int NP, bool WARM = false>
 __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__restrict__ pos_in, const int *__restrict__ unsort_in,
                                                                float4 *__restrict__ pos_out, int *__restrict__ unsort_out,
                                                                const int *__restrict__ sd_l, SelNode *__restrict__ nodes,
                                                                uint32_t *__restrict__ tielist, long long n, int l, float *__restrict__ lbound,
                                                                float *__restrict__ rbound, int *__restrict__ splitdim, int *__restrict__ index,
-                                                               int *__restrict__ flag, const uint32_t *__restrict__ hist)
+                                                               int *__restrict__ flag, const uint32_t *__restrict__ hist, int drop)
 {
 	constexpr int CHUNK = 8 * BLOCK;
 	static_assert(CHUNK < 65536, "packed 16-bit block counters");
@@ -348,15 +484,28 @@ __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__re
 	// NP = 2: the select stopped after two passes -- piv is the 22-bit bucket of the pivot under the box-linear bucket key,
 	// every element of that bucket is a candidate for the resolver; NP = 3: piv is the pivot itself (an ordered key)
 	constexpr bool EARLY = NP < 3;
-	constexpr int kDrop = 10;   // key bits below the bucket
+	const int kDrop = drop;   // key bits below the bucket
 	uint32_t piv[2] = {0, 0}, all_left[2] = {0, 0};
 	float lo[2] = {0.f, 0.f}, scale[2] = {0.f, 0.f};
+	bool miss[2] = {false, false};   // warm select: the window did not hold the median -- the node is left alone, flag 2
 	SelPivot pvs[2];
 	for (int jj = 0; jj < 2; ++jj)
 	{
 		pvs[jj] = SelPivot{0, 0, 0, 0};
 		if (j0 + jj <= j1)
 		{
+			if (WARM)
+			{
+				lin_window(lbound, rbound, sd_l, l, j0 + jj, lo[jj], scale[jj]);
+				// (the children's old boxes are still in place: they are rewritten by the workgroup that completes the node, and no
+				// workgroup of the node completes before this one has)
+				const uint32_t w0 = warm_window_start(lbound, rbound, sd_l, l, j0 + jj, lo[jj], scale[jj], drop);
+				pvs[jj] = resolve_warm<BLOCK>(hist, nodes, n, l, j0 + jj, w0, sh);
+				miss[jj] = pvs[jj].need == 0;
+				if (miss[jj] && threadIdx.x == 0) *flag = 2;
+				piv[jj] = pvs[jj].prefix;
+				continue;
+			}
 			pvs[jj] = resolve_before<NP, BLOCK>(hist, nodes, n, l, j0 + jj, i0, sh);
 			if (EARLY) lin_window(lbound, rbound, sd_l, l, j0 + jj, lo[jj], scale[jj]);
 			else
@@ -371,7 +520,7 @@ __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__re
 			all_left[jj] = !EARLY && pvs[jj].need == pvs[jj].neq;
 		}
 	}
-	if (j1 == j0) { piv[1] = piv[0]; all_left[1] = all_left[0]; lo[1] = lo[0]; scale[1] = scale[0]; }
+	if (j1 == j0) { piv[1] = piv[0]; all_left[1] = all_left[0]; lo[1] = lo[0]; scale[1] = scale[0]; miss[1] = miss[0]; }
 	const int sd[2] = {sd_l[j0], sd_l[j1]};
 	if (threadIdx.x < 2) mR[threadIdx.x] = 0xFFFFFFFFu;
 	// Destination slots.  The four output streams of the chunk (left / right of its one or two nodes) are filled in
@@ -396,7 +545,8 @@ __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__re
 			const int jj = i >= split ? 1 : 0;
 			const uint32_t key = ordered_bits(axis_of(p[e], sd[jj]));
 			const uint32_t cmp = EARLY ? lin_key(axis_of(p[e], sd[jj]), lo[jj], scale[jj]) >> kDrop : key;
-			if (cmp < piv[jj] || (cmp == piv[jj] && all_left[jj])) cat[e] = 2 * jj;
+			if (WARM && miss[jj]) { /* nothing moves */ }
+			else if (cmp < piv[jj] || (cmp == piv[jj] && all_left[jj])) cat[e] = 2 * jj;
 			else if (cmp > piv[jj]) { cat[e] = 2 * jj + 1; tmin[jj] = key < tmin[jj] ? key : tmin[jj]; }
 			else
 			{
@@ -505,7 +655,7 @@ int kd_select_begin(nbco_ctx *c, int l0, bool zero, long long *words_a, long lon
 // l + 1.  `flag` (device int) is set when a node had more ties than the resolver handles.
 template <int BLOCK, int NP>
 static void select_level_launch(nbco_ctx *c, int l, long long n, const float4 *pos_in, const int *unsort_in, float4 *pos_out, int *unsort_out,
-                                float *lbound, float *rbound, int *splitdim, int *index, int *flag)
+                                float *lbound, float *rbound, int *splitdim, int *index, int *flag, int warm_drop)
 {
 	const int m = 1 << l;
 	// level l uses the slices [m - 1, 2m - 1) of the per-build arrays
@@ -516,16 +666,24 @@ static void select_level_launch(nbco_ctx *c, int l, long long n, const float4 *p
 	hipStream_t st = c->stream;
 	constexpr int CHUNK = 8 * BLOCK;
 	const int gchunks = (int)((n + CHUNK - 1) / CHUNK);
+	if (NP == 2 && warm_drop > 0)
+	{
+		hipLaunchKernelGGL((sel_hist_warm_kernel<BLOCK>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l,
+		                   warm_drop);
+		hipLaunchKernelGGL((sel_partition_kernel<BLOCK, 2, true>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, unsort_in, pos_out, unsort_out, sd_l, nodes, ties, n, l,
+		                   lbound, rbound, splitdim, index, flag, (const uint32_t *)hist, warm_drop);
+		return;
+	}
 	hipLaunchKernelGGL((sel_hist_kernel<0, BLOCK, NP == 2>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l);
 	hipLaunchKernelGGL((sel_hist_kernel<1, BLOCK, NP == 2>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l);
 	if (NP >= 3)
 		hipLaunchKernelGGL((sel_hist_kernel<2, BLOCK, false>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l);
 	hipLaunchKernelGGL((sel_partition_kernel<BLOCK, NP>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, unsort_in, pos_out, unsort_out, sd_l, nodes, ties, n, l,
-	                   lbound, rbound, splitdim, index, flag, (const uint32_t *)hist);
+	                   lbound, rbound, splitdim, index, flag, (const uint32_t *)hist, 10);
 }
 
 int kd_select_level(nbco_ctx *c, int l, long long n, const float4 *pos_in, const int *unsort_in, float4 *pos_out, int *unsort_out,
-                    float *lbound, float *rbound, int *splitdim, int *index, int *flag)
+                    float *lbound, float *rbound, int *splitdim, int *index, int *flag, bool warm)
 {
 	// Two radix passes over a bucket key that is linear across the node's box (lin_key) leave the pivot's bucket with about
 	// node size / 2^22 elements times the density contrast inside the box; the tie resolver orders them exactly as long as
@@ -535,7 +693,15 @@ int kd_select_level(nbco_ctx *c, int l, long long n, const float4 *pos_in, const
 	const long long node = n >> l;
 	const int np = (c->sel_three_pass || node > (1LL << 22)) ? 3 : 2;
 	const bool big = node >= 8 * kBlockBig;
-#define NBCO_SEL_ARGS c, l, n, pos_in, unsort_in, pos_out, unsort_out, lbound, rbound, splitdim, index, flag
+	// warm select (one pass): buckets of key >> drop with node / 2^(32 - drop) ~ 1/64 element per bucket on average, at most 22 bits
+	int warm_drop = 0;
+	if (warm && np == 2)
+	{
+		int lg = 0;
+		while ((1LL << lg) < node) ++lg;
+		warm_drop = 32 - std::min(22, std::max(16, lg + 6));
+	}
+#define NBCO_SEL_ARGS c, l, n, pos_in, unsort_in, pos_out, unsort_out, lbound, rbound, splitdim, index, flag, warm_drop
 	if (big)
 	{
 		if (np == 2) select_level_launch<kBlockBig, 2>(NBCO_SEL_ARGS);

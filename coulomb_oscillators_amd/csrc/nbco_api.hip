@@ -177,6 +177,7 @@ int nbco_create(nbco_ctx **out, const nbco_opts *o)
 	if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
 	c->stream = (hipStream_t)c->o.stream;
 	c->poison = getenv("NBCO_POISON") && atoi(getenv("NBCO_POISON")) != 0;
+	if (getenv("NBCO_SEL_WARM")) c->sel_warm_enabled = atoi(getenv("NBCO_SEL_WARM")) != 0;
 	if (hipMalloc(&c->small.ptr, 4096) != hipSuccess) { delete c; return NBCO_ERR_HIP; }
 	c->small.bytes = 4096;
 	*out = c;
@@ -682,6 +683,7 @@ int nbco_kd_get_info(nbco_ctx *c, nbco_kd_info *info)
 	}
 	*info = c->info;
 	info->build_mode = c->force_sort_build ? 2 : (c->sel_three_pass ? 1 : 0);
+	info->warm_builds = c->sel_warm_builds; info->warm_misses = c->sel_warm_misses;
 	return NBCO_OK;
 }
 int nbco_kd_copy(nbco_ctx *c, int which, void *host_dst, long long host_bytes)

@@ -192,6 +192,11 @@ struct nbco_ctx
 		bool partitioned = false, build_done = false, local_done = false, rebuilt = false, traversed = false, let_selected = false, let_packed = false;
 		const void *pos_all = nullptr;   // gathered positions, between the two halves of the finish stage
 	} dist;
+	// warm select (k_kdselect.hip): one histogram pass per level around the previous build's pivots.  used: this build ran it;
+	// a flagged build that used it is repeated cold before anything is escalated, three misses in a row switch it off
+	bool sel_warm_enabled = true, sel_warm_used = false;
+	int sel_warm_strikes = 0;
+	long long sel_warm_builds = 0, sel_warm_misses = 0;
 	bool sel_three_pass = false;            // set after the first tie / bucket overflow: three radix passes per select
 	bool force_sort_build = false;          // set after the second: use the sorting build from then on
 	bool escalate_build()                   // next more conservative build; false when there is none left
@@ -314,7 +319,7 @@ int kd_dist_finish_rest(nbco_ctx *c, const void *mpole_all, float *buf_local, fl
 // k_kdselect.hip
 int kd_select_begin(nbco_ctx *c, int l0, bool zero = true, long long *words_a = nullptr, long long *words_b = nullptr);
 int kd_select_level(nbco_ctx *c, int l, long long n, const float4 *pos_in, const int *unsort_in, float4 *pos_out, int *unsort_out,
-                    float *lbound, float *rbound, int *splitdim, int *index, int *flag);
+                    float *lbound, float *rbound, int *splitdim, int *index, int *flag, bool warm = false);
 // k_farfield.hip
 int launch_upward_gen(nbco_ctx *c, int P, const float4 *pos, float *center, float *mpole, int *mult, const int *index, int L, int write_geom);
 int launch_kd_centres(nbco_ctx *c, float *center, int *mult, int L, const float *lbound, const float *rbound, float4 *csz);

@@ -170,6 +170,8 @@ typedef struct nbco_kd_info {
 	                               more exact ties than that).  The trees are identical; only the speed differs. */
 	int p2p_halves;             /* near-field kernel of the last evaluation: 0 = one-directional; 1, 2, 4 = mutual (Newton III) with
 	                               leaves taken as that many halves of up to 32 particles (opts.p2p_mutual) */
+	long long warm_builds;      /* builds whose median selection ran ONE histogram pass per level around the previous build's pivots */
+	long long warm_misses;      /* .. of which a window missed the median: the evaluation was repeated with the two-pass select */
 } nbco_kd_info;
 int nbco_kd_get_info(nbco_ctx *c, nbco_kd_info *info);
 
