@@ -243,7 +243,7 @@ def cli_leg(n, order):
     exe = os.path.join(ROOT, "coulomb_oscillators_amd", "host", "nbco3")
     if not os.path.exists(exe):
         return None
-    k1, k2 = 50, 350
+    k1, k2 = 200, 2200      # (the difference must dwarf the run-to-run spread of ~0.6 s of process start-up)
     walls = []
     with tempfile.TemporaryDirectory() as tmp:
         for k in (k1, k2):
