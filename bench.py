@@ -236,26 +236,27 @@ def cpu_baseline(args, n):
             "sample": "direct3 on N=%d (pair rate %.3g/s scaled to N=%d), %d std::threads" % (ns, rate, n, cores)}
 
 
-def cli_leg(n, order):
-    """Throughput of the drop-in binary itself: wall time of `nbco3 -n N -p P -iters K` for two K (one snapshot each, at
-    iteration 0), differenced so that process start-up, the host-side init and the snapshot drop out."""
+def cli_leg(n, order, iters):
+    """Throughput of the drop-in binary itself over the same stretch of the simulation the library legs time: `nbco3 -n N -p P
+    -iters K` prints the wall time of its integration loop (device-synchronised at both ends, the one snapshot at iteration 0
+    included).  (The cost of a step grows as the ball evolves -- 0.5 ms per step over the first 200 steps, 2.8 ms around
+    step 2000, where the cloud has focused -- so runs of different length must not be differenced.)"""
+    import re
     import tempfile
     exe = os.path.join(ROOT, "coulomb_oscillators_amd", "host", "nbco3")
     if not os.path.exists(exe):
         return None
-    k1, k2 = 200, 2200      # (the difference must dwarf the run-to-run spread of ~0.6 s of process start-up)
-    walls = []
     with tempfile.TemporaryDirectory() as tmp:
-        for k in (k1, k2):
-            t0 = time.perf_counter()
-            r = subprocess.run([exe, "-n", str(n), "-p", str(order), "-iters", str(k), "-steps", "100000", "-o", tmp],
-                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=900)
-            walls.append(time.perf_counter() - t0)
-            if r.returncode != 0:
-                return {"error": r.stderr[-300:]}
-    per_iter = (walls[1] - walls[0]) / (k2 - k1)
-    return {"command": "nbco3 -n %d -p %d -iters {%d,%d} -steps 100000 (tree_steps 8, m2l_first: the reference GPU driver's defaults)" % (n, order, k1, k2),
-            "wall_s": walls, "ms_per_step": 1e3 * per_iter, "cli_particle_steps_per_s": n / per_iter}
+        r = subprocess.run([exe, "-n", str(n), "-p", str(order), "-iters", str(iters), "-steps", "100000", "-o", tmp],
+                           capture_output=True, text=True, timeout=900)
+    if r.returncode != 0:
+        return {"error": r.stderr[-300:]}
+    m = re.search(r"Loop time: ([0-9.eE+-]+) s, (\d+) iterations", r.stdout)
+    if not m:
+        return {"error": "no loop time in the output"}
+    per_iter = float(m.group(1)) / int(m.group(2))
+    return {"command": "nbco3 -n %d -p %d -iters %d -steps 100000 (tree_steps 8, m2l_first: the reference GPU driver's defaults)" % (n, order, iters),
+            "loop_s": float(m.group(1)), "ms_per_step": 1e3 * per_iter, "cli_particle_steps_per_s": n / per_iter}
 
 
 def main():
@@ -379,6 +380,7 @@ def main():
         info = eng.kd_info()
         pairs_per_eval = int(info.directed_p2p)   # this rank's directed pair interactions per evaluation
         extra = {"L": info.L, "p2p_pairs": int(info.p2p_pairs), "m2l_pairs": int(info.m2l_pairs), "build_mode": int(info.build_mode),
+                 "warm_builds": int(info.warm_builds), "warm_misses": int(info.warm_misses),
                  "near_field": ("mutual (Newton III), %d half(s) of 32 per leaf" % info.p2p_halves) if info.p2p_halves else "one-directional"}
         if args.engine_opt:
             extra["engine_opt"] = args.engine_opt
@@ -414,7 +416,9 @@ def main():
         run_steps(k8)
         barrier()
         e8 = time.perf_counter() - t1
-        reuse = {"tree_steps": 8, "steps": k8, "ms_per_step": 1e3 * e8 / k8, "value": n * k8 / e8, "unit": "particle-steps/s"}
+        i8 = eng.kd_info()
+        reuse = {"tree_steps": 8, "steps": k8, "ms_per_step": 1e3 * e8 / k8, "value": n * k8 / e8, "unit": "particle-steps/s",
+                 "warm_builds": int(i8.warm_builds), "warm_misses": int(i8.warm_misses)}
         eng.set(tree_steps=1)
 
     # the same steps with the mutual (Newton III) near-field kernel, opts.p2p_mutual: its pair kernel runs at a higher fraction of
@@ -528,7 +532,7 @@ def main():
         except Exception as e:   # an extra leg must not take the headline down with it
             out["octree_traceless"] = {"error": str(e)[:200]}
         try:
-            out["cli"] = cli_leg(n, args.order)
+            out["cli"] = cli_leg(n, args.order, args.warmup + args.steps + 26)   # (about the stretch the legs above cover)
         except Exception as e:
             out["cli"] = {"error": str(e)[:200]}
     if rank == 0:
