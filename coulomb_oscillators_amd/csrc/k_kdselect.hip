@@ -699,7 +699,8 @@ int kd_select_level(nbco_ctx *c, int l, long long n, const float4 *pos_in, const
 	{
 		int lg = 0;
 		while ((1LL << lg) < node) ++lg;
-		warm_drop = 32 - std::min(22, std::max(16, lg + 6));
+		// (after misses: 2 bits coarser per miss, i.e. a window 4x as wide, down to 12 bits -- the resolver takes 64 candidates)
+		warm_drop = 32 - std::max(12, std::min(22, std::max(16, lg + 6)) - 2 * c->sel_warm_coarsen);
 	}
 #define NBCO_SEL_ARGS c, l, n, pos_in, unsort_in, pos_out, unsort_out, lbound, rbound, splitdim, index, flag, warm_drop
 	if (big)

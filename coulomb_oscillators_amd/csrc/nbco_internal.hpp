@@ -195,7 +195,8 @@ struct nbco_ctx
 	// warm select (k_kdselect.hip): one histogram pass per level around the previous build's pivots.  used: this build ran it;
 	// a flagged build that used it is repeated cold before anything is escalated, three misses in a row switch it off
 	bool sel_warm_enabled = true, sel_warm_used = false;
-	int sel_warm_strikes = 0;
+	// coarsen: bucket width x 4^coarsen after misses; recent / recent_miss: the current window of 32 warm builds; cooldown: cold builds left
+	int sel_warm_coarsen = 0, sel_warm_good = 0, sel_warm_recent = 0, sel_warm_recent_miss = 0, sel_warm_cooldown = 0, sel_warm_cool_len = 128;
 	long long sel_warm_builds = 0, sel_warm_misses = 0;
 	bool sel_three_pass = false;            // set after the first tie / bucket overflow: three radix passes per select
 	bool force_sort_build = false;          // set after the second: use the sorting build from then on

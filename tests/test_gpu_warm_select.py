@@ -79,16 +79,45 @@ def test_a_missed_window_repeats_the_evaluation_cold(oracle32):
     assert i1.warm_misses == 1 and i2.warm_misses == 1 and i2.warm_builds == i1.warm_builds + 1 and i2.build_mode == 0
 
 
-def test_three_misses_in_a_row_switch_it_off(oracle32):
+def test_repeated_misses_send_it_into_a_cool_down(oracle32):
+    """a miss costs a whole evaluation: two misses within 32 warm builds and the next 128 builds are cold (jumps of 50 % are
+    beyond any window -- the situation of a cloud that keeps changing its shape); results stay the cold ones throughout"""
     import torch
     from coulomb_oscillators_amd import EVAL_FMM_KDTREE
     n = 100000
     e = _engine(True, fmm_order=3, unsort=0)
+    c = _engine(False, fmm_order=3, unsort=0)
     d, prm = _state(oracle32, n)
+    d2 = d.clone()
     e.compute_force(EVAL_FMM_KDTREE, d, n, prm)
-    for k in range(4):
-        d[0].mul_(1.5 if k % 2 == 0 else 1 / 1.5)
+    c.compute_force(EVAL_FMM_KDTREE, d2, n, prm)
+    for k in range(8):
+        for x in (d, d2):
+            x[0].mul_(1.5 if k % 2 == 0 else 1 / 1.5)
         e.compute_force(EVAL_FMM_KDTREE, d, n, prm)
+        c.compute_force(EVAL_FMM_KDTREE, d2, n, prm)
     torch.cuda.synchronize()
     info = e.kd_info()
-    assert info.warm_misses == 3 and info.warm_builds == 3 and torch.isfinite(d).all()
+    assert info.warm_misses == 2 and info.warm_builds == 2 and info.build_mode == 0
+    assert torch.equal(d, d2)
+
+
+@pytest.mark.parametrize("tree_steps", [3, 8])
+def test_list_growth_keeps_the_rebuild_schedule(oracle32, tree_steps):
+    """an engine that has to grow its lists in the middle of a run (list_factor = 1) and one that never has to stay identical: the
+    repeated evaluation follows the rebuild schedule instead of forcing a rebuild"""
+    import torch
+    from coulomb_oscillators_amd import Engine, EVAL_FMM_KDTREE, INTEG_LEAPFROG
+    n, p = 65536, 4
+    out = []
+    for lf in (48, 1):
+        e = Engine(fmm_order=p, unsort=0, tree_steps=tree_steps, list_factor=lf, list_grow=1)
+        d, prm = _state(oracle32, n)
+        e.compute_force(EVAL_FMM_KDTREE, d, n, prm)
+        e.integrate_steps(INTEG_LEAPFROG, EVAL_FMM_KDTREE, d, n, prm, 5e-4, 13)
+        for _ in range(4):
+            e.integrate(INTEG_LEAPFROG, EVAL_FMM_KDTREE, d, n, prm, 5e-4)
+        torch.cuda.synchronize()
+        out.append(d.clone())
+        e.close()
+    assert torch.equal(out[0], out[1])
