@@ -944,6 +944,7 @@ __device__ inline int classify_pair(const TreeView &t, const AdmTab *tab, int2 n
 // the same on preloaded traversal records (centre + size, multiplicity): the traversal kernel fetches the records of a pair's
 // nodes AND of their children in one round trip, before it knows how the pair splits
 struct NodeRec { float4 c; int m; };
+#pragma clang fp contract(off)   // the admissibility test must round exactly like the oracle's (kd_admissible above): no fused multiply-adds
 __device__ inline bool kd_admissible_rec(const NodeRec a, const NodeRec b, int n1, int n2, const AdmTab *tabp, float par)
 {
 	float dx = b.c.x - a.c.x, dy = b.c.y - a.c.y, dz = b.c.z - a.c.z;
@@ -955,6 +956,7 @@ __device__ inline bool kd_admissible_rec(const NodeRec a, const NodeRec b, int n
 	float sz = fmaxf(a.c.w, b.c.w);
 	return parM * parM * sz < dist2;
 }
+#pragma clang fp contract(fast)
 __device__ inline int classify_rec(int ntot, const AdmTab *tab, int2 np, const NodeRec a, const NodeRec b, float par, int m2l_first, const Dom dm)
 {
 	if (dm.d > 0 && !dom_touch(dm, np.x) && !dom_touch(dm, np.y)) return 0;   // nothing below this pair reaches the domain

@@ -52,6 +52,12 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
             note = f" [vs fp64: gpu {eg:.2e}, fp32 oracle {ec:.2e}]"
             ok = eg <= 2 * ec + 1e-6
         if not ok: bad += 1
+        if not same_lists:
+            for k in ("p2p", "m2l"):
+                ga, wa = canon_pairs(e.kd_array(k)), canon_pairs(tree[k])
+                og, ow = np.setdiff1d(ga, wa), np.setdiff1d(wa, ga)
+                fmt = lambda v: [(int(x) >> 32, int(x) & 0xFFFFFFFF) for x in v[:4]]
+                print(f"   {k}: gpu {len(ga)} pairs, oracle {len(wa)}; only gpu {len(og)} {fmt(og)}, only oracle {len(ow)} {fmt(ow)}", flush=True)
         print("OK " if ok else "BAD", f"n={n} p={p} {kind} r={radius} i={dens} L={info.L} mode={info.build_mode} err={err:.2e} lists={same_lists} tree={same_tree}{note}", flush=True)
     except Exception as ex:
         bad += 1; print("EXC", n, p, kind, radius, dens, ex, flush=True)
