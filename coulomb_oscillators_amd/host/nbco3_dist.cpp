@@ -5,11 +5,15 @@
 // of the global kd-tree (rank r's particles are rows [r N/G, (r+1) N/G)).
 //
 //   nbco3_dist -gpus G [-n N] [-p order] [-ds dt] [-iters n] [-steps n] [-r radius] [-i dens] [-rebalance k] [-o folder]
+//              [-exchange let|gather] [-partition dist|gather]
 //
 // The launcher process forks the G ranks BEFORE anything touches the GPU; rank 0's ncclUniqueId reaches the others through
 // pipes.  Per evaluation: subtree build -> all-gather of positions and traversal records ->
 // multipoles -> all-gather of the multipoles, on a communication stream of their own, under the traversal -> lists, near and
 // far field, L2P.  Every `rebalance` evaluations the domains are cut again from the gathered state (nbco_dist_partition).
+// Defaults since round 2 (INTEGRATION.md sections 4a, 4b): the locally-essential-tree exchange -- all-gather of the traversal
+// records only, then grouped ncclSend / ncclRecv of exactly the multipoles and positions the other ranks' lists name -- and the
+// re-partition without gathering the state (nbco_dist_repartition_*: the library names a collective, this host runs it).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -42,6 +46,7 @@ namespace {
 struct Args
 {
 	int gpus = 1, n = 1 << 20, order = 3, iters = 30001, steps = 200, rebalance = 16;
+	bool let = true, dist_partition = true;
 	float dt = 5.e-4f, radius = 1.f, dens = 1.f, xi = 2.e-6f;
 	std::string out = "out";
 };
@@ -57,6 +62,14 @@ struct Rank
 	float *buf = nullptr, *state_all = nullptr, *par = nullptr;
 	char *pos_send = nullptr, *nodes_send = nullptr, *pos_all = nullptr, *nodes_all = nullptr;
 	long long evals = 0;
+	bool let = true, dist_partition = true;
+	// LET exchange: count blocks (device + host), record buffers sized for the worst case (everything needed by everyone)
+	long long *counts_send = nullptr, *counts_all_dev = nullptr;
+	std::vector<long long> counts_all;
+	char *let_pos_send = nullptr, *let_mp_send = nullptr, *let_pos_recv = nullptr, *let_mp_recv = nullptr;
+	// re-partition without gathering the state: the library's workspace
+	char *work = nullptr;
+	long long work_bytes = 0;
 
 	void check(int rc, const char *what)
 	{
@@ -72,8 +85,78 @@ struct Rank
 		HIPCHK(hipEventRecord(done, comm_stream));
 	}
 
+	// grouped point-to-point exchange: rows_send[r] records of `bytes` each go to rank r from consecutive segments of `send`,
+	// rows_recv[s] arrive from rank s into consecutive segments of `recv` (the all-to-all with uneven splits of torch.distributed)
+	void all_to_all(const char *send, char *recv, const long long *rows_send, const long long *rows_recv, size_t bytes, hipStream_t st)
+	{
+		NCCLCHK(ncclGroupStart());
+		size_t so = 0, ro = 0;
+		for (int r = 0; r < world; ++r)
+		{
+			if (rows_send[r] > 0) NCCLCHK(ncclSend(send + so, (size_t)rows_send[r] * bytes, ncclChar, r, comm, st));
+			if (rows_recv[r] > 0) NCCLCHK(ncclRecv(recv + ro, (size_t)rows_recv[r] * bytes, ncclChar, r, comm, st));
+			so += (size_t)rows_send[r] * bytes; ro += (size_t)rows_recv[r] * bytes;
+		}
+		NCCLCHK(ncclGroupEnd());
+	}
+
+	// nbco_dist_repartition_*: every collective the library names runs on the compute stream, in order
+	void repartition()
+	{
+		nbco_dist_step st{};
+		check(nbco_dist_repartition_begin(ctx, buf, lay.n_global, world, rank, work, work_bytes, &st), "nbco_dist_repartition_begin");
+		while (st.op != NBCO_COLL_DONE)
+		{
+			switch (st.op)
+			{
+			case NBCO_COLL_ALLREDUCE_MIN_I32: NCCLCHK(ncclAllReduce(work + st.send_off, work + st.send_off, (size_t)st.count, ncclInt32, ncclMin, comm, nullptr)); break;
+			case NBCO_COLL_ALLREDUCE_SUM_I32: NCCLCHK(ncclAllReduce(work + st.send_off, work + st.send_off, (size_t)st.count, ncclInt32, ncclSum, comm, nullptr)); break;
+			case NBCO_COLL_ALLGATHER: NCCLCHK(ncclAllGather(work + st.send_off, work + st.recv_off, (size_t)st.count, ncclChar, comm, nullptr)); break;
+			case NBCO_COLL_ALLTOALL: all_to_all(work + st.send_off, work + st.recv_off, st.rows_send, st.rows_recv, (size_t)st.row_bytes, nullptr); break;
+			default: std::cerr << "rank " << rank << ": unknown collective " << st.op << std::endl; std::exit(4);
+			}
+			check(nbco_dist_repartition_next(ctx, &st), "nbco_dist_repartition_next");
+		}
+		evals = 0;
+	}
+
+	// one force evaluation with the LET exchange
+	void force_let()
+	{
+		const long long nl = lay.n_local;
+		const int S = lay.let_counts;
+		char *csz_send = nodes_send, *csz_all = nodes_all;
+		check(nbco_dist_let_local_geom(ctx, buf, nl, csz_send), "nbco_dist_let_local_geom");
+		NCCLCHK(ncclAllGather(csz_send, csz_all, (size_t)lay.csz_bytes, ncclChar, comm, nullptr));
+		check(nbco_dist_let_local_mpole(ctx, buf, nl), "nbco_dist_let_local_mpole");
+		for (int round = 0;; ++round)
+		{
+			check(nbco_dist_let_select(ctx, csz_all, counts_send), "nbco_dist_let_select");
+			NCCLCHK(ncclAllGather(counts_send, counts_all_dev, (size_t)S, ncclInt64, comm, nullptr));
+			HIPCHK(hipMemcpyAsync(counts_all.data(), counts_all_dev, sizeof(long long) * (size_t)S * world, hipMemcpyDeviceToHost, nullptr));
+			HIPCHK(hipStreamSynchronize(nullptr));   // the evaluation's one host synchronisation
+			bool overflow = false;
+			for (int s = 0; s < world; ++s) overflow = overflow || counts_all[(size_t)s * S + 2 * world] != 0;
+			if (!overflow) break;
+			if (round == 8) { std::cerr << "rank " << rank << ": the traversal lists keep overflowing" << std::endl; std::exit(4); }
+		}
+		check(nbco_dist_let_pack(ctx, counts_all.data(), let_pos_send, let_mp_send), "nbco_dist_let_pack");
+		std::vector<long long> ps(world), pr(world), ms(world), mr(world);
+		for (int r = 0; r < world; ++r)
+		{
+			ms[r] = counts_all[(size_t)rank * S + 2 * r]; ps[r] = counts_all[(size_t)rank * S + 2 * r + 1];
+			mr[r] = counts_all[(size_t)r * S + 2 * rank]; pr[r] = counts_all[(size_t)r * S + 2 * rank + 1];
+		}
+		all_to_all(let_pos_send, let_pos_recv, ps.data(), pr.data(), 16, nullptr);
+		all_to_all(let_mp_send, let_mp_recv, ms.data(), mr.data(), (size_t)lay.let_node_bytes, nullptr);
+		check(nbco_dist_let_finish(ctx, counts_all.data(), let_pos_recv, let_mp_recv, buf, buf + 6 * nl, par), "nbco_dist_let_finish");
+		check(nbco_add_elastic(ctx, buf, buf + 6 * nl, nl, par + 3), "nbco_add_elastic");
+		++evals;
+	}
+
 	void partition()
 	{
+		if (dist_partition) { repartition(); return; }
 		const long long nl = lay.n_local, N = lay.n_global;
 		gather(buf, state_all, sizeof(float) * 3 * nl, ev_geom);                   // positions
 		gather(buf + 3 * nl, state_all + 3 * N, sizeof(float) * 3 * nl, ev_geom);   // velocities
@@ -85,6 +168,7 @@ struct Rank
 	void force(int rebalance)
 	{
 		if (rebalance > 0 && evals >= rebalance) partition();
+		if (let) { force_let(); return; }
 		const long long nl = lay.n_local;
 		char *csz_send = nodes_send, *mp_send = nodes_send + lay.csz_bytes;
 		char *csz_all = nodes_all, *mp_all = nodes_all + (size_t)world * lay.csz_bytes;
@@ -141,7 +225,25 @@ int run_rank(const Args &a, int rank, const ncclUniqueId &id)
 	if (nbco_init_gaussian(host.data(), N, sx, su, NBCO_REF_SEED, NBCO_REF_DISCARD, 0) != NBCO_OK) return -1;
 	const float parh[6] = {a.xi / (float)N, 0, 0, 1.095f * 1.095f, 1.f, 1.f};
 	HIPCHK(hipMalloc((void **)&r.buf, sizeof(float) * 9 * (size_t)nl));
-	HIPCHK(hipMalloc((void **)&r.state_all, sizeof(float) * 6 * (size_t)N));
+	r.let = a.let; r.dist_partition = a.dist_partition && a.gpus <= 32;
+	if (!r.dist_partition) HIPCHK(hipMalloc((void **)&r.state_all, sizeof(float) * 6 * (size_t)N));
+	else
+	{
+		r.check(nbco_dist_repartition_workspace(r.ctx, N, a.gpus, &r.work_bytes), "nbco_dist_repartition_workspace");
+		HIPCHK(hipMalloc((void **)&r.work, (size_t)r.work_bytes));
+	}
+	if (r.let)
+	{
+		const size_t S = (size_t)r.lay.let_counts, others = (size_t)(a.gpus > 1 ? a.gpus - 1 : 1);
+		HIPCHK(hipMalloc((void **)&r.counts_send, sizeof(long long) * S));
+		HIPCHK(hipMalloc((void **)&r.counts_all_dev, sizeof(long long) * S * a.gpus));
+		r.counts_all.resize(S * a.gpus);
+		// worst case: every other rank needs every particle and every node of this one / this one needs all of theirs
+		HIPCHK(hipMalloc((void **)&r.let_pos_send, 16 * (size_t)nl * others));
+		HIPCHK(hipMalloc((void **)&r.let_pos_recv, 16 * (size_t)nl * others));
+		HIPCHK(hipMalloc((void **)&r.let_mp_send, (size_t)r.lay.let_node_bytes * r.lay.ntot_local * others));
+		HIPCHK(hipMalloc((void **)&r.let_mp_recv, (size_t)r.lay.let_node_bytes * r.lay.ntot_local * others));
+	}
 	HIPCHK(hipMalloc((void **)&r.par, sizeof parh));
 	HIPCHK(hipMalloc((void **)&r.pos_send, (size_t)r.lay.pos_bytes));
 	HIPCHK(hipMalloc((void **)&r.nodes_send, (size_t)r.lay.nodes_bytes));
@@ -210,10 +312,13 @@ int main(int argc, char **argv)
 		else if (f == "-i") a.dens = (float)atof(val());
 		else if (f == "-xi") a.xi = (float)atof(val());
 		else if (f == "-rebalance") a.rebalance = atoi(val());
+		else if (f == "-exchange") { const std::string v = val(); if (v != "let" && v != "gather") { std::cerr << "Error: -exchange let|gather\n"; return -1; } a.let = v == "let"; }
+		else if (f == "-partition") { const std::string v = val(); if (v != "dist" && v != "gather") { std::cerr << "Error: -partition dist|gather\n"; return -1; } a.dist_partition = v == "dist"; }
 		else if (f == "-o") a.out = val();
 		else if (f == "-h" || f == "-help")
 		{
 			std::cout << "Usage: nbco3_dist -gpus G [-n N] [-p order] [-ds dt] [-iters n] [-steps n] [-r radius] [-i dens] [-xi v] [-rebalance k] [-o folder]\n"
+			             "                  [-exchange let|gather] [-partition dist|gather]\n"
 			             "  kd-tree FMM simulation (the nbco3 loop) with the particles sharded by kd-domain over G GPUs of this node, one process\n"
 			             "  per GPU, RCCL all-gathers in between; G a power of two, N a multiple of G with at least 4096 particles per GPU.\n";
 			return 0;

@@ -203,7 +203,8 @@ def test_dist_host_argument_errors(nbco3):
 
 
 @pytest.mark.gpu
-def test_dist_host_one_rank_over_rccl(nbco3, engine, oracle32, tmp_path):
+@pytest.mark.parametrize("mode", [(), ("-exchange", "gather", "-partition", "gather"), ("-exchange", "let", "-partition", "gather")])
+def test_dist_host_one_rank_over_rccl(nbco3, engine, oracle32, tmp_path, mode):
     """`nbco3_dist -gpus 1`: the C++ multi-GPU host (one process per GPU, RCCL all-gathers on a stream of their own, the
     two-stage exchange of INTEGRATION.md section 4) with a world of one -- every collective and every nbco_dist_* stage runs.  Its
     snapshot equals the single-GPU engine driven through the plain ABI (same tree order, same forces: the sharded evaluation
@@ -217,7 +218,9 @@ def test_dist_host_one_rank_over_rccl(nbco3, engine, oracle32, tmp_path):
     # -rebalance 1: the domains are cut again before every evaluation, so the (one) domain's root box is the current bounding box
     # as in the single-GPU build; between cuts a domain keeps the union of its inherited box and its particles' bounds, which is
     # a slightly different -- equally valid -- tree (tests/test_gpu_dist.py::test_sharded_stale_domains_stay_correct)
-    r = run(tool, "-gpus", "1", "-n", str(n), "-p", str(p), "-iters", str(iters), "-steps", str(iters), "-rebalance", "1", "-o", str(out))
+    # mode: default = LET exchange + re-partition without gathering the state (grouped ncclSend / ncclRecv, all-reduces and
+    # all-gathers named by the library); the all-gather forms are kept behind -exchange / -partition
+    r = run(tool, "-gpus", "1", "-n", str(n), "-p", str(p), "-iters", str(iters), "-steps", str(iters), "-rebalance", "1", "-o", str(out), *mode)
     assert r.returncode == 0, r.stderr[-2000:]
     snap = np.fromfile(out / ("out%d_0.000500.bin" % iters), dtype=np.float32).reshape(2, n, 3)
     buf = oracle32.init_reference(n)
