@@ -43,6 +43,8 @@ def parse(argv=None):
     ap.add_argument("--tree-steps", type=int, default=1)
     ap.add_argument("--rebalance", type=int, default=16,
                     help="multi-GPU: force evaluations between two re-partitions of the kd-domains (top log2(G) splits)")
+    ap.add_argument("--gather-partition", action="store_true",
+                    help="multi-GPU: re-partition by all-gathering the state (nbco_dist_partition) instead of the distributed selection")
     ap.add_argument("--no-let", action="store_true",
                     help="multi-GPU: all-gather whole node and position blocks instead of the locally-essential-tree exchange")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -319,10 +321,21 @@ def main():
                                dens_inhom=args.dens_inhom), **extra_opts})
         run = None
         if sharded:
-            run = DomainRun(eng, n_sys, TorchComm(), rebalance=args.rebalance, let=not args.no_let)
-            run.partition(d[0].reshape(-1), d[1].reshape(-1))
-            # precompute accelerations (main3.cu:836-839).  The LET exchange is the one stage no single-card rehearsal can run over
-            # RCCL: should it fail on every rank alike, agree on that and carry on with the all-gather exchange (said in `exchange`)
+            run = DomainRun(eng, n_sys, TorchComm(), rebalance=args.rebalance, let=not args.no_let, gather_partition=args.gather_partition or None)
+            # The re-partition without gathering the state and the LET exchange are the two stages no single-card rehearsal can run
+            # over RCCL: should one fail on every rank alike, agree on that and carry on with its all-gather form (said in `config`)
+            ok = 1
+            try:
+                run.partition(d[0].reshape(-1), d[1].reshape(-1))
+            except Exception as e:   # noqa: BLE001
+                if not run.dpart:
+                    raise
+                print("rank %d: distributed re-partition failed (%s)" % (rank, e), file=sys.stderr)
+                ok = 0
+            if run.dpart and reduce(float(ok), dist.ReduceOp.MIN) < 1:
+                run.use_gather_partition()
+                run.partition(d[0].reshape(-1), d[1].reshape(-1))
+            # precompute accelerations (main3.cu:836-839)
             ok = 1
             try:
                 run.force(prm)
@@ -387,6 +400,8 @@ def main():
         if sharded:
             extra.update({"n_system": n_sys, "rebalance_every": args.rebalance,
                           "exchange": "LET (all-gather of traversal records + variable all-to-all)" if run.let else "all-gather",
+                          "partition": "distributed selection + all-to-all of the movers" if run.dpart else "all-gather of the state + redundant selection",
+                          "partition_bytes_per_gpu": run.partition_bytes,
                           "exchange_bytes_per_eval_per_gpu": run.exchange_bytes(),
                           "allgather_bytes_per_eval_per_gpu": run.allgather_bytes(), "backend": args.backend})
     elif args.workload == "fmm_oct":

@@ -177,6 +177,12 @@ class DomainRun:
         self.last_exchange_bytes = None
         self.evals = 0
 
+    def use_gather_partition(self):
+        """switch to nbco_dist_partition (all-gather of the state + redundant selection)"""
+        self.dpart = False
+        if self.state_all is None:
+            self.state_all = torch.empty(6 * self.n_global, dtype=torch.float32, device=self.device)
+
     def _rows(self, name, rows, width):
         """(rows, width) float32 view of a grow-only scratch buffer"""
         need = max(int(rows), 1) * width
