@@ -184,33 +184,56 @@ __global__ __launch_bounds__(kPrepBlock) void kd_turnaround_kernel(float4 *__res
 	float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
 	const long long stride = (long long)gridDim.x * kPrepBlock, tid = (long long)blockIdx.x * kPrepBlock + threadIdx.x;
 	const float k3[3] = {param[3], param[4], param[5]};
-	for (long long i = tid; i < n; i += stride)
+	// four particles per thread and iteration, loads first: the velocity gather is a chain of two dependent scattered reads, and
+	// 128 workgroups (few, because of the bounding-box atomics below) do not hide that latency with occupancy alone
+	constexpr int U = 4;
+	for (long long i0 = tid; i0 < n; i0 += U * stride)
 	{
-		float x[3], v[3];
-		long long src = i;
-		if (GATHER)
-		{
-			const float4 q = pos4[i];
-			x[0] = q.x; x[1] = q.y; x[2] = q.z;
-			src = unsort[i];
-		}
-		else { x[0] = x3[3 * i]; x[1] = x3[3 * i + 1]; x[2] = x3[3 * i + 2]; }
+		float x[U][3], a[U][3], v[U][3];
+		long long src[U];
 #pragma unroll
-		for (int c = 0; c < 3; ++c)
+		for (int u = 0; u < U; ++u)
 		{
-			float ai = a3[3 * i + c];                                  // finish_kick_kernel (no rescale: the evaluator did it)
-			if (elastic) ai = fmaf(-k3[c], x[c], ai);
-			float vi = fmaf(ks, ai, v_in[3 * src + c]);
-			vi = fmaf(ks, ai, vi);                                     // kick_drift_kernel
-			x[c] = fmaf(ds, vi, x[c]);
-			v[c] = vi;
+			const long long i = i0 + u * stride;
+			src[u] = i;
+			if (i >= n) continue;
+			if (GATHER)
+			{
+				const float4 q = pos4[i];
+				x[u][0] = q.x; x[u][1] = q.y; x[u][2] = q.z;
+				src[u] = unsort[i];
+			}
+			else { x[u][0] = x3[3 * i]; x[u][1] = x3[3 * i + 1]; x[u][2] = x3[3 * i + 2]; }
+			a[u][0] = a3[3 * i]; a[u][1] = a3[3 * i + 1]; a[u][2] = a3[3 * i + 2];
 		}
-		x3[3 * i] = x[0]; x3[3 * i + 1] = x[1]; x3[3 * i + 2] = x[2];
-		v_out[3 * i] = v[0]; v_out[3 * i + 1] = v[1]; v_out[3 * i + 2] = v[2];
-		pos4[i] = make_float4(x[0], x[1], x[2], 0.f);                  // kd_prep_kernel / pack4
-		if (prep) unsort[i] = (int)i;
 #pragma unroll
-		for (int c = 0; c < 3; ++c) { mn[c] = fminf(mn[c], x[c]); mx[c] = fmaxf(mx[c], x[c]); }
+		for (int u = 0; u < U; ++u)
+		{
+			if (i0 + u * stride >= n) continue;
+			v[u][0] = v_in[3 * src[u]]; v[u][1] = v_in[3 * src[u] + 1]; v[u][2] = v_in[3 * src[u] + 2];
+		}
+#pragma unroll
+		for (int u = 0; u < U; ++u)
+		{
+			const long long i = i0 + u * stride;
+			if (i >= n) continue;
+#pragma unroll
+			for (int c = 0; c < 3; ++c)
+			{
+				float ai = a[u][c];                                        // finish_kick_kernel (no rescale: the evaluator did it)
+				if (elastic) ai = fmaf(-k3[c], x[u][c], ai);
+				float vi = fmaf(ks, ai, v[u][c]);
+				vi = fmaf(ks, ai, vi);                                     // kick_drift_kernel
+				x[u][c] = fmaf(ds, vi, x[u][c]);
+				v[u][c] = vi;
+			}
+			x3[3 * i] = x[u][0]; x3[3 * i + 1] = x[u][1]; x3[3 * i + 2] = x[u][2];
+			v_out[3 * i] = v[u][0]; v_out[3 * i + 1] = v[u][1]; v_out[3 * i + 2] = v[u][2];
+			pos4[i] = make_float4(x[u][0], x[u][1], x[u][2], 0.f);          // kd_prep_kernel / pack4
+			if (prep) unsort[i] = (int)i;
+#pragma unroll
+			for (int c = 0; c < 3; ++c) { mn[c] = fminf(mn[c], x[u][c]); mx[c] = fmaxf(mx[c], x[u][c]); }
+		}
 	}
 	if (tid == 0) *flag = 0;
 	if (!prep) return;
