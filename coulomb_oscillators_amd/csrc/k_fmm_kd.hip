@@ -1758,7 +1758,7 @@ static int kd_build_upward(nbco_ctx *c, const float *p, long long n, int L, cons
 			hipLaunchKernelGGL(kd_prep_kernel, dim3(kPrepGrid), dim3(kPrepBlock), 0, st, p, n, pos, unsort, c->sel_hist.as<uint32_t>(), words_a,
 			                   c->sel_nodes.as<uint32_t>(), words_b, c->counters.as<int>() + 110, c->prep_state.as<unsigned>(), tv, root6);
 			// the previous build's boxes are still in the tree arrays: select around its pivots (one pass per level instead of two)
-			bool warm = use_select && l0 > 0 && c->sel_warm_enabled && c->tree_valid && !root6 && !c->sel_three_pass;
+			bool warm = use_select && l0 > 0 && c->sel_warm_enabled && c->tree_valid && !c->sel_three_pass;
 			if (warm && c->sel_warm_cooldown > 0) { --c->sel_warm_cooldown; warm = false; }
 			c->sel_warm_used = warm;
 			if (warm) ++c->sel_warm_builds;
@@ -2300,32 +2300,11 @@ int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 	{
 		// the one-pass select missed a median (or what it left behind tripped the tie flag): the same evaluation with the cold
 		// two-pass select, nothing escalated
-		// A miss costs a whole evaluation, a warm build saves ~5 % of one: it pays while fewer than one build in twenty misses.
-		// Drift-type misses are answered with coarser buckets (a window 4x as wide per miss, three times); a node whose parent
-		// changed its split axis cannot be predicted at all, and while the cloud changes shape that happens every few builds:
-		// two misses within 32 warm builds send the warm select into a cool-down (128 builds, doubling up to 4096).
-		++c->sel_warm_misses;
-		c->sel_warm_good = 0;
-		if (c->sel_warm_coarsen < 3) ++c->sel_warm_coarsen;
-		if (++c->sel_warm_recent_miss >= 2)
-		{
-			c->sel_warm_cooldown = c->sel_warm_cool_len;
-			c->sel_warm_cool_len = std::min(4096, 2 * c->sel_warm_cool_len);
-			c->sel_warm_recent = c->sel_warm_recent_miss = 0;
-		}
+		c->note_warm_miss();
 		c->tree_valid = false;
 		return fmm_kdtree_eval(c, p, a, n, param);
 	}
-	if (rebuild && c->sel_warm_used)
-	{
-		if (++c->sel_warm_recent >= 32) c->sel_warm_recent = c->sel_warm_recent_miss = 0;
-		if (++c->sel_warm_good >= 64)   // a quiet stretch: back towards fine buckets and short cool-downs
-		{
-			if (c->sel_warm_coarsen > 0) --c->sel_warm_coarsen;
-			c->sel_warm_cool_len = std::max(128, c->sel_warm_cool_len / 2);
-			c->sel_warm_good = 0;
-		}
-	}
+	if (rebuild && c->sel_warm_used) c->note_warm_ok();
 	if (cnt.sel_overflow)
 	{
 		// next more conservative build: three radix passes, then the sorting build
@@ -2567,8 +2546,10 @@ int kd_dist_local(nbco_ctx *c, float *buf_local, long long n_local, void *nodes_
 			int flag = 0;
 			NBCO_HIP(hipMemcpyAsync(&flag, c->counters.as<int>() + 110, sizeof(int), hipMemcpyDeviceToHost, st));
 			NBCO_HIP(hipStreamSynchronize(st));
-			if (!flag) break;
-			c->escalate_build();
+			if (!flag) { if (c->sel_warm_used) c->note_warm_ok(); break; }
+			// (a flagged build that ran the warm select is repeated cold first, nothing escalated)
+			if (c->sel_warm_used) c->note_warm_miss();
+			else c->escalate_build();
 			c->tree_valid = false;
 			NBCO_TRY(kd_build_upward(c, buf_local, n_local, lay.L_local, root6, rebuild, 1));
 		}

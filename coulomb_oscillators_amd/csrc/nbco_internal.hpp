@@ -198,6 +198,32 @@ struct nbco_ctx
 	// coarsen: bucket width x 4^coarsen after misses; recent / recent_miss: the current window of 32 warm builds; cooldown: cold builds left
 	int sel_warm_coarsen = 0, sel_warm_good = 0, sel_warm_recent = 0, sel_warm_recent_miss = 0, sel_warm_cooldown = 0, sel_warm_cool_len = 128;
 	long long sel_warm_builds = 0, sel_warm_misses = 0;
+	// A miss costs a whole evaluation, a warm build saves ~5 % of one: it pays while fewer than one build in twenty misses.
+	// Drift-type misses are answered with coarser buckets (a window 4x as wide per miss, three times); a node whose parent
+	// changed its split axis cannot be predicted at all, and while the cloud changes shape that happens every few builds:
+	// two misses within 32 warm builds send the warm select into a cool-down (128 builds, doubling up to 4096).
+	void note_warm_miss()
+	{
+		++sel_warm_misses;
+		sel_warm_good = 0;
+		if (sel_warm_coarsen < 3) ++sel_warm_coarsen;
+		if (++sel_warm_recent_miss >= 2)
+		{
+			sel_warm_cooldown = sel_warm_cool_len;
+			sel_warm_cool_len = sel_warm_cool_len < 2048 ? 2 * sel_warm_cool_len : 4096;
+			sel_warm_recent = sel_warm_recent_miss = 0;
+		}
+	}
+	void note_warm_ok()
+	{
+		if (++sel_warm_recent >= 32) sel_warm_recent = sel_warm_recent_miss = 0;
+		if (++sel_warm_good >= 64)   // a quiet stretch: back towards fine buckets and short cool-downs
+		{
+			if (sel_warm_coarsen > 0) --sel_warm_coarsen;
+			sel_warm_cool_len = sel_warm_cool_len > 256 ? sel_warm_cool_len / 2 : 128;
+			sel_warm_good = 0;
+		}
+	}
 	bool sel_three_pass = false;            // set after the first tie / bucket overflow: three radix passes per select
 	bool force_sort_build = false;          // set after the second: use the sorting build from then on
 	bool escalate_build()                   // next more conservative build; false when there is none left

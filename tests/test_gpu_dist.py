@@ -427,3 +427,36 @@ def test_sharded_stale_domains_stay_correct(oracle32):
     err_sharded, err_single = mean_rel(A), mean_rel(one)
     assert err_single < 2e-2
     assert err_sharded < 1.25 * err_single, (err_sharded, err_single)
+
+
+def test_sharded_local_builds_use_the_warm_select(oracle32):
+    """between two cuts of the domains every rank rebuilds its subtree from slowly moving particles: the local builds run the
+    one-pass (warm) median select, and the run equals the one with cold builds bit for bit"""
+    import os
+    import torch
+    from coulomb_oscillators_amd import Engine, LoopbackWorld
+    n, G, p, steps, dt = 1 << 17, 2, 4, 6, 5e-4
+    pos, vel = make_state(oracle32, n, "reference")
+    par = torch.from_numpy(oracle32.params(n)).cuda()
+    nl = n // G
+    out, warm_builds = [], []
+    for warm in ("1", "0"):
+        os.environ["NBCO_SEL_WARM"] = warm
+        try:
+            engines = [Engine(fmm_order=p, unsort=0, tree_steps=1) for _ in range(G)]
+        finally:
+            del os.environ["NBCO_SEL_WARM"]
+        world = LoopbackWorld(engines, n)
+        world.partition([torch.from_numpy(pos[r * nl:(r + 1) * nl]).cuda() for r in range(G)], [torch.from_numpy(vel[r * nl:(r + 1) * nl]).cuda() for r in range(G)])
+        world.force(par, elastic=True, let=True)
+        for _ in range(steps):
+            for r in world.runs:
+                r.eng.step(r.vel, r.acc, 0.5 * dt, nl); r.eng.step(r.pos, r.vel, dt, nl)
+            world.force(par, elastic=True, let=True)
+            for r in world.runs:
+                r.eng.step(r.vel, r.acc, 0.5 * dt, nl)
+        torch.cuda.synchronize()
+        out.append(torch.cat([r.buf for r in world.runs]))
+        warm_builds.append(sum(int(r.eng.kd_info().warm_builds) for r in world.runs))
+    assert torch.equal(out[0], out[1])
+    assert warm_builds[0] >= G * (steps - 1) and warm_builds[1] == 0
