@@ -28,15 +28,18 @@ class _Done:
 class TorchComm:
     """all-gather over a torch.distributed process group (one rank per GPU)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, always_collective=False):
+        """always_collective: run the collectives even in a world of one (tests: the RCCL code paths, dtypes and reduce ops on the
+        one card the GPU box has)"""
         import torch.distributed as dist
         self.dist = dist
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self.single = self.world == 1 and not always_collective
 
     def all_gather(self, out, inp):
-        if self.world == 1:
+        if self.single:
             out.copy_(inp)
         elif self.dist.get_backend(self.group) == "gloo" and inp.is_cuda:
             # rehearsal mode (several ranks on one card / CPU-only transport): stage through host memory
@@ -49,14 +52,14 @@ class TorchComm:
 
     def all_gather_start(self, out, inp):
         """all_gather that returns at once; .wait() on the result orders the CURRENT stream behind the collective"""
-        if self.world == 1 or (self.dist.get_backend(self.group) == "gloo" and inp.is_cuda):
+        if self.single or (self.dist.get_backend(self.group) == "gloo" and inp.is_cuda):
             self.all_gather(out, inp)
             return _Done()
         return self.dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True)
 
     def all_reduce_i32(self, t, op):
         """in-place MIN / SUM of an int32 tensor"""
-        if self.world == 1:
+        if self.single:
             return
         rop = self.dist.ReduceOp.MIN if op == "min" else self.dist.ReduceOp.SUM
         if self.dist.get_backend(self.group) == "gloo" and t.is_cuda:
@@ -68,7 +71,7 @@ class TorchComm:
 
     def all_to_all(self, out, inp, out_rows, in_rows):
         """variable all-to-all along dim 0: in_rows[r] rows of `inp` go to rank r, out_rows[s] rows of `out` come from rank s"""
-        if self.world == 1:
+        if self.single:
             out.copy_(inp)
         elif self.dist.get_backend(self.group) == "gloo" and inp.is_cuda:
             host = torch.empty(out.shape, dtype=out.dtype)
@@ -79,7 +82,7 @@ class TorchComm:
 
     def all_reduce(self, t, op="sum"):
         """in-place reduction of a small tensor of scalars (energies, bounds)"""
-        if self.world == 1:
+        if self.single:
             return t
         ops = {"sum": self.dist.ReduceOp.SUM, "min": self.dist.ReduceOp.MIN, "max": self.dist.ReduceOp.MAX}
         if self.dist.get_backend(self.group) == "gloo" and t.is_cuda:

@@ -460,3 +460,43 @@ def test_sharded_local_builds_use_the_warm_select(oracle32):
         warm_builds.append(sum(int(r.eng.kd_info().warm_builds) for r in world.runs))
     assert torch.equal(out[0], out[1])
     assert warm_builds[0] >= G * (steps - 1) and warm_builds[1] == 0
+
+
+def test_collectives_over_rccl_in_a_world_of_one(oracle32):
+    """the one card cannot host two RCCL ranks, but a world of one still runs every collective DomainRun issues through RCCL
+    (torch.distributed backend "nccl"): int32 MIN / SUM all-reduces, byte and int64 all-gathers, the asynchronous all-gather,
+    the all-to-all with row splits -- dtypes, views into the workspace, reduce ops.  Result: the single-GPU one."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from coulomb_oscillators_amd import Engine, DomainRun, TorchComm
+    n, p, steps, dt = 65536, 4, 3, 5e-4
+    pos, vel = make_state(oracle32, n, "reference")
+    par = torch.from_numpy(oracle32.params(n)).cuda()
+    e1, ref = single_gpu(n, pos, vel, par, fmm_order=p, unsort=0, tree_steps=1)
+    e1.add_elastic(ref[:3 * n], ref[6 * n:], n, par[3:])
+    for _ in range(steps):
+        e1.step(ref[3 * n:6 * n], ref[6 * n:], 0.5 * dt, n); e1.step(ref[:3 * n], ref[3 * n:6 * n], dt, n)
+        e1.fmm_cart3_kdtree(ref, ref[6 * n:], n, par)
+        e1.add_elastic(ref[:3 * n], ref[6 * n:], n, par[3:])
+        e1.step(ref[3 * n:6 * n], ref[6 * n:], 0.5 * dt, n)
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % port, world_size=1, rank=0, device_id=torch.device("cuda", 0))
+    try:
+        for let in (True, False):
+            run = DomainRun(Engine(fmm_order=p, unsort=0, tree_steps=1), n, TorchComm(always_collective=True), rebalance=1, let=let)
+            assert run.dpart and run.let == let
+            run.partition(torch.from_numpy(pos).cuda().reshape(-1), torch.from_numpy(vel).cuda().reshape(-1))
+            run.force(par)
+            for _ in range(steps):
+                run.leapfrog(par, dt)       # (rebalance = 1: the domain is cut again before every evaluation)
+            if let:
+                run.eng.dist_let_check()
+            kin = run.energy(par)[0]
+            torch.cuda.synchronize()
+            assert torch.equal(run.buf, ref), "let=%s" % let
+            assert kin > 0
+    finally:
+        dist.destroy_process_group()
