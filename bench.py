@@ -45,6 +45,9 @@ def parse(argv=None):
                     help="multi-GPU: force evaluations between two re-partitions of the kd-domains (top log2(G) splits)")
     ap.add_argument("--gather-partition", action="store_true",
                     help="multi-GPU: re-partition by all-gathering the state (nbco_dist_partition) instead of the distributed selection")
+    ap.add_argument("--sharded-one", action="store_true",
+                    help="diagnostics: run the sharded (multi-GPU) pipeline in a world of ONE rank over RCCL -- every stage and collective of "
+                         "DomainRun on one card -- to price the pipeline itself against the plain single-GPU path")
     ap.add_argument("--no-let", action="store_true",
                     help="multi-GPU: all-gather whole node and position blocks instead of the locally-essential-tree exchange")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -274,6 +277,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Libraries below may write to stdout on their own (RCCL prints a version banner when its first communicator comes up): the
+    # process's stdout carries the ONE JSON line and nothing else, everything before it goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         devidx = local_rank % torch.cuda.device_count()
@@ -284,8 +292,13 @@ def main():
             dist.init_process_group(backend="gloo")
     else:
         torch.cuda.set_device(0)
+        if args.sharded_one:
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                port = s_.getsockname()[1]
+            dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % port, world_size=1, rank=0, device_id=torch.device("cuda", 0))
     n = args.n
-    sharded = world > 1 and args.workload == "fmm_kd"
+    sharded = (world > 1 or args.sharded_one) and args.workload == "fmm_kd"
     slabbed = world > 1 and args.workload == "fmm_oct"      # ONE system of --particles, slabs of the cell order (strong scaling)
     kind = {"fmm_kd": EVAL_FMM_KDTREE, "fmm_oct": EVAL_FMM_TRACELESS, "direct": EVAL_DIRECT}[args.workload]
     if args.far_fp64 and args.workload != "fmm_oct":
@@ -321,7 +334,8 @@ def main():
                                dens_inhom=args.dens_inhom), **extra_opts})
         run = None
         if sharded:
-            run = DomainRun(eng, n_sys, TorchComm(), rebalance=args.rebalance, let=not args.no_let, gather_partition=args.gather_partition or None)
+            run = DomainRun(eng, n_sys, TorchComm(always_collective=args.sharded_one), rebalance=args.rebalance, let=not args.no_let,
+                            gather_partition=args.gather_partition or None)
             # The re-partition without gathering the state and the LET exchange are the two stages no single-card rehearsal can run
             # over RCCL: should one fail on every rank alike, agree on that and carry on with its all-gather form (said in `config`)
             ok = 1
@@ -553,8 +567,10 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and args.workload != "fmm_oct":
             out["cpu_baseline"] = cpu_baseline(args, n)
-        print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+        os.dup2(json_fd, 1)
+        print(json.dumps(out), flush=True)
+    if world > 1 or args.sharded_one:
         dist.destroy_process_group()
 
 

@@ -2538,8 +2538,21 @@ int kd_dist_local(nbco_ctx *c, float *buf_local, long long n_local, void *nodes_
 		TopView top = top_view(c, ntop);
 		float *root6 = c->small.as<float>() + 80;
 		hipLaunchKernelGGL(dist_root6_kernel, dim3(1), dim3(64), 0, st, (const float *)top.lbound, (const float *)top.rbound, (1 << d) - 1 + lay.rank, root6);
+		if (let_stage == 1 && c->dist.let_selected)
+		{
+			// called again after a round in which some rank's build was flagged (the flags travel with the LET counts, so the LET
+			// path needs no host round trip behind the build): repeat this rank's build more conservatively if it was the one
+			NBCO_TRY(c->wait_flags());
+			if (c->h_flags[3] != 0)
+			{
+				if (c->sel_warm_used) c->note_warm_miss();
+				else if (!c->escalate_build()) return c->fail(NBCO_ERR_UNSUPPORTED, "kd-tree build: tie flag raised by the sorting build");
+				c->tree_valid = false;
+			}
+			c->dist.let_selected = c->dist.let_packed = c->dist.traversed = c->dist.local_done = false;
+		}
 		NBCO_TRY(kd_build_upward(c, buf_local, n_local, lay.L_local, root6, rebuild, 1));
-		while (rebuild && !c->force_sort_build)
+		while (rebuild && !c->force_sort_build && let_stage != 1)
 		{
 			// A tie overflow of the selection build has to be caught BEFORE the exchange (the other domains are
 			// about to consume these positions and nodes); the retry with a more conservative build is purely local.
@@ -2688,7 +2701,7 @@ __global__ void let_counts_kernel(const int *__restrict__ cursors, const int *__
 {
 	const int r = threadIdx.x;
 	if (r < G) { counts[2 * r] = cursors[4 * r]; counts[2 * r + 1] = cursors[4 * r + 2]; }
-	if (r == 0) { counts[2 * G] = counters[2] != 0; counts[2 * G + 1] = 0; }
+	if (r == 0) { counts[2 * G] = counters[2] != 0; counts[2 * G + 1] = counters[110] != 0; }   // list overflow; the build's tie / warm-miss flag
 }
 
 struct LetBases { long long v[65]; };   // first record of every receiver's (sender's) segment
@@ -2867,7 +2880,12 @@ int kd_dist_let_pack(nbco_ctx *c, const long long *counts_all, void *pos_send, v
 	NBCO_TRY(kd_dist_layout(c, c->dist.n_global, c->dist.world, c->dist.rank, &lay));
 	const int G = lay.world, S = 2 * G + 2, offM = sym_off(lay.order), rec = let_rec_floats(offM);
 	for (int s = 0; s < G; ++s)
+	{
 		if (counts_all[(size_t)s * S + 2 * G]) return c->fail(NBCO_ERR_CAPACITY, "nbco_dist_let_pack: a rank reported list overflow; repeat nbco_dist_let_select on every rank");
+		if (counts_all[(size_t)s * S + 2 * G + 1])
+			return c->fail(NBCO_ERR_CAPACITY, "nbco_dist_let_pack: a rank's tree build was flagged; repeat the evaluation from nbco_dist_let_local_geom on every rank");
+	}
+	if (c->sel_warm_used && c->dist.rebuilt) c->note_warm_ok();
 	const long long *mine = counts_all + (size_t)lay.rank * S;
 	LetBases nb{}, pb{};
 	long long nmax = 0, lmax = 0;

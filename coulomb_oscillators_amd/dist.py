@@ -327,15 +327,20 @@ class DomainRun:
     def _force_let(self, param):
         cb, G = self.csz_bytes, self.world
         csz_send, csz_all = self.nodes_send[:cb], self.nodes_all[: G * cb]
-        self.eng.dist_let_local_geom(self.buf, self.n_local, csz_send)
-        h_csz = self.comm.all_gather_start(csz_all, csz_send)
-        self.eng.dist_let_local_mpole(self.buf, self.n_local)
-        h_csz.wait()
 
         def gather():
             self.comm.all_gather(self.counts_all, self.counts_send)
             return self.counts_all.cpu()   # the one host synchronisation of the evaluation
-        M = self._let_counts(csz_all, gather)
+        for _ in range(6):
+            self.eng.dist_let_local_geom(self.buf, self.n_local, csz_send)
+            h_csz = self.comm.all_gather_start(csz_all, csz_send)
+            self.eng.dist_let_local_mpole(self.buf, self.n_local)
+            h_csz.wait()
+            M = self._let_counts(csz_all, gather)
+            if not bool(M.view(G, int(self.lay.let_counts))[:, 2 * G + 1].any()):
+                break   # (else: some rank's build was flagged -- its flag came with the counts -- and everybody starts over)
+        else:
+            raise RuntimeError("LET exchange: a tree build kept being flagged")
         send_n, send_p, recv_n, recv_p = self._let_splits(M)
         pos_send, mp_send = self._rows("ps", sum(send_p), 4), self._rows("ms", sum(send_n), self.rec)
         pos_recv, mp_recv = self._rows("pr", sum(recv_p), 4), self._rows("mr", sum(recv_n), self.rec)
@@ -476,20 +481,25 @@ class LoopbackWorld:
         """the LET exchange in lockstep; tamper(rank, pos_recv, mp_recv) may damage what a rank received (guard tests)"""
         runs, G = self.runs, self.G
         cb, S = runs[0].csz_bytes, int(runs[0].lay.let_counts)
-        for r in runs:
-            r.eng.dist_let_local_geom(r.buf, r.n_local, r.nodes_send[:cb])
-        csz = torch.cat([r.nodes_send[:cb] for r in runs])
-        for r in runs:
-            r.eng.dist_let_local_mpole(r.buf, r.n_local)
-            r.nodes_all[: G * cb].copy_(csz)
-        for _ in range(8):
+        for _ in range(6):
             for r in runs:
-                r.eng.dist_let_select(r.nodes_all[: G * cb], r.counts_send)
-            M = torch.cat([r.counts_send for r in runs]).cpu()
-            if not bool(M.view(G, S)[:, 2 * G].any()):
-                break
+                r.eng.dist_let_local_geom(r.buf, r.n_local, r.nodes_send[:cb])
+            csz = torch.cat([r.nodes_send[:cb] for r in runs])
+            for r in runs:
+                r.eng.dist_let_local_mpole(r.buf, r.n_local)
+                r.nodes_all[: G * cb].copy_(csz)
+            for _ in range(8):
+                for r in runs:
+                    r.eng.dist_let_select(r.nodes_all[: G * cb], r.counts_send)
+                M = torch.cat([r.counts_send for r in runs]).cpu()
+                if not bool(M.view(G, S)[:, 2 * G].any()):
+                    break
+            else:
+                raise RuntimeError("LET exchange: the traversal lists kept overflowing")
+            if not bool(M.view(G, S)[:, 2 * G + 1].any()):
+                break   # (else: some rank's build was flagged and everybody starts over)
         else:
-            raise RuntimeError("LET exchange: the traversal lists kept overflowing")
+            raise RuntimeError("LET exchange: a tree build kept being flagged")
         M2 = M.view(G, S)
         sends = []
         for r in runs:

@@ -126,6 +126,8 @@ struct Rank
 		const long long nl = lay.n_local;
 		const int S = lay.let_counts;
 		char *csz_send = nodes_send, *csz_all = nodes_all;
+		for (int attempt = 0;; ++attempt)
+		{
 		check(nbco_dist_let_local_geom(ctx, buf, nl, csz_send), "nbco_dist_let_local_geom");
 		NCCLCHK(ncclAllGather(csz_send, csz_all, (size_t)lay.csz_bytes, ncclChar, comm, nullptr));
 		check(nbco_dist_let_local_mpole(ctx, buf, nl), "nbco_dist_let_local_mpole");
@@ -139,6 +141,12 @@ struct Rank
 			for (int s = 0; s < world; ++s) overflow = overflow || counts_all[(size_t)s * S + 2 * world] != 0;
 			if (!overflow) break;
 			if (round == 8) { std::cerr << "rank " << rank << ": the traversal lists keep overflowing" << std::endl; std::exit(4); }
+		}
+		// a flagged tree build somewhere (its flag travels with the counts: no host round trip behind the build): everybody starts over
+		bool flagged = false;
+		for (int s = 0; s < world; ++s) flagged = flagged || counts_all[(size_t)s * S + 2 * world + 1] != 0;
+		if (!flagged) break;
+		if (attempt == 5) { std::cerr << "rank " << rank << ": a tree build keeps being flagged" << std::endl; std::exit(4); }
 		}
 		check(nbco_dist_let_pack(ctx, counts_all.data(), let_pos_send, let_mp_send), "nbco_dist_let_pack");
 		std::vector<long long> ps(world), pr(world), ms(world), mr(world);

@@ -311,9 +311,13 @@ int nbco_dist_finish_rest(nbco_ctx *c, const void *mpole_all, float *buf_local, 
  *   _let_local_mpole  upward pass on the second stream (the multipoles stay on the device)
  *   _let_select       csz_all = world x csz_bytes: global geometry, traversal, selection; writes this rank's count block to
  *                     counts_send (DEVICE, let_counts 64-bit values: [2 r] node records / [2 r + 1] position records it
- *                     will send to rank r, [2 world] = 1 when its traversal ran out of list room)  -> all-gather, copy to host
- *                     If any rank's block reports overflow, every rank calls _let_select again (it repeats the traversal
- *                     with more room where needed, is a no-op elsewhere) and the blocks are gathered again.
+ *                     will send to rank r, [2 world] = 1 when its traversal ran out of list room, [2 world + 1] = 1 when its
+ *                     tree build was flagged -- pivot ties beyond the resolver, a missed warm-select window)
+ *                                                                                                  -> all-gather, copy to host
+ *                     If any rank's block reports list overflow, every rank calls _let_select again (it repeats the traversal
+ *                     with more room where needed, is a no-op elsewhere) and the blocks are gathered again.  If any reports a
+ *                     flagged build, every rank starts the evaluation again from _let_local_geom (the flagged rank builds more
+ *                     conservatively, the others reproduce their trees): the LET form needs no host round trip behind the build.
  *   _let_pack         counts_all = the gathered blocks on the HOST, [sender][let_counts]; fills pos_send (16 B records
  *                     {x, y, z, global particle index}) and mpole_send (let_node_bytes records {global node id, multipole}),
  *                     segments in receiver order                                                  -> two all-to-alls with

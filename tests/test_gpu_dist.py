@@ -500,3 +500,38 @@ def test_collectives_over_rccl_in_a_world_of_one(oracle32):
             assert kin > 0
     finally:
         dist.destroy_process_group()
+
+
+def test_flagged_build_restarts_the_let_evaluation(oracle32):
+    """LET form: no host round trip behind the local build -- a flagged build (here: the warm select misses after the positions
+    were stretched by 30 %) is reported with the counts and every rank starts the evaluation over; same result as with cold
+    builds, which are never flagged here"""
+    import os
+    import torch
+    from coulomb_oscillators_amd import Engine, LoopbackWorld
+    n, G, p = 1 << 17, 2, 4
+    pos, vel = make_state(oracle32, n, "reference")
+    par = torch.from_numpy(oracle32.params(n)).cuda()
+    nl = n // G
+    out, misses = [], []
+    for warm in ("1", "0"):
+        os.environ["NBCO_SEL_WARM"] = warm
+        try:
+            engines = [Engine(fmm_order=p, unsort=0, tree_steps=1) for _ in range(G)]
+        finally:
+            del os.environ["NBCO_SEL_WARM"]
+        world = LoopbackWorld(engines, n)
+        world.partition([torch.from_numpy(pos[r * nl:(r + 1) * nl]).cuda() for r in range(G)], [torch.from_numpy(vel[r * nl:(r + 1) * nl]).cuda() for r in range(G)])
+        world.force(par, elastic=False, let=True)
+        world.force(par, elastic=False, let=True)
+        for r in world.runs:
+            r.pos.mul_(1.3)
+        world.force(par, elastic=False, let=True)
+        world.force(par, elastic=False, let=True)
+        for r in world.runs:
+            r.eng.dist_let_check()
+        torch.cuda.synchronize()
+        out.append(torch.cat([r.buf for r in world.runs]))
+        misses.append(sum(int(r.eng.kd_info().warm_misses) for r in world.runs))
+    assert torch.equal(out[0], out[1])
+    assert misses[0] >= 1 and misses[1] == 0
