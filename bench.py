@@ -366,10 +366,8 @@ def main():
                 run.partition(d[0].reshape(-1), d[1].reshape(-1))
                 run.force(prm)
             step = lambda: run.leapfrog(prm, args.dt)
-
-            def run_steps(k):
-                for _ in range(k):
-                    step()
+            # K steps with ONE pass between two force evaluations (nbco_dist_turnaround), as the single-GPU path does
+            run_steps = (lambda k: run.leapfrog_steps(prm, args.dt, k)) if not args.step_calls else (lambda k: [step() for _ in range(k)])
         elif slabbed:
             run = SlabRun(eng, n_local, TorchComm())
             run.set_state(d[0], d[1])

@@ -179,7 +179,8 @@ __global__ __launch_bounds__(kPrepBlock) void kd_turnaround_kernel(float4 *__res
                                                                    const float *v_in, float *v_out, const float *__restrict__ a3,
                                                                    const float *__restrict__ param, float ks, float ds, int elastic, long long n, int prep,
                                                                    uint32_t *__restrict__ zero_a, long long words_a, uint32_t *__restrict__ zero_b,
-                                                                   long long words_b, int *__restrict__ flag, unsigned *__restrict__ state, TreeView t)
+                                                                   long long words_b, int *__restrict__ flag, unsigned *__restrict__ state, TreeView t,
+                                                                   const float *__restrict__ root6)
 {
 	float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
 	const long long stride = (long long)gridDim.x * kPrepBlock, tid = (long long)blockIdx.x * kPrepBlock + threadIdx.x;
@@ -268,6 +269,8 @@ __global__ __launch_bounds__(kPrepBlock) void kd_turnaround_kernel(float4 *__res
 		__hip_atomic_store(&state[c], c < 3 ? 0xFFFFFFFFu : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 	__hip_atomic_store(&state[6], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	if (root6)   // a kd-domain keeps the union of its inherited box and the current bounds (as kd_prep_kernel does)
+		for (int c = 0; c < 3; ++c) { b[c] = fminf(b[c], root6[c]); b[3 + c] = fmaxf(b[3 + c], root6[3 + c]); }
 	t.lbound[0] = b[0]; t.lbound[1] = b[1]; t.lbound[2] = b[2];
 	t.rbound[0] = b[3]; t.rbound[1] = b[4]; t.rbound[2] = b[5];
 	t.splitdim[0] = longest_axis(b[3] - b[0], b[4] - b[1], b[5] - b[2]);
@@ -2235,7 +2238,8 @@ int kd_finish_pending_order(nbco_ctx *c, float *p, long long n)
 
 // nbco_integrate_steps, between the force evaluation of one leapfrog step and that of the next (kd_turnaround_kernel).  v_in: where
 // the current velocities are (the caller's array or the scratch copy of the turnaround before); returns where they are now.
-int kd_turnaround(nbco_ctx *c, float *p, const float *v_in, const float **v_now, const float *param, float ks, float ds, bool elastic, long long n)
+int kd_turnaround(nbco_ctx *c, float *p, const float *v_in, const float **v_now, const float *param, float ks, float ds, bool elastic, long long n,
+                  const float *root6)
 {
 	const bool gather = c->order_pending;
 	c->order_pending = false;
@@ -2262,7 +2266,7 @@ int kd_turnaround(nbco_ctx *c, float *p, const float *v_in, const float **v_now,
 	TreeView tv = view_of(c->kd);
 	hipStream_t st = c->stream;
 #define NBCO_TURN_ARGS c->pos4.as<float4>(), c->unsort.as<int>(), x, v_in, v_out, (const float *)a, param, ks, ds, elastic ? 1 : 0, n, next_rebuild ? 1 : 0, \
-	c->sel_hist.as<uint32_t>(), words_a, c->sel_nodes.as<uint32_t>(), words_b, c->counters.as<int>() + 110, c->prep_state.as<unsigned>(), tv
+	c->sel_hist.as<uint32_t>(), words_a, c->sel_nodes.as<uint32_t>(), words_b, c->counters.as<int>() + 110, c->prep_state.as<unsigned>(), tv, root6
 	if (gather) hipLaunchKernelGGL(kd_turnaround_kernel<true>, dim3(kPrepGrid), dim3(kPrepBlock), 0, st, NBCO_TURN_ARGS);
 	else hipLaunchKernelGGL(kd_turnaround_kernel<false>, dim3(kPrepGrid), dim3(kPrepBlock), 0, st, NBCO_TURN_ARGS);
 #undef NBCO_TURN_ARGS
@@ -2461,8 +2465,27 @@ int kd_dist_top_arrays(nbco_ctx *c, int ntop, float **lb, float **rb, int **sd, 
 	return NBCO_OK;
 }
 // what nbco_dist_partition leaves behind besides the domain's state and the top boxes
+// between the force evaluation of one leapfrog step of a sharded run and that of the next: elastic term, both half kicks, drift and
+// the next local build's prologue in one pass over the domain's state (kd_turnaround_kernel; the state is in tree order already)
+int kd_dist_turnaround(nbco_ctx *c, float *buf_local, long long n_local, const float *param, float ks, float ds, bool elastic)
+{
+	if (!c->dist.partitioned || n_local != c->dist.n_local || !c->tree_valid)
+		return c->fail(NBCO_ERR_ARG, "nbco_dist_turnaround: call it right after a sharded force evaluation");
+	nbco_dist_layout lay;
+	NBCO_TRY(kd_dist_layout(c, c->dist.n_global, c->dist.world, c->dist.rank, &lay));
+	const int d = lay.d, ntop = (1 << (d + 1)) - 1;
+	TopView top = top_view(c, ntop);
+	float *root6 = c->small.as<float>() + 80;
+	hipLaunchKernelGGL(dist_root6_kernel, dim3(1), dim3(64), 0, c->stream, (const float *)top.lbound, (const float *)top.rbound, (1 << d) - 1 + lay.rank, root6);
+	const float *v_now = nullptr;
+	c->order_pending = false;
+	NBCO_TRY(kd_turnaround(c, buf_local, buf_local + 3 * n_local, &v_now, param, ks, ds, elastic, n_local, root6));
+	return NBCO_OK;
+}
+
 int kd_dist_set_partitioned(nbco_ctx *c, long long n_global, int world, int rank)
 {
+	c->skip_prep = 0;   // (a prologue done by nbco_dist_turnaround belonged to the state before the cut)
 	nbco_dist_layout lay;
 	NBCO_TRY(kd_dist_layout(c, n_global, world, rank, &lay));
 	c->dist.world = world; c->dist.rank = rank; c->dist.d = lay.d; c->dist.n_global = n_global; c->dist.n_local = lay.n_local; c->dist.L = lay.L;
@@ -2513,6 +2536,7 @@ int kd_dist_partition(nbco_ctx *c, const float *state_all, long long n_global, i
 	c->dist.world = world; c->dist.rank = rank; c->dist.d = d; c->dist.n_global = n_global; c->dist.n_local = nl; c->dist.L = lay.L;
 	c->dist.partitioned = true;
 	c->tree_valid = false;
+	c->skip_prep = 0;
 	return NBCO_OK;
 }
 

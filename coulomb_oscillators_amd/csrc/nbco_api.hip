@@ -405,6 +405,12 @@ int nbco_dist_let_finish(nbco_ctx *c, const long long *counts_all, const void *p
 	NBCO_TRY(kd_dist_let_finish(c, counts_all, pos_recv, mpole_recv, buf_local, a_local, param));
 	return maybe_sync(c);
 }
+int nbco_dist_turnaround(nbco_ctx *c, float *buf_local, long long n_local, const float *param, double dt_, double scale_, int elastic)
+{
+	if (!c || !buf_local || !param) return c ? c->fail(NBCO_ERR_ARG, "nbco_dist_turnaround: null pointer") : NBCO_ERR_ARG;
+	const long double dt = dt_, scale = scale_;
+	return kd_dist_turnaround(c, buf_local, n_local, param, (float)(dt * scale * 0.5L), (float)dt, elastic != 0);
+}
 int nbco_dist_let_check(nbco_ctx *c)
 {
 	if (!c) return NBCO_ERR_ARG;

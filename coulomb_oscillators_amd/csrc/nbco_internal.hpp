@@ -333,7 +333,9 @@ int dpart_workspace(nbco_ctx *c, long long n_global, int world, long long *bytes
 int dpart_begin(nbco_ctx *c, float *state_local, long long n_global, int world, int rank, void *work, long long work_bytes, nbco_dist_step *out);
 int dpart_next(nbco_ctx *c, nbco_dist_step *out);
 int kd_finish_pending_order(nbco_ctx *c, float *p, long long n);
-int kd_turnaround(nbco_ctx *c, float *p, const float *v_in, const float **v_now, const float *param, float ks, float ds, bool elastic, long long n);
+int kd_turnaround(nbco_ctx *c, float *p, const float *v_in, const float **v_now, const float *param, float ks, float ds, bool elastic, long long n,
+                  const float *root6 = nullptr);
+int kd_dist_turnaround(nbco_ctx *c, float *buf_local, long long n_local, const float *param, float ks, float ds, bool elastic);
 int kd_dist_let_select(nbco_ctx *c, const void *csz_all, long long *counts);
 int kd_dist_let_pack(nbco_ctx *c, const long long *counts_all, void *pos_send, void *mpole_send);
 int kd_dist_let_finish(nbco_ctx *c, const long long *counts_all, const void *pos_recv, const void *mpole_recv, float *buf_local, float *a_local, const float *param);

@@ -396,6 +396,27 @@ class DomainRun:
         self.eng.step(self.vel, self.acc, 0.5 * dt, nl)
 
 
+    def leapfrog_steps(self, param, dt, steps, elastic=True):
+        """`steps` kick-drift-kick steps; between two force evaluations ONE pass over the domain's state (nbco_dist_turnaround)
+        instead of add_elastic + three step kernels + the next build's prologue.  Same final state as `steps` calls of leapfrog()."""
+        nl = self.n_local
+        if steps <= 0:
+            return
+        if not hasattr(self.eng, "dist_turnaround") or param is None:
+            for _ in range(steps):
+                self.leapfrog(param, dt, elastic)
+            return
+        self.eng.step(self.vel, self.acc, 0.5 * dt, nl)
+        self.eng.step(self.pos, self.vel, dt, nl)
+        for s in range(steps):
+            self.force(param, elastic=False)
+            if s + 1 < steps:
+                self.eng.dist_turnaround(self.buf, nl, param, dt, 1.0, elastic)
+        if elastic:
+            self.eng.add_elastic(self.pos, self.acc, nl, param[3:])
+        self.eng.step(self.vel, self.acc, 0.5 * dt, nl)
+
+
 class LoopbackWorld:
     """G domains driven in lockstep inside ONE process / on ONE GPU (one Engine context per domain).
 

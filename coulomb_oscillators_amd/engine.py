@@ -142,6 +142,7 @@ def _load():
         "nbco_dist_let_pack": [P, P, P, P],
         "nbco_dist_let_finish": [P, P, P, P, P, P, P],
         "nbco_dist_let_check": [P],
+        "nbco_dist_turnaround": [P, P, LL, P, D, D, I],
         "nbco_aux_stream": [P, C.POINTER(C.c_void_p)],
         "nbco_debug_violations": [P, C.POINTER(LL)],
         "nbco_profile_enable": [P, I],
@@ -365,6 +366,10 @@ class Engine:
     def dist_let_finish(self, counts_all_host, pos_recv, mpole_recv, buf_local, a_local, param=None):
         self._chk(self.lib.nbco_dist_let_finish(self.ctx, _ptr(counts_all_host), _ptr(pos_recv), _ptr(mpole_recv), _ptr(buf_local), _ptr(a_local),
                                                 _ptr(param)))
+
+    def dist_turnaround(self, buf_local, n_local, param, dt, scale=1.0, elastic=True):
+        """one pass between two force evaluations of a sharded leapfrog run (nbco_dist_turnaround)"""
+        self._chk(self.lib.nbco_dist_turnaround(self.ctx, _ptr(buf_local), n_local, _ptr(param), dt, scale, int(elastic)))
 
     def dist_let_check(self):
         self._chk(self.lib.nbco_dist_let_check(self.ctx))

@@ -333,6 +333,13 @@ int nbco_dist_let_pack(nbco_ctx *c, const long long *counts_all, void *pos_send,
 int nbco_dist_let_finish(nbco_ctx *c, const long long *counts_all, const void *pos_recv, const void *mpole_recv, float *buf_local,
                          float *a_local, const float *param);
 int nbco_dist_let_check(nbco_ctx *c);
+/* Between the force evaluation of one leapfrog step of a sharded run and that of the next (any of the three forms above; the
+ * accelerations a_local = buf_local + 6 n_local are those nbco_dist_*finish* wrote, WITHOUT the elastic term): one pass over the
+ * domain's state that does  a -= k o x (elastic != 0), v += a dt scale / 2  [end of this step]  and  v += a dt scale / 2,
+ * x += v dt  [start of the next]  -- the same operations with the same roundings as nbco_add_elastic + three nbco_step calls --
+ * and the next local build's prologue.  The next call on this context must be the next evaluation's nbco_dist_local* /
+ * nbco_dist_let_local_geom (a re-partition in between is fine: it discards the prologue). */
+int nbco_dist_turnaround(nbco_ctx *c, float *buf_local, long long n_local, const float *param, double dt, double scale, int elastic);
 /* The context's second stream (hipStream_t), on which the far-field chain runs and which alone reads mpole_all in
  * nbco_dist_finish_rest: a caller whose collective runs on its own stream can make THIS stream wait for the multipole
  * all-gather (hipStreamWaitEvent before calling _finish_rest) instead of the compute stream, so that the near-field

@@ -498,6 +498,15 @@ def test_collectives_over_rccl_in_a_world_of_one(oracle32):
             torch.cuda.synchronize()
             assert torch.equal(run.buf, ref), "let=%s" % let
             assert kin > 0
+            # and K more steps with the fused pass in between (DomainRun.leapfrog_steps) against K more calls of leapfrog
+            twin = DomainRun(Engine(fmm_order=p, unsort=0, tree_steps=1), n, TorchComm(always_collective=True), rebalance=1, let=let)
+            twin.partition(torch.from_numpy(pos).cuda().reshape(-1), torch.from_numpy(vel).cuda().reshape(-1))
+            twin.force(par)
+            for _ in range(steps + 4):
+                twin.leapfrog(par, dt)
+            run.leapfrog_steps(par, dt, 4)
+            torch.cuda.synchronize()
+            assert torch.equal(run.buf, twin.buf), "leapfrog_steps, let=%s" % let
     finally:
         dist.destroy_process_group()
 
@@ -535,3 +544,38 @@ def test_flagged_build_restarts_the_let_evaluation(oracle32):
         misses.append(sum(int(r.eng.kd_info().warm_misses) for r in world.runs))
     assert torch.equal(out[0], out[1])
     assert misses[0] >= 1 and misses[1] == 0
+
+
+@pytest.mark.parametrize("tree_steps,recut", [(1, 0), (3, 0), (1, 4)])
+def test_sharded_turnaround_equals_step_kernels(oracle32, tree_steps, recut):
+    """nbco_dist_turnaround (one pass between two force evaluations of a sharded leapfrog run: elastic term, both half kicks, drift,
+    next build's prologue) against nbco_add_elastic + three nbco_step calls + the build's own prologue: same state bit for bit,
+    through tree reuse and through a re-cut of the domains in the middle (which discards the prologue)"""
+    import torch
+    n, G, p, steps, dt = 1 << 17, 4, 4, 7, 5e-4
+    pos, vel = make_state(oracle32, n, "reference")
+    par = torch.from_numpy(oracle32.params(n)).cuda()
+    nl = n // G
+    out = []
+    for fused in (False, True):
+        w = loopback(n, G, pos, vel, fmm_order=p, unsort=0, tree_steps=tree_steps)
+        w.force(par, elastic=True, let=True)
+        for r in w.runs:
+            r.eng.step(r.vel, r.acc, 0.5 * dt, nl); r.eng.step(r.pos, r.vel, dt, nl)
+        for k in range(steps):
+            if recut and k == recut:
+                w.partition([r.pos for r in w.runs], [r.vel for r in w.runs])
+            w.force(par, elastic=False, let=True)
+            last = k + 1 == steps
+            for r in w.runs:
+                if fused and not last:
+                    r.eng.dist_turnaround(r.buf, nl, par, dt)
+                else:
+                    r.eng.add_elastic(r.pos, r.acc, nl, par[3:])
+                    r.eng.step(r.vel, r.acc, 0.5 * dt, nl)
+                    if not last:
+                        r.eng.step(r.vel, r.acc, 0.5 * dt, nl); r.eng.step(r.pos, r.vel, dt, nl)
+        torch.cuda.synchronize()
+        # (the fused pass does not write the accelerations of the steps in between: compare positions, velocities and the last ones)
+        out.append(torch.cat([r.buf for r in w.runs]))
+    assert torch.equal(out[0], out[1])
