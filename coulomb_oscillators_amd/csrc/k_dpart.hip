@@ -423,7 +423,6 @@ static int dpart_advance(nbco_ctx *c, nbco_dist_step *out)
 	auto start_hist = [&]() {
 		const int m = 1 << s.level;
 		NBCO_HIP(hipMemsetAsync(coll, 0, sizeof(int) * (size_t)m * kBins, st));
-		if (trace) fprintf(stderr, "   memset: %s\n", hipGetErrorString(hipStreamSynchronize(st)));
 		hipLaunchKernelGGL(dp_hist_kernel, dim3(kGX, m), dim3(kB), 0, st, (const float4 *)P, (const int *)seg, (const DpNode *)nd, s.pass, coll);
 		NBCO_HIP(hipGetLastError());
 		s.stage = ST_HIST;
@@ -439,10 +438,6 @@ static int dpart_advance(nbco_ctx *c, nbco_dist_step *out)
 	{
 		const hipError_t e = hipStreamSynchronize(st);
 		fprintf(stderr, "[dpart rank %d] stage %d level %d pass %d (%s)\n", s.rank, s.stage, s.level, s.pass, hipGetErrorString(e));
-		fprintf(stderr, "   W %p coll_recv %p send %p recv %p | P %p Palt %p nd %p seg %p seg_next %p cntL %p cursor %p flag %p cand %p dec %p | lb %p rb %p sd %p idx %p | nl %lld G %d d %d state %p\n",
-		        (void *)W, (void *)coll_recv, (void *)sendbuf, (void *)recvbuf, (void *)P, (void *)Palt, (void *)nd, (void *)seg, (void *)seg_next, (void *)cntL, (void *)cursor,
-		        (void *)flag, (void *)cand, (void *)dec, (void *)t.lb, (void *)t.rb, (void *)t.sd, (void *)t.index, nl, G, d, (void *)s.state);
-		if (getenv("NBCO_DPART_DRY")) { s.stage = ST_IDLE; return c->fail(NBCO_ERR_UNSUPPORTED, "dry run"); }
 	}
 	switch (s.stage)
 	{
@@ -450,11 +445,9 @@ static int dpart_advance(nbco_ctx *c, nbco_dist_step *out)
 	{
 		hipLaunchKernelGGL(dp_root_kernel, dim3(1), dim3(64), 0, st, (const int *)coll, t);
 		NBCO_HIP(hipGetLastError());
-		if (trace) fprintf(stderr, "   root: %s\n", hipGetErrorString(hipStreamSynchronize(st)));
 		s.level = 0; s.pass = 0;
 		if (d == 0) return start_counts();
 		hipLaunchKernelGGL(dp_nodes_kernel, dim3(1), dim3(64), 0, st, t, 0, s.n_global, nd);
-		if (trace) fprintf(stderr, "   nodes: %s\n", hipGetErrorString(hipStreamSynchronize(st)));
 		return start_hist();
 	}
 	case ST_HIST:
