@@ -49,6 +49,10 @@ def test_simulation_snapshots_match_engine(nbco3, engine, oracle32, tmp_path):
     assert (out / "args.txt").read_text().split()[1:] == ["-n", str(n), "-p", str(p), "-iters", "4", "-steps", "2", "-o", str(out)]
     names = sorted(f for f in os.listdir(out) if f.endswith(".bin"))
     assert names == ["out0_0.000500.bin", "out2_0.000500.bin", "out4_0.000500.bin"]      # -iters n runs n+1 iterations (main3.cu:357)
+    # (not in the reference: the wall time of the loop behind the first snapshot, read by bench.py's `cli` leg)
+    import re
+    m = re.search(r"Loop time: ([0-9.eE+-]+) s, (\d+) iterations", r.stdout)
+    assert m and int(m.group(2)) == 4 and float(m.group(1)) > 0
     snap = np.fromfile(out / "out4_0.000500.bin", dtype=np.float32)
     assert snap.size == 2 * n * 3
     snap = snap.reshape(2, n, 3)
