@@ -31,6 +31,7 @@ using namespace kdc;
 constexpr int kBlockBig = 1024, kBlockSmall = 256;
 constexpr int kBins = 2048;
 constexpr int kTieCap = 64;
+constexpr int kTieWords = 8;   // a candidate's record: {k1, k2, k3, original index, x, y, z, -}
 
 // per-node state of one level (zeroed for all levels by one memset per build)
 struct SelNode
@@ -381,26 +382,17 @@ __device__ inline void ties_and_boxes(const float4 *__restrict__ pos_in, const i
 	if (nt > kTieCap) { if (lane == 0) *flag = 1; }
 	else if (nt > 0)
 	{
-		int a2 = -1, a3 = -1;
-		for (int anc = node; anc > 0;)
-		{
-			anc = (anc - 1) >> 1;
-			const int a = splitdim[anc];
-			if (a == a1 || a == a2) continue;
-			if (a2 < 0) a2 = a;
-			else { a3 = a; break; }
-		}
-		// candidates: the elements that tie with the pivot (three passes) or share its 22-bit bucket (two passes).  Their
+		// candidates: the elements that tie with the pivot (three passes) or share its bucket (two passes, warm select).  Their
 		// order in the stable-sort chain is (c[a1], c[a2], c[a3], original index); the first `need` belong to the left child.
-		uint32_t idx = 0, k1 = 0, k2 = 0, k3 = 0, org = 0;
+		// The workgroups that met them left complete records {k1, k2, k3, original index, x, y, z} (no second round of loads
+		// here), and every other element of the node has its slot by now, so the candidates' slots follow the final cursors.
+		const uint32_t cl = ld_agent_u32(&nodes[j].cntL), cr = ld_agent_u32(&nodes[j].cntR);
+		uint32_t k1 = 0, k2 = 0, k3 = 0, org = 0, bx = 0, by = 0, bz = 0;
 		if ((uint32_t)lane < nt)
 		{
-			idx = ld_agent_u32(&tielist[(size_t)j * kTieCap + lane]);
-			const float4 p = pos_in[idx];
-			k1 = ordered_bits(axis_of(p, a1));
-			k2 = a2 >= 0 ? ordered_bits(axis_of(p, a2)) : 0;
-			k3 = a3 >= 0 ? ordered_bits(axis_of(p, a3)) : 0;
-			org = (uint32_t)unsort_in[idx];
+			const uint32_t *rec = tielist + ((size_t)j * kTieCap + lane) * kTieWords;
+			k1 = ld_agent_u32(rec); k2 = ld_agent_u32(rec + 1); k3 = ld_agent_u32(rec + 2); org = ld_agent_u32(rec + 3);
+			bx = ld_agent_u32(rec + 4); by = ld_agent_u32(rec + 5); bz = ld_agent_u32(rec + 6);
 		}
 		uint32_t rank = 0;
 		for (uint32_t q = 0; q < nt; ++q)
@@ -412,11 +404,9 @@ __device__ inline void ties_and_boxes(const float4 *__restrict__ pos_in, const i
 		const bool mine = (uint32_t)lane < nt;
 		if (mine)
 		{
-			long long dst;
-			if (rank < pv.need) dst = range_start(n, j, m) + atomicAdd(&nodes[j].cntL, 1u);
-			else dst = range_start(n, 2 * j + 1, 2LL * m) + atomicAdd(&nodes[j].cntR, 1u);
-			pos_out[dst] = pos_in[idx];
-			unsort_out[dst] = unsort_in[idx];
+			const long long dst = rank < pv.need ? range_start(n, j, m) + cl + rank : range_start(n, 2 * j + 1, 2LL * m) + cr + (rank - pv.need);
+			pos_out[dst] = make_float4(__uint_as_float(bx), __uint_as_float(by), __uint_as_float(bz), 0.f);
+			unsort_out[dst] = (int)org;
 		}
 		const unsigned long long at_pivot = __ballot(mine && rank + 1 == pv.need), after = __ballot(mine && rank == pv.need);
 		if (at_pivot) pivot = __shfl(k1, __ffsll((long long)at_pivot) - 1);
@@ -523,6 +513,29 @@ __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__re
 	if (j1 == j0) { piv[1] = piv[0]; all_left[1] = all_left[0]; lo[1] = lo[0]; scale[1] = scale[0]; miss[1] = miss[0]; }
 	const int sd[2] = {sd_l[j0], sd_l[j1]};
 	if (threadIdx.x < 2) mR[threadIdx.x] = 0xFFFFFFFFu;
+	// the next two distinct split axes of a node's ancestors (keys two and three of the stable-sort chain, for the candidates'
+	// records): the ancestors' indices follow from the node's, so their axes are fetched side by side
+	__shared__ signed char sdanc[2][32], anc23[2][2];
+	if (threadIdx.x < 64)
+	{
+		const int jj = threadIdx.x >> 5, t = threadIdx.x & 31;
+		if (t < l && j0 + jj <= j1) sdanc[jj][t] = (signed char)splitdim[(((int)(m + j0 + jj)) >> (t + 1)) - 1];
+	}
+	__syncthreads();
+	if (threadIdx.x < 2 && j0 + threadIdx.x <= j1)
+	{
+		const int a1 = sd[threadIdx.x];
+		int a2 = -1, a3 = -1;
+		for (int t = 0; t < l; ++t)
+		{
+			const int a = sdanc[threadIdx.x][t];
+			if (a == a1 || a == a2) continue;
+			if (a2 < 0) a2 = a;
+			else { a3 = a; break; }
+		}
+		anc23[threadIdx.x][0] = (signed char)a2; anc23[threadIdx.x][1] = (signed char)a3;
+	}
+	__syncthreads();
 	// Destination slots.  The four output streams of the chunk (left / right of its one or two nodes) are filled in
 	// element order: consecutive lanes with the same destination stream write consecutive slots, so the stores coalesce
 	// (per-thread cursors made every lane of a store instruction hit a different sector: twice the HBM write traffic).
@@ -551,8 +564,16 @@ __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__re
 			else
 			{
 				const uint32_t t = atomicAdd(&nodes[j0 + jj].tiecnt, 1u);
-				// read back inside this launch by the workgroup that completes the node: store past the (non-coherent) L2
-				if (t < kTieCap) __hip_atomic_store(&tielist[(size_t)(j0 + jj) * kTieCap + t], (uint32_t)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				// read back inside this launch by the workgroup that completes the node: stores past the (non-coherent) L2
+				if (t < kTieCap)
+				{
+					uint32_t *rec = tielist + ((size_t)(j0 + jj) * kTieCap + t) * kTieWords;
+					const int a2 = anc23[jj][0], a3 = anc23[jj][1];
+					const uint32_t w[7] = {key, a2 >= 0 ? ordered_bits(axis_of(p[e], a2)) : 0u, a3 >= 0 ? ordered_bits(axis_of(p[e], a3)) : 0u, (uint32_t)org[e],
+					                       __float_as_uint(p[e].x), __float_as_uint(p[e].y), __float_as_uint(p[e].z)};
+#pragma unroll
+					for (int q = 0; q < 7; ++q) __hip_atomic_store(&rec[q], w[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
 			}
 		}
 		uint64_t packed = 0;
@@ -640,7 +661,7 @@ int kd_select_begin(nbco_ctx *c, int l0, bool zero, long long *words_a, long lon
 	const size_t nodes = ((size_t)1 << l0) - 1;
 	NBCO_TRY(c->reserve(c->sel_hist, sizeof(uint32_t) * 3 * nodes * kBins));
 	NBCO_TRY(c->reserve(c->sel_nodes, sizeof(SelNode) * nodes));
-	NBCO_TRY(c->reserve(c->sel_ties, sizeof(uint32_t) * nodes * kTieCap));
+	NBCO_TRY(c->reserve(c->sel_ties, sizeof(uint32_t) * nodes * kTieCap * kTieWords));
 	if (words_a) *words_a = (long long)(3 * nodes * kBins);
 	if (words_b) *words_b = (long long)(sizeof(SelNode) / sizeof(uint32_t) * nodes);
 	if (zero)
@@ -661,7 +682,7 @@ static void select_level_launch(nbco_ctx *c, int l, long long n, const float4 *p
 	// level l uses the slices [m - 1, 2m - 1) of the per-build arrays
 	SelNode *nodes = c->sel_nodes.as<SelNode>() + (m - 1);
 	uint32_t *hist = c->sel_hist.as<uint32_t>() + (size_t)3 * (m - 1) * kBins;
-	uint32_t *ties = c->sel_ties.as<uint32_t>() + (size_t)(m - 1) * kTieCap;
+	uint32_t *ties = c->sel_ties.as<uint32_t>() + (size_t)(m - 1) * kTieCap * kTieWords;
 	const int *sd_l = splitdim + (m - 1);
 	hipStream_t st = c->stream;
 	constexpr int CHUNK = 8 * BLOCK;
