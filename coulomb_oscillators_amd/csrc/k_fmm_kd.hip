@@ -421,13 +421,49 @@ struct SubSel
 __device__ inline float ld_agent(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline void st_agent(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// wave64 inclusive prefix sum / minimum across the lanes on DPP row shifts and row broadcasts (gfx9): six vector instructions
+// instead of six LDS round trips (__shfl_up / __shfl_xor are ds_bpermute).  All 64 lanes must be active.
+// halves: the two 32-lane halves are scanned on their own (the last step is left out)
+__device__ inline uint32_t wave_scan_add(uint32_t x, bool halves = false)
+{
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);   // row_shr:1
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);   // row_shr:2
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);   // row_shr:4
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);   // row_shr:8: scanned inside the rows of 16
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
+	const uint32_t y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
+	return halves ? x : x + y;
+}
+__device__ inline uint32_t wave_min_u32(uint32_t x)   // the minimum over the wave, in every lane
+{
+	x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x111, 0xF, 0xF, false));
+	x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x112, 0xF, 0xF, false));
+	x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x114, 0xF, 0xF, false));
+	x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x118, 0xF, 0xF, false));
+	x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x142, 0xA, 0xF, false));
+	x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x143, 0xC, 0xF, false));
+	return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+
+#ifdef NBCO_SUBTREE_PROF
+// profiling build only (make prof): phase timestamps (100 MHz) of one workgroup of kd_subtree_kernel, tools/subtree_prof.py
+__device__ long long g_subtree_prof[512];
+#define SUBTREE_MARK(k) do { if (blockIdx.x == 37 && threadIdx.x == 0) g_subtree_prof[(k)] = wall_clock64(); } while (0)
+extern "C" int nbco_debug_subtree_prof(long long *out512)
+{
+	return (int)hipMemcpyFromSymbol(out512, HIP_SYMBOL(g_subtree_prof), sizeof(long long) * 512);
+}
+#else
+#define SUBTREE_MARK(k)
+#endif
+
 __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const float4 *__restrict__ pos_in, const int *__restrict__ unsort_in,
                                                            float4 *__restrict__ pos_out, int *__restrict__ unsort_out, long long n, int l0,
                                                            int canon, int two_pass, int *__restrict__ flag)
 {
-	__shared__ uint64_t keys[kSubS];
+	__shared__ __attribute__((aligned(16))) uint64_t keys[kSubS];
 	__shared__ int prio[3];
-	__shared__ float px[kSubS], py[kSubS], pz[kSubS];
+	__shared__ __attribute__((aligned(16))) float px[kSubS], py[kSubS], pz[kSubS];
 	__shared__ int orig[kSubS];
 	__shared__ unsigned char sdl[kSubS];   // split dimension of the current level's nodes of this subtree
 	// in-LDS selection levels (segments > kSelSeg): per node select state, tie lists and ancestor axes
@@ -437,9 +473,11 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 	__shared__ signed char anc_next[kSelNodes][3];
 	// selection keys are normalised to the node's box along its split axis (subtract the lower face, shift the span up to
 	// bit 31): order preserving, and the FIRST radix digit spreads over all bins instead of hammering one LDS counter
+	__shared__ float boxs[2][kSelNodes][6];        // lower and upper faces of the current level's nodes, and of their children
 	__shared__ uint32_t wmin[kSelNodes], wmin_next[kSelNodes];
 	__shared__ int wshl[kSelNodes], wshl_next[kSelNodes];
 	const int tid = threadIdx.x;
+	SUBTREE_MARK(500);
 	const long long j0 = blockIdx.x, m0 = 1LL << l0;
 	const long long s0 = (j0 == 0) ? 0 : (n * j0 - 1) / m0 + 1;
 	const long long e0 = (n * (j0 + 1) - 1) / m0 + 1;
@@ -452,24 +490,42 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 		px[i] = q.x; py[i] = q.y; pz[i] = q.z;
 		orig[i] = unsort_in[s0 + i];
 	}
-	if (tid == 0)
+	// the selection levels' histograms live in the key buffer; every scan leaves the bins it read at zero, so clearing the
+	// buffer once (while the particles are on their way) serves all levels
+	for (int q = tid; q < 2 * kSubS; q += kSubT) reinterpret_cast<uint32_t *>(keys)[q] = 0u;
+	if (tid < 64)
 	{
-		sdl[0] = (unsigned char)t.splitdim[kd_beg(l0) + (int)j0];
-		// distinct split axes of the ancestors, most recent first (keys of the stable-sort chain)
-		int b[3] = {-1, -1, -1}, nb = 0;
-		for (int anc = kd_beg(l0) + (int)j0; anc > 0 && nb < 3;)
+		// the subtree's root: its split axis, box, and the distinct split axes of its ancestors, most recent first (keys of the
+		// stable-sort chain).  One round trip: lane k fetches the axis of the ancestor k + 1 levels up, all six faces are loaded
+		// before the axis is known.  (Scalars, not an indexed array: an indexable private array is promoted to LDS by the
+		// compiler, and the promoted form reads the workgroup size from the dispatch packet in host memory -- 5 to 25 us at the
+		// head of every launch.)
+		const int root = kd_beg(l0) + (int)j0;
+		const int up = (root + 1) >> (tid + 1);                       // 1-based heap number of that ancestor, 0: above the root
+		const int mine = (tid < 31 && up > 0) ? t.splitdim[up - 1] : -1;
+		const int a = t.splitdim[root];
+		const float l0f = t.lbound[3 * root], l1f = t.lbound[3 * root + 1], l2f = t.lbound[3 * root + 2];
+		const float r0f = t.rbound[3 * root], r1f = t.rbound[3 * root + 1], r2f = t.rbound[3 * root + 2];
+		int b0 = -1, b1 = -1, b2 = -1;
+		for (int k = 0; k < l0 && k < 31; ++k)
 		{
-			anc = (anc - 1) >> 1;
-			const int a = t.splitdim[anc];
-			if (a != b[0] && a != b[1]) b[nb++] = a;
+			const int ax = __shfl(mine, k);
+			if (ax < 0 || ax == b0 || ax == b1 || b2 >= 0) continue;
+			if (b0 < 0) b0 = ax; else if (b1 < 0) b1 = ax; else b2 = ax;
 		}
-		prio[0] = b[0]; prio[1] = b[1]; prio[2] = b[2];
-		anc[0][0] = (signed char)b[0]; anc[0][1] = (signed char)b[1]; anc[0][2] = (signed char)b[2];
-		const int root = kd_beg(l0) + (int)j0, a = t.splitdim[root];
-		const uint32_t lo = ordered_bits(t.lbound[3 * root + a]), span = ordered_bits(t.rbound[3 * root + a]) - lo;
-		wmin[0] = lo; wshl[0] = span ? __clz(span) : 0;
+		if (tid == 0)
+		{
+			sdl[0] = (unsigned char)a;
+			prio[0] = b0; prio[1] = b1; prio[2] = b2;
+			anc[0][0] = (signed char)b0; anc[0][1] = (signed char)b1; anc[0][2] = (signed char)b2;
+			const uint32_t lo = ordered_bits(a == 0 ? l0f : (a == 1 ? l1f : l2f)), span = ordered_bits(a == 0 ? r0f : (a == 1 ? r1f : r2f)) - lo;
+			wmin[0] = lo; wshl[0] = span ? __clz(span) : 0;
+			boxs[0][0][0] = l0f; boxs[0][0][1] = l1f; boxs[0][0][2] = l2f; boxs[0][0][3] = r0f; boxs[0][0][4] = r1f; boxs[0][0][5] = r2f;
+			sel[0] = SubSel{0u, 0xFFFFFFFFu, 0u, P2 >> 1, 0, 0, 0, 0};
+		}
 	}
 	__syncthreads();
+	SUBTREE_MARK(501);
 
 	// Bitonic sort of keys[0, P2), ascending inside every aligned block of `seg` elements (seg = P2: the whole
 	// slice).  Each wave owns a contiguous chunk of 64 R keys in registers (R = 1, 2 or 4 per lane): all
@@ -599,8 +655,11 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 			keys[i] = k;
 		}
 		__syncthreads();
+		SUBTREE_MARK(410);
 		bitonic(seg);
+		SUBTREE_MARK(411);
 		permute();
+		SUBTREE_MARK(412);
 		for (int i = tid; i + 1 < cnt; i += kSubT)
 		{
 			const int b1 = anc_of(i, 0), b2 = anc_of(i, 1), b3 = anc_of(i, 2);
@@ -619,6 +678,51 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 					px[v - 1] = tx; py[v - 1] = ty; pz[v - 1] = tz; orig[v - 1] = to;
 				}
 		}
+		__syncthreads();
+	};
+
+	// The same order for aligned blocks of exactly 32 elements (the leaves of a power-of-two tree), by ranking instead of sorting:
+	// an element's place is the number of elements of its block that precede it.  The 32 first keys of a block are read as eight
+	// 16-byte broadcasts (the lanes of a half wave share the block), compared in registers; only an element whose first key is
+	// not unique in its block walks the chain order.  No dependent shuffle stages, a third of the bitonic network's instructions.
+	auto canonical_rank32 = [&](auto anc_of) {
+		uint32_t *k32 = reinterpret_cast<uint32_t *>(keys);
+#pragma unroll
+		for (int e = 0; e < kSubE; ++e)
+		{
+			const int i = tid + e * kSubT;
+			const int b1 = anc_of(i, 0);
+			k32[i] = b1 >= 0 ? ordered_bits(coord(i, b1)) : 0u;
+		}
+		__syncthreads();
+		float rx[kSubE], ry[kSubE], rz[kSubE];
+		int ro[kSubE], dst[kSubE];
+#pragma unroll
+		for (int e = 0; e < kSubE; ++e)
+		{
+			const int i = tid + e * kSubT, base = i & ~31;
+			const uint32_t me = k32[i];
+			const uint4 *blk = reinterpret_cast<const uint4 *>(k32 + base);
+			int less = 0, same = 0;
+#pragma unroll
+			for (int q = 0; q < 8; ++q)
+			{
+				const uint4 o = blk[q];
+				less += (int)(o.x < me) + (int)(o.y < me) + (int)(o.z < me) + (int)(o.w < me);
+				same += (int)(o.x == me) + (int)(o.y == me) + (int)(o.z == me) + (int)(o.w == me);
+			}
+			if (same > 1)
+			{
+				const int b2 = anc_of(i, 1), b3 = anc_of(i, 2);
+				for (int u = base; u < base + 32; ++u)
+					if (u != i && k32[u] == me && chain_less(u, i, -1, b2, b3)) ++less;
+			}
+			dst[e] = base + less;
+			rx[e] = px[i]; ry[e] = py[i]; rz[e] = pz[i]; ro[e] = orig[i];
+		}
+		__syncthreads();
+#pragma unroll
+		for (int e = 0; e < kSubE; ++e) { const int d = dst[e]; px[d] = rx[e]; py[d] = ry[e]; pz[d] = rz[e]; orig[d] = ro[e]; }
 		__syncthreads();
 	};
 
@@ -642,9 +746,8 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 			// which orders them by (key, ancestor axes, original index)
 			const int db = nodes <= 32 ? 8 : 7, bins = 1 << db, npass = two_pass ? 2 : (32 + db - 1) / db;
 			const int rest = 32 - min(32, db * npass);   // key bits not looked at by the passes
-			if (tid < nodes) sel[tid] = SubSel{0u, 0xFFFFFFFFu, 0u, half, 0, 0, 0, 0};
-			for (int q = tid; q < nodes * bins; q += kSubT) hist[q] = 0;
-			__syncthreads();
+			SUBTREE_MARK(16 * s);
+			// (sel[] of this level's nodes and the zeroed bins were left by the prologue / the previous level)
 			uint32_t key[kSubE];
 #pragma unroll
 			for (int e = 0; e < kSubE; ++e)
@@ -665,22 +768,24 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 					if (pass == 0 || (key[e] >> hi) == sel[j].prefix) atomicAdd(&hist[j * bins + ((key[e] >> lo) & ((1u << wd) - 1u))], 1u);
 				}
 				__syncthreads();
-				for (int j = wv; j < nodes; j += kSubT / 64)
+				SUBTREE_MARK(16 * s + 2 + 2 * pass);
+				const bool halves = bins == 128;   // 7-bit digits: a node's bins fill half a wave, two nodes per wave
+				for (int g = wv; (halves ? 2 * g : g) < nodes; g += kSubT / 64)
 				{
-					// one wave per node: find the bin holding rank r (1-based among the remaining candidates)
+					// one wave (or half wave) per node: find the bin holding rank r (1-based among the remaining candidates)
+					const int j = halves ? 2 * g + (lane >> 5) : g, ln = halves ? (lane & 31) : lane;
 					const int r = sel[j].rank;
 					uint32_t cb[4];
 					uint32_t sum = 0;
 #pragma unroll
 					for (int q = 0; q < 4; ++q)
 					{
-						const int bin = lane * 4 + q;
-						cb[q] = bin < bins ? hist[j * bins + bin] : 0u;
-						if (bin < bins) hist[j * bins + bin] = 0;
+						const int bin = ln * 4 + q;
+						cb[q] = hist[j * bins + bin];
+						hist[j * bins + bin] = 0;
 						sum += cb[q];
 					}
-					uint32_t incl = sum;
-					for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+					const uint32_t incl = wave_scan_add(sum, halves);
 					uint32_t before = incl - sum;
 					if ((uint32_t)r > before && (uint32_t)r <= incl)
 					{
@@ -689,7 +794,7 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 						{
 							if ((uint32_t)r > before && (uint32_t)r <= before + cb[q])
 							{
-								sel[j].prefix = (sel[j].prefix << wd) | (uint32_t)(lane * 4 + q);
+								sel[j].prefix = (sel[j].prefix << wd) | (uint32_t)(ln * 4 + q);
 								sel[j].rank = r - (int)before;
 								sel[j].neq = (int)cb[q];
 							}
@@ -698,6 +803,7 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 					}
 				}
 				__syncthreads();
+				SUBTREE_MARK(16 * s + 3 + 2 * pass);
 			}
 			if (!two_pass && tid < nodes) sel[tid].pivot = sel[tid].prefix;   // all digits known: the prefix is the pivot
 			// classify: 0 left, 1 right, 2 candidate (pivot tie, or pivot bucket after two passes: side decided by its rank
@@ -720,6 +826,7 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 				}
 			}
 			__syncthreads();
+			SUBTREE_MARK(16 * s + 6);
 			float rx[kSubE], ry[kSubE], rz[kSubE];
 			int ro[kSubE], dst[kSubE];
 #pragma unroll
@@ -753,29 +860,44 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 				}
 				rx[e] = px[i]; ry[e] = py[i]; rz[e] = pz[i]; ro[e] = orig[i];
 			}
+			SUBTREE_MARK(16 * s + 11);
 			// slots: the 64 lanes of a wave hold consecutive elements of ONE node (segments are >= 64 long), so one LDS atomic
 			// per wave and side reserves the slots and a ballot prefix hands them out
+			// (the live lanes of a wave are a prefix of it, so lane 0 is live whenever one is; it issues the atomics of all four
+			// elements back to back -- one wait instead of four)
+			uint64_t mLs[kSubE], mRs[kSubE];
+			uint32_t kmins[kSubE];
+			int bLs[kSubE], bRs[kSubE];
+#pragma unroll
+			for (int e = 0; e < kSubE; ++e)
+			{
+				const bool on = tid + e * kSubT < cnt;
+				mLs[e] = __ballot(on && side[e] == 0);
+				mRs[e] = __ballot(on && side[e] != 0);
+				kmins[e] = wave_min_u32((on && side[e] != 0) ? key[e] : 0xFFFFFFFFu);
+				bLs[e] = 0; bRs[e] = 0;
+			}
+			if (lane == 0)
+			{
+#pragma unroll
+				for (int e = 0; e < kSubE; ++e)
+				{
+					const int j = (tid + e * kSubT) >> lseg;
+					if (mLs[e]) bLs[e] = atomicAdd(&sel[j].cntL, __popcll(mLs[e]));
+					if (mRs[e]) { bRs[e] = atomicAdd(&sel[j].cntR, __popcll(mRs[e])); atomicMin(&sel[j].minR, kmins[e]); }
+				}
+			}
 #pragma unroll
 			for (int e = 0; e < kSubE; ++e)
 			{
 				const int i = tid + e * kSubT;
-				const bool on = i < cnt;
-				const int j = on ? (i >> lseg) : 0;
-				const uint64_t mL = __ballot(on && side[e] == 0), mR = __ballot(on && side[e] != 0);
+				const int j = i >> lseg;
 				const uint64_t below = (1ull << lane) - 1ull;
-				int baseL = 0, baseR = 0;
-				uint32_t kmin = (on && side[e] != 0) ? key[e] : 0xFFFFFFFFu;
-				for (int o = 32; o > 0; o >>= 1) kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o));
-				const int leader = __ffsll((unsigned long long)(mL | mR)) - 1;
-				if (lane == leader)
-				{
-					if (mL) baseL = atomicAdd(&sel[j].cntL, __popcll(mL));
-					if (mR) { baseR = atomicAdd(&sel[j].cntR, __popcll(mR)); atomicMin(&sel[j].minR, kmin); }
-				}
-				if (leader >= 0) { baseL = __shfl(baseL, leader); baseR = __shfl(baseR, leader); }
-				if (on) dst[e] = side[e] == 0 ? j * seg + baseL + __popcll(mL & below) : j * seg + half + baseR + __popcll(mR & below);
+				const int baseL = __builtin_amdgcn_readfirstlane(bLs[e]), baseR = __builtin_amdgcn_readfirstlane(bRs[e]);
+				if (i < cnt) dst[e] = side[e] == 0 ? j * seg + baseL + __popcll(mLs[e] & below) : j * seg + half + baseR + __popcll(mRs[e] & below);
 			}
 			__syncthreads();
+			SUBTREE_MARK(16 * s + 7);
 			if (tid < nodes && sel[tid].ntie > kSubTieCap) *flag = 1;   // unresolved ties: the host redoes the build by sorting
 #pragma unroll
 			for (int e = 0; e < kSubE; ++e)
@@ -786,6 +908,7 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 					px[d] = rx[e]; py[d] = ry[e]; pz[d] = rz[e]; orig[d] = ro[e];
 				}
 			__syncthreads();
+			SUBTREE_MARK(16 * s + 8);
 			// evalBox for the children (fmm_cart3_kdtree.cuh:109-137): the left child's upper face is the pivot (its last
 			// particle in sorted order), the right child's lower face its smallest coordinate
 			const long long m = 1LL << l, mc = m << 1, jbase = j0 << s;
@@ -798,27 +921,33 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 				const long long start = (jc == 0) ? 0 : (n * jc - 1) / mc + 1;
 				const int node = kd_beg(l + 1) + (int)jc, parent = (node - 1) >> 1, split = sdl[j];
 				float lb[3], rb[3];
-				for (int a = 0; a < 3; ++a) { lb[a] = ld_agent(&t.lbound[3 * parent + a]); rb[a] = ld_agent(&t.rbound[3 * parent + a]); }
+				for (int a = 0; a < 3; ++a) { lb[a] = boxs[s & 1][j][a]; rb[a] = boxs[s & 1][j][3 + a]; }   // the parent's box, kept in LDS
 				if (cidx & 1) lb[split] = unordered_bits((sel[j].minR >> wshl[j]) + wmin[j]);
 				else rb[split] = unordered_bits((sel[j].pivot >> wshl[j]) + wmin[j]);
 				for (int a = 0; a < 3; ++a) { st_agent(&t.lbound[3 * node + a], lb[a]); st_agent(&t.rbound[3 * node + a], rb[a]); }
+				if (cidx < kSelNodes)
+					for (int a = 0; a < 3; ++a) { boxs[(s & 1) ^ 1][cidx][a] = lb[a]; boxs[(s & 1) ^ 1][cidx][3 + a] = rb[a]; }
 				sdc = longest_axis(rb[0] - lb[0], rb[1] - lb[1], rb[2] - lb[2]);
 				t.splitdim[node] = sdc;
 				t.index[node] = (int)start;
 				// ancestor axes of the child: the parent's split axis first, then the parent's own list without it
-				int na = 0;
-				signed char out[3] = {-1, -1, -1};
-				out[na++] = (signed char)split;
-				for (int q = 0; q < 3 && na < 3; ++q)
-					if (anc[j][q] >= 0 && anc[j][q] != split) out[na++] = anc[j][q];
+				signed char o1 = -1, o2 = -1;
+#pragma unroll
+				for (int q = 0; q < 3; ++q)
+				{
+					const signed char a = anc[j][q];
+					if (a < 0 || a == split) continue;
+					if (o1 < 0) o1 = a; else if (o2 < 0) o2 = a;
+				}
 				if (cidx < kSelNodes)
 				{
-					anc_next[cidx][0] = out[0]; anc_next[cidx][1] = out[1]; anc_next[cidx][2] = out[2];
+					anc_next[cidx][0] = (signed char)split; anc_next[cidx][1] = o1; anc_next[cidx][2] = o2;
 					const uint32_t lo = ordered_bits(lb[sdc]), span = ordered_bits(rb[sdc]) - lo;
 					wmin_next[cidx] = lo; wshl_next[cidx] = span ? __clz(span) : 0;
 				}
 			}
 			__syncthreads();
+			SUBTREE_MARK(16 * s + 9);
 			if (tid < nchild)
 			{
 				sdl[tid] = (unsigned char)sdc;
@@ -827,14 +956,19 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 					anc[tid][0] = anc_next[tid][0]; anc[tid][1] = anc_next[tid][1]; anc[tid][2] = anc_next[tid][2];
 					wmin[tid] = wmin_next[tid]; wshl[tid] = wshl_next[tid];
 				}
+				if (tid < kSelNodes / 2) sel[tid] = SubSel{0u, 0xFFFFFFFFu, 0u, seg >> 2, 0, 0, 0, 0};   // the next level's nodes
 			}
 			__syncthreads();
+			SUBTREE_MARK(16 * s + 10);
 		}
 		s_begin = s;
+		SUBTREE_MARK(400);
 		// every remaining node (or leaf, if the selection levels reached the bottom) is an aligned block of `seg` elements
 		// with its own ancestors: restore the canonical order inside each
 		const int seg = P2 >> s_begin;
-		canonical_sort(seg, [&](int i, int q) { return (int)anc[i / seg][q]; });
+		if (seg == 32 && P2 == kSubS) canonical_rank32([&](int i, int q) { return (int)anc[i >> 5][q]; });
+		else canonical_sort(seg, [&](int i, int q) { return (int)anc[i / seg][q]; });
+		SUBTREE_MARK(401);
 	}
 	else if (canon && l0 > 0)
 	{
@@ -846,6 +980,7 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 	for (int l = l0 + s_begin; l < t.L; ++l)
 	{
 		const int s = l - l0;                     // sub-level
+		SUBTREE_MARK(200 + 8 * s);
 		const long long m = 1LL << l;
 		const long long jbase = j0 << s;          // first node of this subtree at level l
 		// (a) composite keys (fmm_cart3_kdtree.cuh:167-187): node = floor(2^l i / n)
@@ -862,9 +997,12 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 			keys[i] = k;
 		}
 		__syncthreads();
+		SUBTREE_MARK(200 + 8 * s + 1);
 		// (b) bitonic sort, ascending; (c) apply the permutation
 		bitonic(pow2 ? (P2 >> s) : P2);
+		SUBTREE_MARK(200 + 8 * s + 2);
 		permute();
+		SUBTREE_MARK(200 + 8 * s + 3);
 		// (d) evalBox for the children (fmm_cart3_kdtree.cuh:109-137); parents' boxes were written by this
 		// workgroup (or by the global pass for l = l0): read them past the L1
 		const long long mc = m << 1;
@@ -897,17 +1035,42 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 		__syncthreads();
 		for (int cidx = tid; cidx < nchild; cidx += kSubT) sdl[cidx] = (unsigned char)keys[cidx];
 		__syncthreads();
+		SUBTREE_MARK(200 + 8 * s + 4);
 	}
+	SUBTREE_MARK(402);
 	for (int i = tid; i < cnt; i += kSubT)
 	{
 		pos_out[s0 + i] = make_float4(px[i], py[i], pz[i], 0.f);
 		unsort_out[s0 + i] = orig[i];
 	}
+	SUBTREE_MARK(403);
 	// multiplicity and centre of charge of this slice's leaves, while their particles are still in LDS (what kd_leaf_kernel
 	// does from HBM: sequential sum in particle order, one division)
 	{
 		const int sl = t.L - l0;
 		const long long mL = 1LL << t.L, jb = j0 << sl;
+		if (pow2 && (cnt >> sl) == 32)
+		{
+			// leaves of exactly 32 particles at multiples of 32: one thread per leaf and axis, the particles as eight 16-byte reads
+			// (the leaves of a wave's lanes all start in the same LDS bank: a quarter of the conflicts of 32 single reads)
+			const int nl = 1 << sl;
+			for (int w = tid; w < 3 * nl; w += kSubT)
+			{
+				const int axis = w / nl, i = w - axis * nl;
+				const float4 *src = reinterpret_cast<const float4 *>((axis == 0 ? px : (axis == 1 ? py : pz)) + 32 * i);
+				float sum = 0.f;
+#pragma unroll
+				for (int q = 0; q < 8; ++q)
+				{
+					const float4 v = src[q];
+					sum = sum + v.x; sum = sum + v.y; sum = sum + v.z; sum = sum + v.w;
+				}
+				const int node = kd_beg(t.L) + (int)(jb + i);
+				if (axis == 0) t.mult[node] = 32;
+				t.center[3 * node + axis] = sum / 32.f;
+			}
+		}
+		else
 		for (int i = tid; i < (1 << sl); i += kSubT)
 		{
 			const long long jc = jb + i;
@@ -921,6 +1084,7 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 			t.center[3 * node] = sx; t.center[3 * node + 1] = sy; t.center[3 * node + 2] = sz;
 		}
 	}
+	SUBTREE_MARK(404);
 }
 
 #pragma clang fp contract(fast)
@@ -1769,6 +1933,12 @@ static int kd_build_upward(nbco_ctx *c, const float *p, long long n, int L, cons
 			// the rest of every level-l0 subtree inside one workgroup's LDS
 			hipLaunchKernelGGL(kd_subtree_kernel, dim3(kd_cnt(l0)), dim3(kSubT), 0, st, tv, (const float4 *)pos, (const int *)unsort, pos_alt, unsort_alt, n, l0,
 			                   use_select ? 1 : 0, c->sel_three_pass ? 0 : 1, c->counters.as<int>() + 110);
+#ifdef NBCO_SUBTREE_PROF
+			// the kernel only reads its inputs: a second launch right behind the first one repeats it with warm instruction caches
+			if (std::getenv("NBCO_SUBTREE_TWICE"))
+				hipLaunchKernelGGL(kd_subtree_kernel, dim3(kd_cnt(l0)), dim3(kSubT), 0, st, tv, (const float4 *)pos, (const int *)unsort, pos_alt, unsort_alt, n, l0,
+				                   use_select ? 1 : 0, c->sel_three_pass ? 0 : 1, c->counters.as<int>() + 110);
+#endif
 			std::swap(pos, pos_alt);
 			std::swap(unsort, unsort_alt);
 			NBCO_HIP(hipGetLastError());

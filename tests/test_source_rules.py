@@ -37,3 +37,60 @@ def test_rounding_critical_functions_are_compiled_without_contraction():
         for n in names:
             assert n in got, "%s: definition of %s not found" % (fname, n)
             assert got[n] == "off", "%s: %s is defined under fp contract(%s)" % (fname, n, got[n])
+
+
+# ---- no kernel may ask for the dispatch packet ---------------------------------------------------------------------------------
+# An indexable private array (`out[na++]`) is promoted to LDS by the compiler, and the promoted form takes the workgroup size from the
+# AQL dispatch packet, which lives in HOST memory: one scalar load across the link at the head of the kernel, 5-25 us per launch
+# (kd_subtree_kernel, round 2, found with tools/subtree_prof.py).  The kernel descriptors of the built library say which kernels
+# have the dispatch / queue pointer enabled (kernel_code_properties, bits 1 and 2).
+def _device_elfs(blob):
+    import struct
+    at = 0
+    while True:
+        at = blob.find(b"\x7fELF", at)
+        if at < 0:
+            return
+        if struct.unpack_from("<H", blob, at + 18)[0] == 224:   # EM_AMDGPU
+            yield at
+        at += 4
+
+
+def _kernel_descriptors(blob, base):
+    import struct
+    shoff = struct.unpack_from("<Q", blob, base + 0x28)[0]
+    shentsize, shnum = struct.unpack_from("<HH", blob, base + 0x3A)
+    secs = []
+    for i in range(shnum):
+        o = base + shoff + i * shentsize
+        name, typ, _flags, addr, off, size, link, _info, _align, entsize = struct.unpack_from("<IIQQQQIIQQ", blob, o)
+        secs.append(dict(type=typ, addr=addr, off=off, size=size, link=link, entsize=entsize))
+    for s in secs:
+        if s["type"] != 2:   # SHT_SYMTAB
+            continue
+        strtab = secs[s["link"]]
+        for k in range(s["size"] // s["entsize"]):
+            st_name, _info, _other, shndx, value, size = struct.unpack_from("<IBBHQQ", blob, base + s["off"] + k * s["entsize"])
+            end = blob.index(b"\0", base + strtab["off"] + st_name)
+            name = blob[base + strtab["off"] + st_name:end].decode()
+            if not name.endswith(".kd") or size != 64 or shndx == 0 or shndx >= len(secs):
+                continue
+            sec = secs[shndx]
+            kd = base + sec["off"] + (value - sec["addr"])
+            yield name[:-3], struct.unpack_from("<H", blob, kd + 56)[0]
+
+
+def test_no_kernel_reads_the_dispatch_packet():
+    lib = os.path.join(ROOT, "coulomb_oscillators_amd", "libnbco_hip.so")
+    if not os.path.exists(lib):
+        import pytest
+        pytest.skip("libnbco_hip.so is not built")
+    blob = open(lib, "rb").read()
+    seen, bad = 0, []
+    for base in _device_elfs(blob):
+        for name, props in _kernel_descriptors(blob, base):
+            seen += 1
+            if props & 0x6:   # ENABLE_SGPR_DISPATCH_PTR | ENABLE_SGPR_QUEUE_PTR
+                bad.append(name)
+    assert seen > 50, "kernel descriptors not found (%d)" % seen
+    assert not bad, "kernels that read the dispatch / queue packet from host memory: %s" % bad

@@ -1,0 +1,49 @@
+"""Phase timestamps inside kd_subtree_kernel (one workgroup), from the profiling build of the kd-tree file:
+
+    make -C coulomb_oscillators_amd/csrc prof
+    NBCO_LIB=coulomb_oscillators_amd/libnbco_hip_prof.so python tools/subtree_prof.py [n]
+
+Marks are 100 MHz wall-clock reads of thread 0 after the barriers that end a phase.  Diagnostics only."""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from coulomb_oscillators_amd import Engine, EVAL_FMM_KDTREE, INTEG_LEAPFROG  # noqa: E402
+from coulomb_oscillators_amd import engine as E  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
+    eng = Engine(fmm_order=6, unsort=0, sync=0)
+    import bench
+    buf = torch.from_numpy(bench.gaussian_ball(n)).cuda()
+    par = torch.from_numpy(bench.coulomb_params(n)).cuda()
+    eng.compute_force(EVAL_FMM_KDTREE, buf, n, par)
+    for _ in range(5):
+        eng.integrate(INTEG_LEAPFROG, EVAL_FMM_KDTREE, buf, n, par, 5e-4)
+    torch.cuda.synchronize()
+    lib = C.CDLL(E.lib_path())
+    out = (C.c_longlong * 512)()
+    rc = lib.nbco_debug_subtree_prof(out)
+    assert rc == 0, rc
+    t = np.array(out[:], dtype=np.int64)
+    t0 = t[500]
+    rel = {int(k): float((t[k] - t0) / 100.0) for k in range(512) if t[k] != 0}   # microseconds since kernel entry
+    keys = sorted(rel, key=lambda k: rel[k])
+    prev = 0.0
+    rows = []
+    for k in keys:
+        rows.append((k, round(rel[k], 2), round(rel[k] - prev, 2)))
+        prev = rel[k]
+    for r in rows:
+        print("mark %3d  t=%8.2f us  +%6.2f" % r)
+    print(json.dumps({"n": n, "marks": rows}))
+
+
+if __name__ == "__main__":
+    main()
