@@ -29,6 +29,7 @@
 //             assembled global tree, pruned to the own domain), see the section at the end of this file.
 #include "nbco_internal.hpp"
 #include "k_p2p.hpp"
+#include "kd_common.hpp"
 #include <rocprim/rocprim.hpp>
 #include <chrono>
 #include <functional>
@@ -36,6 +37,9 @@
 #include <algorithm>
 
 namespace {
+
+using kdc::wave_scan_add;
+using kdc::wave_min_u32;
 
 // tuple offsets (fmm_cart_base3.cuh:180-188): symmetric orders 0..n-1 hold n(n+1)(n+2)/6 reals, traceless orders 0..n-1 hold n^2
 constexpr int sym_off(int n) { return n * (n + 1) * (n + 2) / 6; }
@@ -421,30 +425,6 @@ struct SubSel
 __device__ inline float ld_agent(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline void st_agent(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// wave64 inclusive prefix sum / minimum across the lanes on DPP row shifts and row broadcasts (gfx9): six vector instructions
-// instead of six LDS round trips (__shfl_up / __shfl_xor are ds_bpermute).  All 64 lanes must be active.
-// halves: the two 32-lane halves are scanned on their own (the last step is left out)
-__device__ inline uint32_t wave_scan_add(uint32_t x, bool halves = false)
-{
-	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);   // row_shr:1
-	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);   // row_shr:2
-	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);   // row_shr:4
-	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);   // row_shr:8: scanned inside the rows of 16
-	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
-	const uint32_t y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
-	return halves ? x : x + y;
-}
-__device__ inline uint32_t wave_min_u32(uint32_t x)   // the minimum over the wave, in every lane
-{
-	x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x111, 0xF, 0xF, false));
-	x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x112, 0xF, 0xF, false));
-	x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x114, 0xF, 0xF, false));
-	x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x118, 0xF, 0xF, false));
-	x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x142, 0xA, 0xF, false));
-	x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x143, 0xC, 0xF, false));
-	return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
-}
-
 #ifdef NBCO_SUBTREE_PROF
 // profiling build only (make prof): phase timestamps (100 MHz) of one workgroup of kd_subtree_kernel, tools/subtree_prof.py
 __device__ long long g_subtree_prof[512];
@@ -479,8 +459,8 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 	const int tid = threadIdx.x;
 	SUBTREE_MARK(500);
 	const long long j0 = blockIdx.x, m0 = 1LL << l0;
-	const long long s0 = (j0 == 0) ? 0 : (n * j0 - 1) / m0 + 1;
-	const long long e0 = (n * (j0 + 1) - 1) / m0 + 1;
+	const long long s0 = (j0 == 0) ? 0 : ((n * j0 - 1) >> l0) + 1;   // (shifts: the divisors are powers of two)
+	const long long e0 = ((n * (j0 + 1) - 1) >> l0) + 1;
 	const int cnt = (int)(e0 - s0);
 	int P2 = 1;
 	while (P2 < cnt) P2 <<= 1;
@@ -918,7 +898,7 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 			{
 				const int cidx = tid, j = cidx >> 1;
 				const long long jc = (jbase << 1) + cidx;
-				const long long start = (jc == 0) ? 0 : (n * jc - 1) / mc + 1;
+				const long long start = (jc == 0) ? 0 : ((n * jc - 1) >> (l + 1)) + 1;
 				const int node = kd_beg(l + 1) + (int)jc, parent = (node - 1) >> 1, split = sdl[j];
 				float lb[3], rb[3];
 				for (int a = 0; a < 3; ++a) { lb[a] = boxs[s & 1][j][a]; rb[a] = boxs[s & 1][j][3 + a]; }   // the parent's box, kept in LDS
@@ -1097,12 +1077,9 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 __device__ inline uint64_t block_exclusive_scan3(uint64_t v, uint64_t *sh_wave, uint64_t &total)
 {
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-	uint64_t incl = v;
-	for (int o = 1; o < 64; o <<= 1)
-	{
-		uint64_t y = __shfl_up(incl, o);
-		if (lane >= o) incl += y;
-	}
+	// (three 20-bit fields, scanned one by one on DPP: a 64-bit __shfl_up is two LDS round trips per step)
+	const uint64_t incl = (uint64_t)wave_scan_add((uint32_t)(v & 0xFFFFFu)) | ((uint64_t)wave_scan_add((uint32_t)((v >> 20) & 0xFFFFFu)) << 20) |
+	                      ((uint64_t)wave_scan_add((uint32_t)(v >> 40)) << 40);
 	if (lane == 63) sh_wave[w] = incl;
 	__syncthreads();
 	uint64_t base = 0, tot = 0;
@@ -1228,8 +1205,7 @@ __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab
 		// prefix sums of the input frontier's region sizes
 		const int lane = threadIdx.x;
 		// (a region that ran over its capacity holds capR valid pairs; the overflow flag is already up)
-		int v = lane < kTravK ? (int)min((long long)tctr[kTcFrontier + it * kTravK + lane], capR) : 0, incl = v;
-		for (int o = 1; o < kTravK; o <<= 1) { const int y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+		const int v = lane < kTravK ? (int)min((long long)tctr[kTcFrontier + it * kTravK + lane], capR) : 0, incl = (int)wave_scan_add((uint32_t)v);
 		if (lane < kTravK) in_pref[lane] = incl - v;
 		if (lane == kTravK - 1) in_pref[kTravK] = incl;
 	}
@@ -1582,8 +1558,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 				// exclusive scan of the 256 digit counts (four per lane)
 				unsigned v0 = off[4 * lane], v1 = off[4 * lane + 1], v2 = off[4 * lane + 2], v3 = off[4 * lane + 3];
 				const unsigned sum = v0 + v1 + v2 + v3;
-				unsigned incl = sum;
-				for (int o = 1; o < 64; o <<= 1) { const unsigned y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+				const unsigned incl = wave_scan_add(sum);
 				const unsigned base = incl - sum;
 				wave_lds_sync();
 				off[4 * lane] = base; off[4 * lane + 1] = base + v0; off[4 * lane + 2] = base + v0 + v1; off[4 * lane + 3] = base + v0 + v1 + v2;

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(BLOCK) void sel_hist_kernel(const float4 *__restric
 	}
 	for (int t = threadIdx.x; t < 2 * kBins; t += BLOCK) (&h[0][0])[t] = 0;
 	const long long ilast = (i0 + CHUNK < n ? i0 + CHUNK : n) - 1;
-	const long long j0 = (m * i0) / n, j1 = (m * ilast) / n;
+	const long long j0 = div_floor_small(m * i0, n), j1 = div_floor_small(m * ilast, n);
 	uint32_t pfx[2] = {0, 0}, kmin[2] = {0, 0};
 	int shl[2] = {0, 0};
 	float lo[2] = {0.f, 0.f}, scale[2] = {0.f, 0.f};
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(BLOCK) void sel_hist_warm_kernel(const float4 *__re
 	for (int t = threadIdx.x; t < 2 * kWarmBins; t += BLOCK) (&h[0][0])[t] = 0;
 	if (threadIdx.x < 2) below[threadIdx.x] = 0;
 	const long long ilast = (i0 + CHUNK < n ? i0 + CHUNK : n) - 1;
-	const long long j0 = (m * i0) / n, j1 = (m * ilast) / n;
+	const long long j0 = div_floor_small(m * i0, n), j1 = div_floor_small(m * ilast, n);
 	float lo[2] = {0.f, 0.f}, scale[2] = {0.f, 0.f};
 	uint32_t w0[2] = {0, 0};
 	for (int jj = 0; jj < 2; ++jj)
@@ -289,32 +289,39 @@ __global__ __launch_bounds__(BLOCK) void sel_hist_warm_kernel(const float4 *__re
 }
 
 // the window histogram of node j -> the pivot's bucket; pv.need == 0 reports a window that does not hold the median
+// (the thread's bins v[] and the count below the window were fetched by the caller, next to everything else it needs to know
+// about the node: warm_bins)
 template <int BLOCK>
-__device__ inline SelPivot resolve_warm(const uint32_t *__restrict__ hist, const SelNode *__restrict__ nodes, long long n, int l, long long j, uint32_t w0,
+__device__ inline void warm_bins(const uint32_t *__restrict__ hist, long long m, long long j, uint32_t (&v)[kWarmBins / BLOCK])
+{
+#pragma unroll
+	for (int q = 0; q < kWarmBins / BLOCK; ++q)
+	{
+		const int bin = threadIdx.x * (kWarmBins / BLOCK) + q;
+		v[q] = ld_agent_u32(&hist[((size_t)(bin / kBins) * m + j) * kBins + (bin % kBins)]);
+	}
+}
+template <int BLOCK>
+__device__ inline SelPivot resolve_warm(const uint32_t (&v)[kWarmBins / BLOCK], uint32_t below, long long n, int l, long long j, uint32_t w0,
                                         uint32_t *sh /* [BLOCK/64 + 4] */)
 {
 	constexpr int R = BLOCK / 64, PER = kWarmBins / BLOCK;
 	const long long m = 1LL << l;
 	SelPivot pv;
 	pv.prefix = 0; pv.neq = 0; pv.need = 0;
-	const long long rank = range_start(n, 2 * j + 1, 2 * m) - range_start(n, j, m) - 1 - (long long)ld_agent_u32(&nodes[j].below);
-	uint32_t v[PER], s = 0;
+	const long long rank = range_start(n, 2 * j + 1, 2 * m) - range_start(n, j, m) - 1 - (long long)below;
+	uint32_t s = 0;
 #pragma unroll
-	for (int q = 0; q < PER; ++q)
-	{
-		const int bin = threadIdx.x * PER + q;
-		v[q] = ld_agent_u32(&hist[((size_t)(bin / kBins) * m + j) * kBins + (bin % kBins)]);
-		s += v[q];
-	}
+	for (int q = 0; q < PER; ++q) s += v[q];
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-	uint32_t incl = s;
-	for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+	const uint32_t incl = wave_scan_add(s);
 	__syncthreads();
 	if (lane == 63) sh[w] = incl;
 	if (threadIdx.x == 0) sh[R + 3] = 0;
 	__syncthreads();
-	uint32_t base = 0;
-	for (int q = 0; q < w; ++q) base += sh[q];
+	// the waves' totals, scanned by every wave for itself
+	const uint32_t wt = lane < R ? sh[lane] : 0u;
+	const uint32_t base = __shfl(wave_scan_add(wt) - wt, w);
 	uint32_t cum = base + incl - s;
 	if (rank >= 0)
 	{
@@ -362,38 +369,53 @@ __device__ inline uint64_t block_scan4(uint64_t v, uint64_t *sh_wave, uint64_t &
 	return base + incl - v;
 }
 
+#ifdef NBCO_SUBTREE_PROF
+// profiling build only (make prof): phase timestamps (100 MHz) of one workgroup of the partition of level 7, tools/subtree_prof.py
+__device__ long long g_part_prof[64];
+#define PART_MARK(k) do { if (l == 7 && blockIdx.x == 37 && threadIdx.x == 0) g_part_prof[(k)] = wall_clock64(); } while (0)
+extern "C" int nbco_debug_partition_prof(long long *out64)
+{
+	return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_part_prof), sizeof(long long) * 64);
+}
+#else
+#define PART_MARK(k)
+#endif
+
 #pragma clang fp contract(off)
+// What a workgroup has to know about one of its nodes, fetched in ONE round trip at the head of the partition by 64 of its threads
+// (every address follows from the node's number): words 0 .. 31 the split axes of the ancestors (nearest first), then the
+// node's own split axis, its box, the OLD box of its left child (warm select: the previous build's pivot) and the count below
+// the warm window.
+constexpr int kMetaSd = 32, kMetaLb = 33, kMetaRb = 36, kMetaOld = 39, kMetaBelow = 42, kMetaWords = 64;
+
 // Run by ONE wave once every workgroup of node j has finished its part of the partition (last-block-done).  It first
 // orders the elements that tie with the pivot by the remaining keys of the stable-sort chain -- the next distinct
 // ancestor split axes, then the original index -- and hands the first `need` of them to the left child; then evalBox
 // for the two children (fmm_cart3_kdtree.cuh:109-137): the sorted order's boundary elements are the pivot (largest
 // key of the left child) and the smallest key of the right child.
-__device__ inline void ties_and_boxes(const float4 *__restrict__ pos_in, const int *__restrict__ unsort_in, float4 *__restrict__ pos_out,
-                                      int *__restrict__ unsort_out, float *__restrict__ lbound, float *__restrict__ rbound,
+__device__ inline void ties_and_boxes(float4 *__restrict__ pos_out, int *__restrict__ unsort_out, float *__restrict__ lbound, float *__restrict__ rbound,
                                       int *__restrict__ splitdim, int *__restrict__ index, SelNode *__restrict__ nodes,
                                       const uint32_t *__restrict__ tielist, int *__restrict__ flag, long long n, int l, int j, int lane,
-                                      const SelPivot pv /* three passes: prefix = the pivot as an ordered key */)
+                                      const SelPivot pv /* three passes: prefix = the pivot as an ordered key */, const uint32_t *meta)
 {
 	const int m = 1 << l;
-	const int node = m - 1 + j, a1 = splitdim[node];
-	const uint32_t nt = ld_agent_u32(&nodes[j].tiecnt);
+	const int a1 = (int)meta[kMetaSd];
+	// one round trip: the node's counters and (whether or not there are any) the lane's candidate record.  The candidates are
+	// the elements that tie with the pivot (three passes) or share its bucket (two passes, warm select); the workgroups that
+	// met them left complete records {k1, k2, k3, original index, x, y, z}
+	const uint32_t *rec = tielist + ((size_t)j * kTieCap + lane) * kTieWords;
+	const uint32_t nt = ld_agent_u32(&nodes[j].tiecnt), cl = ld_agent_u32(&nodes[j].cntL), cr = ld_agent_u32(&nodes[j].cntR);
+	const uint32_t inv = ld_agent_u32(&nodes[j].minR);   // inverted, 0 = no element above the candidates
+	const uint32_t k1 = ld_agent_u32(rec), k2 = ld_agent_u32(rec + 1), k3 = ld_agent_u32(rec + 2), org = ld_agent_u32(rec + 3);
+	const uint32_t bx = ld_agent_u32(rec + 4), by = ld_agent_u32(rec + 5), bz = ld_agent_u32(rec + 6);
 	// the pivot (largest key of the left child) and the smallest candidate key that went right
 	uint32_t pivot = pv.prefix, cand_right = 0xFFFFFFFFu;
 	if (nt > kTieCap) { if (lane == 0) *flag = 1; }
 	else if (nt > 0)
 	{
-		// candidates: the elements that tie with the pivot (three passes) or share its bucket (two passes, warm select).  Their
-		// order in the stable-sort chain is (c[a1], c[a2], c[a3], original index); the first `need` belong to the left child.
-		// The workgroups that met them left complete records {k1, k2, k3, original index, x, y, z} (no second round of loads
-		// here), and every other element of the node has its slot by now, so the candidates' slots follow the final cursors.
-		const uint32_t cl = ld_agent_u32(&nodes[j].cntL), cr = ld_agent_u32(&nodes[j].cntR);
-		uint32_t k1 = 0, k2 = 0, k3 = 0, org = 0, bx = 0, by = 0, bz = 0;
-		if ((uint32_t)lane < nt)
-		{
-			const uint32_t *rec = tielist + ((size_t)j * kTieCap + lane) * kTieWords;
-			k1 = ld_agent_u32(rec); k2 = ld_agent_u32(rec + 1); k3 = ld_agent_u32(rec + 2); org = ld_agent_u32(rec + 3);
-			bx = ld_agent_u32(rec + 4); by = ld_agent_u32(rec + 5); bz = ld_agent_u32(rec + 6);
-		}
+		// Their order in the stable-sort chain is (c[a1], c[a2], c[a3], original index); the first `need` belong to the left
+		// child.  Every other element of the node has its slot by now, so the candidates' slots follow the final cursors.
+		const bool mine = (uint32_t)lane < nt;
 		uint32_t rank = 0;
 		for (uint32_t q = 0; q < nt; ++q)
 		{
@@ -401,7 +423,6 @@ __device__ inline void ties_and_boxes(const float4 *__restrict__ pos_in, const i
 			const bool before = q1 < k1 || (q1 == k1 && (q2 < k2 || (q2 == k2 && (q3 < k3 || (q3 == k3 && qo < org)))));
 			rank += before ? 1u : 0u;
 		}
-		const bool mine = (uint32_t)lane < nt;
 		if (mine)
 		{
 			const long long dst = rank < pv.need ? range_start(n, j, m) + cl + rank : range_start(n, 2 * j + 1, 2LL * m) + cr + (rank - pv.need);
@@ -415,12 +436,11 @@ __device__ inline void ties_and_boxes(const float4 *__restrict__ pos_in, const i
 	if (lane < 2)
 	{
 		const int c = 2 * j + lane, child = 2 * m - 1 + c;
-		float lb[3] = {lbound[3 * node], lbound[3 * node + 1], lbound[3 * node + 2]};
-		float rb[3] = {rbound[3 * node], rbound[3 * node + 1], rbound[3 * node + 2]};
+		float lb[3] = {__uint_as_float(meta[kMetaLb]), __uint_as_float(meta[kMetaLb + 1]), __uint_as_float(meta[kMetaLb + 2])};
+		float rb[3] = {__uint_as_float(meta[kMetaRb]), __uint_as_float(meta[kMetaRb + 1]), __uint_as_float(meta[kMetaRb + 2])};
 		if (pv.need == 0) { /* warm select, window missed: nothing was moved; the children inherit the box (flag 2 is up) */ }
 		else if (c & 1)
 		{
-			const uint32_t inv = ld_agent_u32(&nodes[j].minR);   // inverted, 0 = no element above the candidates
 			const uint32_t above = inv ? ~inv : 0xFFFFFFFFu;
 			const float v = unordered_bits(cand_right < above ? cand_right : above);
 			if (a1 == 0) lb[0] = v; else if (a1 == 1) lb[1] = v; else lb[2] = v;
@@ -442,6 +462,13 @@ __device__ inline void ties_and_boxes(const float4 *__restrict__ pos_in, const i
 // pivot go left when all of them belong there and to the tie list otherwise.  All loads of a thread's 8 elements
 // are issued up front, slots are reserved with one packed block scan and four concurrent global atomics.
 // WARM: the select was one windowed pass (sel_hist_warm_kernel), buckets are key >> drop; otherwise drop = 10 (two passes of 11 bits)
+//
+// A workgroup is a chain of dependent round trips through L2 (~1.5 us each; the 40 MB it moves per level hide beside them), so
+// the kernel is laid out to have few: (1) the elements, the node's description (kMeta*) and its window histogram leave
+// together; (2) the cursors of the four output streams AND the slots of the workgroup's candidates are reserved by one batch of
+// atomics; (3) the stores drain; (4) the completion counter; (5) the completing wave fetches counters and candidate records in
+// one batch.  (Round 2 started with eleven: axis -> box -> old pivot -> histogram -> ancestors' axes, one atomic per
+// candidate, and three rounds of loads in the tail.)
 template <int BLOCK, int NP, bool WARM = false>
 __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__restrict__ pos_in, const int *__restrict__ unsort_in,
                                                                float4 *__restrict__ pos_out, int *__restrict__ unsort_out,
@@ -452,13 +479,16 @@ __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__re
 {
 	constexpr int CHUNK = 8 * BLOCK;
 	static_assert(CHUNK < 65536, "packed 16-bit block counters");
-	__shared__ uint32_t base_s[4], mR[2];
+	static_assert(BLOCK >= 128, "two nodes' descriptions are fetched by 128 threads");
+	__shared__ uint32_t base_s[6], mR[2], ntie_s[2];   // base_s[4 + jj]: first slot of the workgroup's candidates in node jj's list
+	__shared__ uint32_t meta[2][kMetaWords];
 	const long long m = 1LL << l;
 	const long long i0 = (long long)blockIdx.x * CHUNK;
 	// element loads first: they are independent of the node state resolved below
 	constexpr int PER = CHUNK / BLOCK;
 	float4 p[PER];
 	int org[PER];
+	PART_MARK(0);
 #pragma unroll
 	for (int e = 0; e < PER; ++e)
 	{
@@ -466,9 +496,50 @@ __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__re
 		if (i < n) { p[e] = pos_in[i]; org[e] = unsort_in[i]; }
 	}
 	const long long ilast = (i0 + CHUNK < n ? i0 + CHUNK : n) - 1;
-	const long long j0 = (m * i0) / n, j1 = (m * ilast) / n;
+	const long long j0 = div_floor_small(m * i0, n), j1 = div_floor_small(m * ilast, n);
+	PART_MARK(1);
+	// the description of the chunk's one or two nodes (see kMeta*), and the first node's window histogram, in the same round trip
+	if (threadIdx.x < 128)
+	{
+		const int jj = threadIdx.x >> 6, t = threadIdx.x & 63;
+		const long long j = j0 + jj;
+		uint32_t v = 0;
+		if (j <= j1)
+		{
+			const int node = (int)(m - 1 + j), left = 2 * node + 1;
+			if (t < 32) { if (t < l) v = (uint32_t)splitdim[(((int)(m + j)) >> (t + 1)) - 1]; }
+			else if (t == kMetaSd) v = (uint32_t)sd_l[j];
+			else if (t < kMetaRb) v = __float_as_uint(lbound[3 * node + (t - kMetaLb)]);
+			else if (t < kMetaOld) v = __float_as_uint(rbound[3 * node + (t - kMetaRb)]);
+			// (the children's old boxes are still in place: they are rewritten by the workgroup that completes the node, and no
+			// workgroup of the node completes before this one has)
+			else if (t < kMetaBelow) v = WARM ? __float_as_uint(rbound[3 * left + (t - kMetaOld)]) : 0u;
+			else if (t == kMetaBelow) v = WARM ? ld_agent_u32(&nodes[j].below) : 0u;
+		}
+		meta[jj][t] = v;
+	}
+	uint32_t wbins[kWarmBins / BLOCK];
+	if (WARM) warm_bins<BLOCK>(hist, m, j0, wbins);
+	if (threadIdx.x < 2) { mR[threadIdx.x] = 0xFFFFFFFFu; ntie_s[threadIdx.x] = 0; }
 	// first element of node j1 (only meaningful when the chunk straddles two nodes)
 	const long long split = j1 > j0 ? range_start(n, j1, m) : n;
+	__syncthreads();
+	PART_MARK(2);
+	// the next two distinct split axes of a node's ancestors (keys two and three of the stable-sort chain, for the candidates' records)
+	__shared__ signed char anc23[2][2];
+	if (threadIdx.x < 2 && j0 + threadIdx.x <= j1)
+	{
+		const int a1 = (int)meta[threadIdx.x][kMetaSd];
+		int a2 = -1, a3 = -1;
+		for (int t = 0; t < l && t < 32; ++t)
+		{
+			const int a = (int)meta[threadIdx.x][t];
+			if (a == a1 || a == a2) continue;
+			if (a2 < 0) a2 = a;
+			else { a3 = a; break; }
+		}
+		anc23[threadIdx.x][0] = (signed char)a2; anc23[threadIdx.x][1] = (signed char)a3;
+	}
 	// the third pass's histogram is descended here (see resolve_before): pivot back to the un-normalised ordered key
 	__shared__ uint32_t sh[BLOCK / 64 + 4];
 	// NP = 2: the select stopped after two passes -- piv is the 22-bit bucket of the pivot under the box-linear bucket key,
@@ -484,58 +555,42 @@ __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__re
 		pvs[jj] = SelPivot{0, 0, 0, 0};
 		if (j0 + jj <= j1)
 		{
+			const int a = (int)meta[jj][kMetaSd];
+			const float blo = __uint_as_float(meta[jj][kMetaLb + a]), bhi = __uint_as_float(meta[jj][kMetaRb + a]);
+			if (EARLY)
+			{
+				// lin_window
+				lo[jj] = blo;
+				const float span = __fsub_rn(bhi, blo);
+				scale[jj] = span > 0.f ? __fdiv_rn(4294967040.f, span) : 0.f;
+			}
 			if (WARM)
 			{
-				lin_window(lbound, rbound, sd_l, l, j0 + jj, lo[jj], scale[jj]);
-				// (the children's old boxes are still in place: they are rewritten by the workgroup that completes the node, and no
-				// workgroup of the node completes before this one has)
-				const uint32_t w0 = warm_window_start(lbound, rbound, sd_l, l, j0 + jj, lo[jj], scale[jj], drop);
-				pvs[jj] = resolve_warm<BLOCK>(hist, nodes, n, l, j0 + jj, w0, sh);
+				// warm_window_start: the bucket of the previous pivot under the current box
+				const uint32_t c = lin_key(__uint_as_float(meta[jj][kMetaOld + a]), lo[jj], scale[jj]) >> drop;
+				const uint32_t w0 = c > (uint32_t)(kWarmBins / 2) ? c - (uint32_t)(kWarmBins / 2) : 0u;
+				if (jj == 1) warm_bins<BLOCK>(hist, m, j0 + 1, wbins);   // a straddling chunk: one more round trip
+				pvs[jj] = resolve_warm<BLOCK>(wbins, meta[jj][kMetaBelow], n, l, j0 + jj, w0, sh);
 				miss[jj] = pvs[jj].need == 0;
 				if (miss[jj] && threadIdx.x == 0) *flag = 2;
 				piv[jj] = pvs[jj].prefix;
 				continue;
 			}
 			pvs[jj] = resolve_before<NP, BLOCK>(hist, nodes, n, l, j0 + jj, i0, sh);
-			if (EARLY) lin_window(lbound, rbound, sd_l, l, j0 + jj, lo[jj], scale[jj]);
-			else
+			if (!EARLY)
 			{
-				// all passes done: back from the node's key window to the pivot as an ordered key
-				uint32_t kmin;
-				int shl;
-				key_window(lbound, rbound, sd_l, l, j0 + jj, kmin, shl);
-				pvs[jj].prefix = (pvs[jj].prefix >> shl) + kmin;
+				// all passes done: back from the node's key window (key_window) to the pivot as an ordered key
+				const uint32_t kmin = ordered_bits(blo), span = ordered_bits(bhi) - kmin;
+				pvs[jj].prefix = (pvs[jj].prefix >> (span ? __clz(span) : 0)) + kmin;
 			}
 			piv[jj] = pvs[jj].prefix;
 			all_left[jj] = !EARLY && pvs[jj].need == pvs[jj].neq;
 		}
 	}
 	if (j1 == j0) { piv[1] = piv[0]; all_left[1] = all_left[0]; lo[1] = lo[0]; scale[1] = scale[0]; miss[1] = miss[0]; }
-	const int sd[2] = {sd_l[j0], sd_l[j1]};
-	if (threadIdx.x < 2) mR[threadIdx.x] = 0xFFFFFFFFu;
-	// the next two distinct split axes of a node's ancestors (keys two and three of the stable-sort chain, for the candidates'
-	// records): the ancestors' indices follow from the node's, so their axes are fetched side by side
-	__shared__ signed char sdanc[2][32], anc23[2][2];
-	if (threadIdx.x < 64)
-	{
-		const int jj = threadIdx.x >> 5, t = threadIdx.x & 31;
-		if (t < l && j0 + jj <= j1) sdanc[jj][t] = (signed char)splitdim[(((int)(m + j0 + jj)) >> (t + 1)) - 1];
-	}
+	const int sd[2] = {(int)meta[0][kMetaSd], j1 > j0 ? (int)meta[1][kMetaSd] : (int)meta[0][kMetaSd]};
 	__syncthreads();
-	if (threadIdx.x < 2 && j0 + threadIdx.x <= j1)
-	{
-		const int a1 = sd[threadIdx.x];
-		int a2 = -1, a3 = -1;
-		for (int t = 0; t < l; ++t)
-		{
-			const int a = sdanc[threadIdx.x][t];
-			if (a == a1 || a == a2) continue;
-			if (a2 < 0) a2 = a;
-			else { a3 = a; break; }
-		}
-		anc23[threadIdx.x][0] = (signed char)a2; anc23[threadIdx.x][1] = (signed char)a3;
-	}
-	__syncthreads();
+	PART_MARK(3);
 	// Destination slots.  The four output streams of the chunk (left / right of its one or two nodes) are filled in
 	// element order: consecutive lanes with the same destination stream write consecutive slots, so the stores coalesce
 	// (per-thread cursors made every lane of a store instruction hit a different sector: twice the HBM write traffic).
@@ -546,6 +601,7 @@ __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__re
 	const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const uint64_t below = (1ull << lane) - 1ull;
 	int cat[PER];          // -1 tie / nothing, else 2 * (second node ?) + (right ?)
+	int tslot[PER];        // candidates: place among the workgroup's candidates of the node, else -1
 	uint32_t lp[PER];      // rank among the wave's elements of the same stream in this round
 	uint32_t tmin[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
 #pragma unroll
@@ -553,6 +609,7 @@ __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__re
 	{
 		const long long i = i0 + e * BLOCK + threadIdx.x;
 		cat[e] = -1;
+		tslot[e] = -1;
 		if (i < n)
 		{
 			const int jj = i >= split ? 1 : 0;
@@ -561,63 +618,61 @@ __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__re
 			if (WARM && miss[jj]) { /* nothing moves */ }
 			else if (cmp < piv[jj] || (cmp == piv[jj] && all_left[jj])) cat[e] = 2 * jj;
 			else if (cmp > piv[jj]) { cat[e] = 2 * jj + 1; tmin[jj] = key < tmin[jj] ? key : tmin[jj]; }
-			else
-			{
-				const uint32_t t = atomicAdd(&nodes[j0 + jj].tiecnt, 1u);
-				// read back inside this launch by the workgroup that completes the node: stores past the (non-coherent) L2
-				if (t < kTieCap)
-				{
-					uint32_t *rec = tielist + ((size_t)(j0 + jj) * kTieCap + t) * kTieWords;
-					const int a2 = anc23[jj][0], a3 = anc23[jj][1];
-					const uint32_t w[7] = {key, a2 >= 0 ? ordered_bits(axis_of(p[e], a2)) : 0u, a3 >= 0 ? ordered_bits(axis_of(p[e], a3)) : 0u, (uint32_t)org[e],
-					                       __float_as_uint(p[e].x), __float_as_uint(p[e].y), __float_as_uint(p[e].z)};
-#pragma unroll
-					for (int q = 0; q < 7; ++q) __hip_atomic_store(&rec[q], w[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				}
-			}
+			else tslot[e] = (int)atomicAdd(&ntie_s[jj], 1u);   // a candidate: its record is written once the node's list has room for it
 		}
 		uint64_t packed = 0;
 		lp[e] = 0;
 #pragma unroll
 		for (int q = 0; q < 4; ++q)
 		{
+			if (q >= 2 && j1 == j0) break;   // one node: two streams
 			const uint64_t bq = __ballot(cat[e] == q);
 			packed |= (uint64_t)__popcll(bq) << (16 * q);
 			if (cat[e] == q) lp[e] = (uint32_t)__popcll(bq & below);
 		}
 		if (lane == 0) pw[e * W + wv] = packed;
 	}
-	__syncthreads();
-	if (threadIdx.x < 64)
-	{
-		// exclusive scan of the PER * W packed counters (two consecutive entries per lane)
-		constexpr int NE = PER * W;
-		const int k0 = 2 * lane, k1 = 2 * lane + 1;
-		const uint64_t v0 = k0 < NE ? pw[k0] : 0, v1 = k1 < NE ? pw[k1] : 0;
-		uint64_t incl = v0 + v1;
-		for (int o = 1; o < 64; o <<= 1) { const uint64_t y = __shfl_up(incl, o); if (lane >= o) incl += y; }
-		const uint64_t excl = incl - (v0 + v1);
-		if (k0 < NE) pw[k0] = excl;
-		if (k1 < NE) pw[k1] = excl + v0;
-		if (lane == 63) pw[NE] = incl;
-	}
-	__syncthreads();
-	const uint64_t tot = pw[PER * W];
-	if (threadIdx.x < 4)
-	{
-		const int jj = threadIdx.x >> 1, right = threadIdx.x & 1;
-		const uint32_t c = (uint32_t)((tot >> (16 * threadIdx.x)) & 0xFFFF);
-		base_s[threadIdx.x] = c ? atomicAdd(right ? &nodes[j0 + jj].cntR : &nodes[j0 + jj].cntL, c) : 0;
-	}
 #pragma unroll
 	for (int q = 0; q < 2; ++q)
 	{
-		uint32_t v = tmin[q];
-		for (int o = 32; o > 0; o >>= 1) { const uint32_t y = __shfl_xor(v, o); v = y < v ? y : v; }
+		const uint32_t v = wave_min_u32(tmin[q]);
 		if (lane == 0 && v != 0xFFFFFFFFu) atomicMin(&mR[q], v);
 	}
+	PART_MARK(10);
 	__syncthreads();
-	if (threadIdx.x < 2 && mR[threadIdx.x] != 0xFFFFFFFFu) atomicMax(&nodes[j0 + threadIdx.x].minR, ~mR[threadIdx.x]);
+	PART_MARK(4);
+	if (threadIdx.x < 64)
+	{
+		// exclusive scan of the PER * W packed counters (two consecutive entries per lane; the 16-bit fields cannot carry: a
+		// workgroup holds fewer than 2^16 elements)
+		constexpr int NE = PER * W;
+		const int k0 = 2 * lane, k1 = 2 * lane + 1;
+		const uint64_t v0 = k0 < NE ? pw[k0] : 0, v1 = k1 < NE ? pw[k1] : 0;
+		const uint64_t both = v0 + v1;
+		const uint64_t incl = (uint64_t)wave_scan_add((uint32_t)both) | ((uint64_t)wave_scan_add((uint32_t)(both >> 32)) << 32);
+		const uint64_t excl = incl - both;
+		if (k0 < NE) pw[k0] = excl;
+		if (k1 < NE) pw[k1] = excl + v0;
+		// the one batch of atomics: the cursors of the four streams, the places of the candidates, the smallest key that went right
+		const uint64_t tot = __shfl(incl, 63);
+		if (lane < 4)
+		{
+			const int jj = lane >> 1, right = lane & 1;
+			const uint32_t c = (uint32_t)((tot >> (16 * lane)) & 0xFFFF);
+			base_s[lane] = c ? atomicAdd(right ? &nodes[j0 + jj].cntR : &nodes[j0 + jj].cntL, c) : 0;
+		}
+		else if (lane < 6)
+		{
+			const uint32_t c = ntie_s[lane - 4];
+			base_s[lane] = c ? atomicAdd(&nodes[j0 + (lane - 4)].tiecnt, c) : 0;
+		}
+		else if (lane < 8)
+		{
+			if (mR[lane - 6] != 0xFFFFFFFFu) atomicMax(&nodes[j0 + (lane - 6)].minR, ~mR[lane - 6]);
+		}
+	}
+	__syncthreads();
+	PART_MARK(5);
 	// first slot of each stream: [left0, right0, left1, right1]
 	long long first[4];
 #pragma unroll
@@ -629,6 +684,22 @@ __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__re
 #pragma unroll
 	for (int e = 0; e < PER; ++e)
 	{
+		if (tslot[e] >= 0)
+		{
+			const int jj = (i0 + e * BLOCK + threadIdx.x) >= split ? 1 : 0;
+			const uint32_t t = base_s[4 + jj] + (uint32_t)tslot[e];
+			// read back inside this launch by the workgroup that completes the node: stores past the (non-coherent) L2
+			if (t < kTieCap)
+			{
+				uint32_t *rec = tielist + ((size_t)(j0 + jj) * kTieCap + t) * kTieWords;
+				const int a2 = anc23[jj][0], a3 = anc23[jj][1];
+				const uint32_t w[7] = {ordered_bits(axis_of(p[e], sd[jj])), a2 >= 0 ? ordered_bits(axis_of(p[e], a2)) : 0u,
+				                       a3 >= 0 ? ordered_bits(axis_of(p[e], a3)) : 0u, (uint32_t)org[e],
+				                       __float_as_uint(p[e].x), __float_as_uint(p[e].y), __float_as_uint(p[e].z)};
+#pragma unroll
+				for (int q = 0; q < 7; ++q) __hip_atomic_store(&rec[q], w[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
 		if (cat[e] < 0) continue;
 		const int q = cat[e];
 		const long long dst = (q == 0 ? first[0] : (q == 1 ? first[1] : (q == 2 ? first[2] : first[3])))
@@ -639,15 +710,19 @@ __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__re
 	// The workgroup that completes a node resolves its pivot ties and writes the children's boxes (last-block-done: the
 	// cursors, tie list and minimum are only touched by device atomics and read back with agent-scope loads).
 	__shared__ uint32_t fin[2];
+	PART_MARK(6);
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	__syncthreads();
+	PART_MARK(7);
 	if (threadIdx.x < 2) fin[threadIdx.x] = (j0 + threadIdx.x <= j1) ? atomicAdd(&nodes[j0 + threadIdx.x].done_part, 1u) : 0xFFFFFFFFu;
 	__syncthreads();
+	PART_MARK(8);
 	if (threadIdx.x < 64)
 		for (int jj = 0; jj < 2; ++jj)
 			if (j0 + jj <= j1 && fin[jj] == chunks_of_node<CHUNK>(n, j0 + jj, m) - 1)
-				ties_and_boxes(pos_in, unsort_in, pos_out, unsort_out, lbound, rbound, splitdim, index, nodes, tielist, flag, n, l, (int)(j0 + jj),
-				               (int)threadIdx.x, pvs[jj]);
+				ties_and_boxes(pos_out, unsort_out, lbound, rbound, splitdim, index, nodes, tielist, flag, n, l, (int)(j0 + jj),
+				               (int)threadIdx.x, pvs[jj], meta[jj]);
+	PART_MARK(9);
 }
 
 

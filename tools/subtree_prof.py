@@ -43,6 +43,15 @@ def main():
     for r in rows:
         print("mark %3d  t=%8.2f us  +%6.2f" % r)
     print(json.dumps({"n": n, "marks": rows}))
+    if hasattr(lib, "nbco_debug_partition_prof"):
+        out = (C.c_longlong * 64)()
+        assert lib.nbco_debug_partition_prof(out) == 0
+        t = np.array(out[:], dtype=np.int64)
+        ks = sorted([k for k in range(64) if t[k] != 0], key=lambda k: t[k])
+        prev = t[ks[0]] if ks else 0
+        for k in ks:
+            print("part %3d  t=%8.2f us  +%6.2f" % (k, (t[k] - t[ks[0]]) / 100.0, (t[k] - prev) / 100.0))
+            prev = t[k]
 
 
 if __name__ == "__main__":
