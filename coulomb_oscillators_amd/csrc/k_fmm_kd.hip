@@ -433,8 +433,20 @@ extern "C" int nbco_debug_subtree_prof(long long *out512)
 {
 	return (int)hipMemcpyFromSymbol(out512, HIP_SYMBOL(g_subtree_prof), sizeof(long long) * 512);
 }
+// ... and of one workgroup of the traversal launch NBCO_TRAV_PROF_IT (first pass of its loop)
+#ifndef NBCO_TRAV_PROF_IT
+#define NBCO_TRAV_PROF_IT 8
+#endif
+#define TRAV_MARK(k) do { if (it == NBCO_TRAV_PROF_IT && blockIdx.x == 37 && threadIdx.x == 0 && first_pass) g_subtree_prof[448 + (k)] = wall_clock64(); } while (0)
+#define TRAV_FIRST_PASS(v) first_pass = (v)
+#define TRAV_DEP(v) asm volatile("" :: "v"(v))
+#define TRAV_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #else
 #define SUBTREE_MARK(k)
+#define TRAV_MARK(k)
+#define TRAV_DEP(v)
+#define TRAV_DRAIN()
+#define TRAV_FIRST_PASS(v)
 #endif
 
 __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const float4 *__restrict__ pos_in, const int *__restrict__ unsort_in,
@@ -1199,6 +1211,11 @@ __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab
 	__shared__ int sh_base[3];
 	__shared__ int in_pref[kTravK + 1];
 	__shared__ AdmTab tab;   // LDS copy: a lane-indexed read of the kernel argument would be one more global round trip per test
+#ifdef NBCO_SUBTREE_PROF
+	bool first_pass;
+#endif
+	TRAV_FIRST_PASS(true);
+	TRAV_MARK(0);
 	for (int q = threadIdx.x; q < (int)(sizeof(AdmTab) / sizeof(int)); q += kBlock) reinterpret_cast<int *>(&tab)[q] = reinterpret_cast<const int *>(&tab_arg)[q];
 	if (threadIdx.x < 64)
 	{
@@ -1210,6 +1227,7 @@ __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab
 		if (lane == kTravK - 1) in_pref[kTravK] = incl;
 	}
 	__syncthreads();
+	TRAV_MARK(1);
 	const int nin = in_pref[kTravK];
 	const int lbeg = kd_beg(t.L);
 	const int rout = (blockIdx.x + 5 * it) & (kTravK - 1);   // rotate, so that a busy part of the frontier does not keep feeding one region
@@ -1227,11 +1245,15 @@ __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab
 		{
 			p0 = fin[region_slot(in_pref, capR, i)];
 			if (!NBCO_CHECKED_OK((unsigned)p0.x < (unsigned)t.ntot && (unsigned)p0.y < (unsigned)t.ntot, NBCO_CHK_FRONTIER)) p0 = make_int2(0, 0);
+			TRAV_DEP(p0.x);
+			TRAV_MARK(2);
 			// records of x, y and of their children, all in flight together (a leaf's "children" are clamped and never used)
 			const int last = t.ntot - 1;
 			const int ix1 = min(2 * p0.x + 1, last), ix2 = min(2 * p0.x + 2, last), iy1 = min(2 * p0.y + 1, last), iy2 = min(2 * p0.y + 2, last);
 			const NodeRec X{t.csz[p0.x], t.mult[p0.x]}, Y{t.csz[p0.y], t.mult[p0.y]};
 			const NodeRec X1{t.csz[ix1], t.mult[ix1]}, X2{t.csz[ix2], t.mult[ix2]}, Y1{t.csz[iy1], t.mult[iy1]}, Y2{t.csz[iy2], t.mult[iy2]};
+			TRAV_DEP(Y2.m); TRAV_DEP(X.c.x); TRAV_DEP(Y.c.x); TRAV_DEP(X1.c.x); TRAV_DEP(X2.c.x); TRAV_DEP(Y1.c.x); TRAV_DEP(Y2.c.x);
+			TRAV_MARK(3);
 			k0 = classify_rec(t.ntot, &tab, p0, X, Y, par, m2l_first, dm);
 			ch = pair_children(k0, p0);
 			// children (pair_children): 3 -> (x1,x1) (x1,x2) (x2,x2); 4 -> (x,y1) (x,y2); 5 -> (x1,y) (x2,y)
@@ -1242,12 +1264,15 @@ __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab
 			if (ch.n > 2) k3 = classify_rec(t.ntot, &tab, ch.c, X2, X2, par, m2l_first, dm);
 		}
 		const int nch = ch.n;
+		TRAV_DEP(k0 + k1 + k2 + k3);
+		TRAV_MARK(4);
 		auto weight = [](int q) { return (uint64_t)(q == 3 ? 3 : (q >= 4 ? 2 : 0)) | ((uint64_t)(q == 1) << 20) | ((uint64_t)(q == 2) << 40); };
 		// a split input pair itself emits nothing
 		const uint64_t cnt = nch > 0 ? weight(k1) + weight(k2) + weight(k3) : weight(k0);
 		uint64_t tot;
 		const uint64_t off = block_exclusive_scan3(cnt, sh_wave, tot);
 		const int tf = (int)(tot & 0xFFFFF), tp = (int)((tot >> 20) & 0xFFFFF), tm = (int)(tot >> 40);
+		TRAV_MARK(5);
 		if (threadIdx.x == 0) sh_base[0] = tf ? atomicAdd(&tctr[kTcFrontier + (it + 1) * kTravK + rout], tf) : 0;
 		if (threadIdx.x == 64) sh_base[1] = tp ? atomicAdd(&tctr[kTcP2P + rout], tp) : 0;
 		if (threadIdx.x == 128) sh_base[2] = tm ? atomicAdd(&tctr[kTcM2L + rout], tm) : 0;
@@ -1273,7 +1298,10 @@ __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab
 			return r;
 		};
 		const int2 r0 = slots(k0, p0, nch == 0 && i < nin), r1 = slots(k1, ch.a, nch > 0), r2 = slots(k2, ch.b, nch > 1), r3 = slots(k3, ch.c, nch > 2);
+		TRAV_DEP(r0.x + r1.x + r2.x + r3.x + r0.y + r1.y + r2.y + r3.y);
+		TRAV_MARK(6);
 		__syncthreads();
+		TRAV_MARK(7);
 		long long bf = sh_base[0], bp = sh_base[1], bm = sh_base[2];
 		const bool okf = bf + tf <= capR, okp = bp + tp <= capR, okm = bm + tm <= capR;
 		if (threadIdx.x == 0 && !(okf && okp && okm)) counters[2] = 1;
@@ -1307,8 +1335,14 @@ __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab
 			emit(k2, ch.b, r2);
 			if (nch > 2) emit(k3, ch.c, r3);
 		}
+		TRAV_MARK(8);
+		TRAV_DRAIN();
+		TRAV_MARK(9);
 		__syncthreads();
+		TRAV_MARK(10);
+		TRAV_FIRST_PASS(false);
 	}
+	TRAV_MARK(11);
 }
 
 // start state of a traversal: the root pair in the frontier, counters cleared, and (all workgroups) the per-target entry

@@ -245,17 +245,39 @@ __global__ __launch_bounds__(BLOCK) void sel_hist_warm_kernel(const float4 *__re
 	if (threadIdx.x < 2) below[threadIdx.x] = 0;
 	const long long ilast = (i0 + CHUNK < n ? i0 + CHUNK : n) - 1;
 	const long long j0 = div_floor_small(m * i0, n), j1 = div_floor_small(m * ilast, n);
+	// split axis, box and the left child's old box of the chunk's one or two nodes in one round trip (all three axes are
+	// fetched before the axis is known; the partition does the same)
+	__shared__ uint32_t meta[2][16];
+	if (threadIdx.x < 32)
+	{
+		const int jj = threadIdx.x >> 4, t = threadIdx.x & 15;
+		const long long j = j0 + jj;
+		uint32_t v = 0;
+		if (j <= j1)
+		{
+			const int node = (int)(m - 1 + j), left = 2 * node + 1;
+			if (t == 0) v = (uint32_t)sd_l[j];
+			else if (t < 4) v = __float_as_uint(lbound[3 * node + (t - 1)]);
+			else if (t < 7) v = __float_as_uint(rbound[3 * node + (t - 4)]);
+			else if (t < 10) v = __float_as_uint(rbound[3 * left + (t - 7)]);
+		}
+		meta[jj][t] = v;
+	}
+	__syncthreads();
 	float lo[2] = {0.f, 0.f}, scale[2] = {0.f, 0.f};
 	uint32_t w0[2] = {0, 0};
 	for (int jj = 0; jj < 2; ++jj)
 		if (j0 + jj <= j1)
 		{
-			lin_window(lbound, rbound, sd_l, l, j0 + jj, lo[jj], scale[jj]);
-			w0[jj] = warm_window_start(lbound, rbound, sd_l, l, j0 + jj, lo[jj], scale[jj], drop);
+			const int a = (int)meta[jj][0];
+			lo[jj] = __uint_as_float(meta[jj][1 + a]);                                         // lin_window
+			const float span = __fsub_rn(__uint_as_float(meta[jj][4 + a]), lo[jj]);
+			scale[jj] = span > 0.f ? __fdiv_rn(4294967040.f, span) : 0.f;
+			const uint32_t c = lin_key(__uint_as_float(meta[jj][7 + a]), lo[jj], scale[jj]) >> drop;   // warm_window_start
+			w0[jj] = c > (uint32_t)(kWarmBins / 2) ? c - (uint32_t)(kWarmBins / 2) : 0u;
 		}
-	__syncthreads();
 	const long long split = j1 > j0 ? range_start(n, j1, m) : n;
-	const int sd[2] = {sd_l[j0], sd_l[j1]};
+	const int sd[2] = {(int)meta[0][0], j1 > j0 ? (int)meta[1][0] : (int)meta[0][0]};
 	uint32_t nb[2] = {0, 0};
 #pragma unroll
 	for (int e = 0; e < PER; ++e)

@@ -33,6 +33,8 @@ def main():
     assert rc == 0, rc
     t = np.array(out[:], dtype=np.int64)
     t0 = t[500]
+    tv = {k - 448: t[k] for k in range(448, 500) if t[k] != 0}
+    t[448:500] = 0
     rel = {int(k): float((t[k] - t0) / 100.0) for k in range(512) if t[k] != 0}   # microseconds since kernel entry
     keys = sorted(rel, key=lambda k: rel[k])
     prev = 0.0
@@ -43,6 +45,12 @@ def main():
     for r in rows:
         print("mark %3d  t=%8.2f us  +%6.2f" % r)
     print(json.dumps({"n": n, "marks": rows}))
+    if tv:
+        ks = sorted(tv, key=lambda k: tv[k])
+        prev = tv[ks[0]]
+        for k in ks:
+            print("trav %3d  t=%8.2f us  +%6.2f" % (k, (tv[k] - tv[ks[0]]) / 100.0, (tv[k] - prev) / 100.0))
+            prev = tv[k]
     if hasattr(lib, "nbco_debug_partition_prof"):
         out = (C.c_longlong * 64)()
         assert lib.nbco_debug_partition_prof(out) == 0
