@@ -433,11 +433,13 @@ extern "C" int nbco_debug_subtree_prof(long long *out512)
 {
 	return (int)hipMemcpyFromSymbol(out512, HIP_SYMBOL(g_subtree_prof), sizeof(long long) * 512);
 }
-// ... and of one workgroup of the traversal launch NBCO_TRAV_PROF_IT (first pass of its loop)
-#ifndef NBCO_TRAV_PROF_IT
-#define NBCO_TRAV_PROF_IT 8
-#endif
-#define TRAV_MARK(k) do { if (it == NBCO_TRAV_PROF_IT && blockIdx.x == 37 && threadIdx.x == 0 && first_pass) g_subtree_prof[448 + (k)] = wall_clock64(); } while (0)
+// ... and of one workgroup of every traversal launch (first pass of its loop)
+__device__ long long g_trav_prof[36 * 12];
+#define TRAV_MARK(k) do { if (it < 36 && blockIdx.x == 37 && threadIdx.x == 0 && first_pass) g_trav_prof[it * 12 + (k)] = wall_clock64(); } while (0)
+extern "C" int nbco_debug_trav_prof(long long *out432)
+{
+	return (int)hipMemcpyFromSymbol(out432, HIP_SYMBOL(g_trav_prof), sizeof(long long) * 36 * 12);
+}
 #define TRAV_FIRST_PASS(v) first_pass = (v)
 #define TRAV_DEP(v) asm volatile("" :: "v"(v))
 #define TRAV_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")

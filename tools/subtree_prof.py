@@ -33,8 +33,6 @@ def main():
     assert rc == 0, rc
     t = np.array(out[:], dtype=np.int64)
     t0 = t[500]
-    tv = {k - 448: t[k] for k in range(448, 500) if t[k] != 0}
-    t[448:500] = 0
     rel = {int(k): float((t[k] - t0) / 100.0) for k in range(512) if t[k] != 0}   # microseconds since kernel entry
     keys = sorted(rel, key=lambda k: rel[k])
     prev = 0.0
@@ -45,12 +43,24 @@ def main():
     for r in rows:
         print("mark %3d  t=%8.2f us  +%6.2f" % r)
     print(json.dumps({"n": n, "marks": rows}))
-    if tv:
-        ks = sorted(tv, key=lambda k: tv[k])
-        prev = tv[ks[0]]
-        for k in ks:
-            print("trav %3d  t=%8.2f us  +%6.2f" % (k, (tv[k] - tv[ks[0]]) / 100.0, (tv[k] - prev) / 100.0))
-            prev = tv[k]
+    if hasattr(lib, "nbco_debug_trav_prof"):
+        out = (C.c_longlong * 432)()
+        assert lib.nbco_debug_trav_prof(out) == 0
+        tv = np.array(out[:], dtype=np.int64).reshape(36, 12)
+        names = ["start", "sizes", "pair", "records", "classified", "scanned", "slots", "barrier", "stored", "drained", "barrier2", "end"]
+        print("trav it  " + " ".join("%10s" % x for x in names[1:]))
+        for it in range(36):
+            if tv[it, 0] == 0:
+                continue
+            row = []
+            prev = tv[it, 0]
+            for k in range(1, 12):
+                if tv[it, k] == 0:
+                    row.append("         -")
+                    continue
+                row.append("%10.2f" % ((tv[it, k] - prev) / 100.0))
+                prev = tv[it, k]
+            print("trav %2d  " % it + " ".join(row))
     if hasattr(lib, "nbco_debug_partition_prof"):
         out = (C.c_longlong * 64)()
         assert lib.nbco_debug_partition_prof(out) == 0
