@@ -1496,18 +1496,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 	// with code 1 = this target's wave evaluates the pair for both leaves (source after target), 2 = the source's wave does
 	// (source before target), 0 = one direction only (the leaf itself, or a source outside the kd-domain [self0, self0 + nself))
 	const int lowbit = (DESC && mu.desc4) ? 32 : 0;
-	auto emit = [&](int t, int slot, uint64_t key) {
+	// (li, lm: first particle and multiplicity of the source leaf, fetched by the caller as soon as it knows the source -- beside the
+	// ranking, not behind it)
+	auto emit = [&](int t, int slot, uint64_t key, int li, int lm) {
 		const int src = (int)((key >> lowbit) & smask);
 		if (!NBCO_CHECKED_OK(src >= 0 && src < ntargets && slot >= start[t] && slot < start[t + 1], NBCO_CHK_SORT)) return;
 		if (DESC && mu.desc4)
 		{
 			out[slot] = ((uint64_t)t << shift) | (uint64_t)src;
 			const int code = (src == t || src < mu.self0 || src >= mu.self0 + mu.nself) ? 0 : (src > t ? 1 : 2);
-			mu.desc4[slot] = make_int4(leaf_index[src], leaf_mult[src], (int)(uint32_t)key, code);
+			mu.desc4[slot] = make_int4(li, lm, (int)(uint32_t)key, code);
 			return;
 		}
 		out[slot] = key;
-		if (DESC) desc[slot] = make_int2(leaf_index[src], leaf_mult[src]);
+		if (DESC) desc[slot] = make_int2(li, lm);
 	};
 	// mutual near field: work units of target t once its list is sorted.  Sorted order = [sources of lower kd-domains: nf
 	// entries][own sources before t: delivered by their waves][t itself][sources after t]; the work entries (all but the
@@ -1531,13 +1533,23 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 		constexpr int J = decltype(jtag)::value;
 		uint64_t key[J];
 		unsigned src[J];
-		int rank[J];
+		int rank[J], li[J], lm[J];
 #pragma unroll
 		for (int j = 0; j < J; ++j)
 		{
 			key[j] = lane + 64 * j < cnt ? in[s + lane + 64 * j] : ~0ull;
 			src[j] = (unsigned)((key[j] >> lowbit) & smask);
 			rank[j] = 0;
+		}
+#pragma unroll
+		for (int j = 0; j < J; ++j)
+		{
+			li[j] = lm[j] = 0;
+			if (DESC)
+			{
+				const int sidx = (int)min(src[j], (unsigned)(ntargets - 1));   // (idle lanes hold the all-ones key)
+				li[j] = leaf_index[sidx]; lm[j] = leaf_mult[sidx];
+			}
 		}
 #pragma unroll
 		for (int jb = 0; jb < J; ++jb)
@@ -1563,7 +1575,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 		}
 #pragma unroll
 		for (int j = 0; j < J; ++j)
-			if (lane + 64 * j < cnt) emit(t, s + rank[j], key[j]);
+			if (lane + 64 * j < cnt) emit(t, s + rank[j], key[j], li[j], lm[j]);
 		if (DESC && mu.desc4) finish_target(t, s, cnt, nf, nq, lane);
 	};
 	for (int t = blockIdx.x * (kBlock / 64) + wv; t < ntargets; t += gridDim.x * (kBlock / 64))
@@ -1630,8 +1642,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 			{
 				const int i = i0 + lane;
 				const uint64_t key = i < cnt ? src[i] : 0ull;
-				if (i < cnt) emit(t, s + i, key);
 				const int sv = (int)((key >> lowbit) & smask);
+				if (i < cnt) emit(t, s + i, key, DESC ? leaf_index[min(sv, ntargets - 1)] : 0, DESC ? leaf_mult[min(sv, ntargets - 1)] : 0);
 				nf += __popcll(__ballot(i < cnt && sv < mu.self0));
 				nq += __popcll(__ballot(i < cnt && sv < t));
 			}
