@@ -390,7 +390,16 @@ def main():
             eng.profile_reset()
         barrier()
         t0 = time.perf_counter()
-        run_steps(steps)
+        if os.environ.get("NBCO_BENCH_PYPROFILE") and rank == 0:
+            # diagnostics: where the host spends the timed steps (python side of a sharded run), top of the cumulative list to stderr
+            import cProfile, pstats
+            pr = cProfile.Profile()
+            pr.enable()
+            run_steps(steps)
+            pr.disable()
+            pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(30)
+        else:
+            run_steps(steps)
         barrier()
         elapsed = reduce(time.perf_counter() - t0, dist.ReduceOp.MAX)
         prof = eng.profile_get() if profile else None
