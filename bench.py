@@ -84,6 +84,9 @@ def spawn_ranks(args):
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # one host thread per rank: the ranks' host sides poll and stage small tensors; an OpenMP pool per rank (one thread per
+        # core of the host, spinning between parallel regions) eats the box's CPU share and stalls every collective
+        env.setdefault("OMP_NUM_THREADS", "1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=out0 if r == 0 else subprocess.DEVNULL))
     failed = None
@@ -212,12 +215,32 @@ def host_cpu():
     return n, model
 
 
+def cpu_quota():
+    """CPUs' worth of time the cgroup of this process may use (None: no limit found)"""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:            # cgroup v2
+            q, p = f.read().split()[:2]
+            return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:   # v1
+            q, p = float(f.read()), float(g.read())
+            return None if q <= 0 else q / p
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(args, n):
     """The oracle (a port of the reference's multithreaded CPU path) on a bounded sample of the same workload: one
-    std::thread per physical host core."""
+    std::thread per physical host core this process can actually keep busy (the box's CPU quota caps it: more threads than
+    that only get throttled)."""
     from oracle import pyoracle as po
     o = po.Oracle(np.float32)
-    cores, model = host_cpu()
+    phys, model = host_cpu()
+    quota = cpu_quota()
+    cores = phys if quota is None else max(1, min(phys, int(quota + 0.999)))
+    model = "%s (%d physical cores visible, cgroup CPU quota %s)" % (model, phys, "none" if quota is None else "%.4g" % quota)
     buf = gaussian_ball(n)                  # the same state the GPU run starts from (rank 0)
     par = coulomb_params(n)
     if args.workload == "fmm_kd":
@@ -277,6 +300,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.set_num_threads(1)   # (see spawn_ranks; also when the ranks come from torchrun)
     # Libraries below may write to stdout on their own (RCCL prints a version banner when its first communicator comes up): the
     # process's stdout carries the ONE JSON line and nothing else, everything before it goes to stderr
     sys.stdout.flush()
@@ -390,7 +415,7 @@ def main():
             eng.profile_reset()
         barrier()
         t0 = time.perf_counter()
-        if os.environ.get("NBCO_BENCH_PYPROFILE") and rank == 0:
+        if os.environ.get("NBCO_BENCH_PYPROFILE") and rank == int(os.environ["NBCO_BENCH_PYPROFILE"]) - 1:   # 1 = rank 0, 2 = rank 1, ..
             # diagnostics: where the host spends the timed steps (python side of a sharded run), top of the cumulative list to stderr
             import cProfile, pstats
             pr = cProfile.Profile()
