@@ -24,7 +24,7 @@ namespace {
 
 using namespace kdc;
 
-// Workgroups of BLOCK threads take chunks of 8 * BLOCK consecutive elements; a chunk must touch at most two nodes.
+// Workgroups of BLOCK threads take chunks of 8 * BLOCK consecutive elements (4 * BLOCK in the warm kernels); a chunk must touch at most two nodes.
 // Atomics on one address retire at ~27 ns each on this part, and every workgroup of a node adds to the node's histogram
 // bins, completion counters and partition cursors: levels whose nodes hold >= 8192 particles use 1024-thread workgroups
 // (8192-element chunks), a quarter of the workgroups per node; the rest (nodes of 4097..8191) use 256 / 2048.
@@ -223,12 +223,12 @@ __device__ inline uint32_t warm_window_start(const float *__restrict__ lbound, c
 	return c > (uint32_t)(kWarmBins / 2) ? c - (uint32_t)(kWarmBins / 2) : 0u;
 }
 
-template <int BLOCK>
+template <int BLOCK, int EPT = 8>
 __global__ __launch_bounds__(BLOCK) void sel_hist_warm_kernel(const float4 *__restrict__ pos, const int *__restrict__ sd_l, uint32_t *__restrict__ hist,
                                                                SelNode *__restrict__ nodes, const float *__restrict__ lbound,
                                                                const float *__restrict__ rbound, long long n, int l, int drop)
 {
-	constexpr int CHUNK = 8 * BLOCK;
+	constexpr int CHUNK = EPT * BLOCK;
 	__shared__ uint32_t h[2][kWarmBins];
 	__shared__ uint32_t below[2];
 	const long long m = 1LL << l;
@@ -491,7 +491,7 @@ __device__ inline void ties_and_boxes(float4 *__restrict__ pos_out, int *__restr
 // atomics; (3) the stores drain; (4) the completion counter; (5) the completing wave fetches counters and candidate records in
 // one batch.  (Round 2 started with eleven: axis -> box -> old pivot -> histogram -> ancestors' axes, one atomic per
 // candidate, and three rounds of loads in the tail.)
-template <int BLOCK, int NP, bool WARM = false>
+template <int BLOCK, int NP, bool WARM = false, int EPT = 8>
 __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__restrict__ pos_in, const int *__restrict__ unsort_in,
                                                                float4 *__restrict__ pos_out, int *__restrict__ unsort_out,
                                                                const int *__restrict__ sd_l, SelNode *__restrict__ nodes,
@@ -499,8 +499,9 @@ __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__re
                                                                float *__restrict__ rbound, int *__restrict__ splitdim, int *__restrict__ index,
                                                                int *__restrict__ flag, const uint32_t *__restrict__ hist, int drop)
 {
-	constexpr int CHUNK = 8 * BLOCK;
+	constexpr int CHUNK = EPT * BLOCK;
 	static_assert(CHUNK < 65536, "packed 16-bit block counters");
+	static_assert(EPT == 8 || WARM, "the cold select's passes agree on 8 elements per thread");
 	static_assert(BLOCK >= 128, "two nodes' descriptions are fetched by 128 threads");
 	__shared__ uint32_t base_s[6], mR[2], ntie_s[2];   // base_s[4 + jj]: first slot of the workgroup's candidates in node jj's list
 	__shared__ uint32_t meta[2][kMetaWords];
@@ -786,9 +787,15 @@ static void select_level_launch(nbco_ctx *c, int l, long long n, const float4 *p
 	const int gchunks = (int)((n + CHUNK - 1) / CHUNK);
 	if (NP == 2 && warm_drop > 0)
 	{
-		hipLaunchKernelGGL((sel_hist_warm_kernel<BLOCK>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l,
-		                   warm_drop);
-		hipLaunchKernelGGL((sel_partition_kernel<BLOCK, 2, true>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, unsort_in, pos_out, unsort_out, sd_l, nodes, ties, n, l,
+		// The warm kernels take FOUR elements per thread (twice the workgroups of the cold passes: 256 of them at N = 1M).  A
+		// workgroup's time is its threads' serial work -- classify, ballots, slot arithmetic per element -- not the node's
+		// atomics: 8 elements per thread took 18.8 us per partition, 4 take 16; 2 are worse again (0.86 ms per step against
+		// 0.80), and 512-thread workgroups with 8 elements each gain nothing.
+		constexpr int EPT = BLOCK == kBlockBig ? 4 : 8;
+		const int wchunks = (int)((n + EPT * BLOCK - 1) / (EPT * BLOCK));
+		hipLaunchKernelGGL((sel_hist_warm_kernel<BLOCK, EPT>), dim3(wchunks), dim3(BLOCK), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound,
+		                   n, l, warm_drop);
+		hipLaunchKernelGGL((sel_partition_kernel<BLOCK, 2, true, EPT>), dim3(wchunks), dim3(BLOCK), 0, st, pos_in, unsort_in, pos_out, unsort_out, sd_l, nodes, ties, n, l,
 		                   lbound, rbound, splitdim, index, flag, (const uint32_t *)hist, warm_drop);
 		return;
 	}
