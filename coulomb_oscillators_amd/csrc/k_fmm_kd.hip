@@ -1300,9 +1300,10 @@ __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab
 			return r;
 		};
 		const int2 r0 = slots(k0, p0, nch == 0 && i < nin), r1 = slots(k1, ch.a, nch > 0), r2 = slots(k2, ch.b, nch > 1), r3 = slots(k3, ch.c, nch > 2);
-		TRAV_DEP(r0.x + r1.x + r2.x + r3.x + r0.y + r1.y + r2.y + r3.y);
-		TRAV_MARK(6);
-		__syncthreads();
+		// The barrier publishes the block's three reservations (sh_base, LDS).  It must NOT wait for the slot atomics above, which
+		// take 2-8 us to come back in a wide launch: an LDS-only barrier (no workgroup fence, which would drain the vector-memory
+		// counter), the pairs and the next frontier are stored under that wait, the slots last.
+		asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 		TRAV_MARK(7);
 		long long bf = sh_base[0], bp = sh_base[1], bm = sh_base[2];
 		const bool okf = bf + tf <= capR, okp = bp + tp <= capR, okm = bm + tm <= capR;
@@ -1315,9 +1316,11 @@ __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab
 		if (!okf && bf < capR)
 			for (long long k = bf + threadIdx.x; k < capR; k += kBlock) fout[obase + k] = make_int2(0, 0);
 		bf += (long long)(off & 0xFFFFF); bp += (long long)((off >> 20) & 0xFFFFF); bm += (long long)(off >> 40);
-		auto emit = [&](int q, int2 np, int2 r) {
-			if (q == 1 && okp) { p2p[obase + bp] = np; p2p_rank[obase + bp] = r; }
-			if (q == 2 && okm) { m2l[obase + bm] = np; m2l_rank[obase + bm] = r; }
+		// returns the entry's place in its pair list (-1: none)
+		auto emit = [&](int q, int2 np) {
+			long long at = -1;
+			if (q == 1 && okp) { p2p[obase + bp] = np; at = obase + bp; }
+			if (q == 2 && okm) { m2l[obase + bm] = np; at = obase + bm; }
 			const PairKids g = pair_children(q, np);
 			if (q >= 3 && okf)
 			{
@@ -1329,14 +1332,23 @@ __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab
 			bp += q == 1 ? 1 : 0;
 			bm += q == 2 ? 1 : 0;
 			bf += g.n;
+			return at;
 		};
-		if (nch == 0) emit(k0, p0, r0);
+		long long at0 = -1, at1 = -1, at2 = -1, at3 = -1;
+		if (nch == 0) at0 = emit(k0, p0);
 		else
 		{
-			emit(k1, ch.a, r1);
-			emit(k2, ch.b, r2);
-			if (nch > 2) emit(k3, ch.c, r3);
+			at1 = emit(k1, ch.a);
+			at2 = emit(k2, ch.b);
+			if (nch > 2) at3 = emit(k3, ch.c);
 		}
+		TRAV_DEP(r0.x + r1.x + r2.x + r3.x + r0.y + r1.y + r2.y + r3.y);
+		TRAV_MARK(6);
+		auto put_slots = [&](int q, long long at, int2 r) {
+			if (at < 0) return;
+			if (q == 1) p2p_rank[at] = r; else m2l_rank[at] = r;
+		};
+		put_slots(k0, at0, r0); put_slots(k1, at1, r1); put_slots(k2, at2, r2); put_slots(k3, at3, r3);
 		TRAV_MARK(8);
 		TRAV_DRAIN();
 		TRAV_MARK(9);

@@ -47,14 +47,16 @@ def main():
         out = (C.c_longlong * 432)()
         assert lib.nbco_debug_trav_prof(out) == 0
         tv = np.array(out[:], dtype=np.int64).reshape(36, 12)
-        names = ["start", "sizes", "pair", "records", "classified", "scanned", "slots", "barrier", "stored", "drained", "barrier2", "end"]
-        print("trav it  " + " ".join("%10s" % x for x in names[1:]))
+        names = {0: "start", 1: "sizes", 2: "pair", 3: "records", 4: "classified", 5: "scanned", 7: "barrier", 6: "slots", 8: "stored", 9: "drained",
+                 10: "barrier2", 11: "end"}
+        order = [1, 2, 3, 4, 5, 7, 6, 8, 9, 10, 11]   # program order of the marks (the slots are awaited after the barrier)
+        print("trav it  " + " ".join("%10s" % names[k] for k in order))
         for it in range(36):
             if tv[it, 0] == 0:
                 continue
             row = []
             prev = tv[it, 0]
-            for k in range(1, 12):
+            for k in order:
                 if tv[it, k] == 0:
                     row.append("         -")
                     continue
