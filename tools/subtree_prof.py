@@ -1,9 +1,15 @@
-"""Phase timestamps inside kd_subtree_kernel (one workgroup), from the profiling build of the kd-tree file:
+"""Phase timestamps inside the build and traversal kernels (one workgroup each), from the profiling build of the library:
 
     make -C coulomb_oscillators_amd/csrc prof
     NBCO_LIB=coulomb_oscillators_amd/libnbco_hip_prof.so python tools/subtree_prof.py [n]
 
-Marks are 100 MHz wall-clock reads of thread 0 after the barriers that end a phase.  Diagnostics only."""
+  mark ..  kd_subtree_kernel: 16 s + k = phase k of in-LDS selection level s, 4xx = rank sort, output, leaf centres
+  part ..  sel_partition_kernel of level 7: start, loads issued, description fetched, select resolved, classified (10: wave 0 done),
+           cursors reserved, stores issued, drained, completion counter, tail
+  trav ..  traverse_kernel, every launch: time spent in each phase (program order)
+
+Marks are 100 MHz wall-clock reads of thread 0 after the barriers that end a phase.  NBCO_SUBTREE_TWICE=1 launches the subtree
+kernel twice in a row (the marks then belong to the second, instruction-cache-warm launch).  Diagnostics only."""
 import ctypes as C
 import json
 import os
