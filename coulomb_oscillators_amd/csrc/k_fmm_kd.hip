@@ -1545,7 +1545,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 		constexpr int J = decltype(jtag)::value;
 		uint64_t key[J];
 		unsigned src[J];
-		int rank[J], li[J], lm[J];
+		// (the descriptors are fetched beside the ranking only while they fit the register budget of 8 waves per SIMD: with more
+		// than four entries per lane they would spill to scratch, and a kernel with a scratch segment pays for it on every launch)
+		constexpr bool PRE = DESC && J <= 4;
+		int rank[J], li[PRE ? J : 1], lm[PRE ? J : 1];
 #pragma unroll
 		for (int j = 0; j < J; ++j)
 		{
@@ -1555,14 +1558,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 		}
 #pragma unroll
 		for (int j = 0; j < J; ++j)
-		{
-			li[j] = lm[j] = 0;
-			if (DESC)
+			if (PRE)
 			{
 				const int sidx = (int)min(src[j], (unsigned)(ntargets - 1));   // (idle lanes hold the all-ones key)
 				li[j] = leaf_index[sidx]; lm[j] = leaf_mult[sidx];
 			}
-		}
 #pragma unroll
 		for (int jb = 0; jb < J; ++jb)
 		{
@@ -1587,7 +1587,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 		}
 #pragma unroll
 		for (int j = 0; j < J; ++j)
-			if (lane + 64 * j < cnt) emit(t, s + rank[j], key[j], li[j], lm[j]);
+			if (lane + 64 * j < cnt)
+			{
+				if (PRE) emit(t, s + rank[j], key[j], li[j], lm[j]);
+				else
+				{
+					const int sidx = DESC ? (int)min(src[j], (unsigned)(ntargets - 1)) : 0;
+					emit(t, s + rank[j], key[j], DESC ? leaf_index[sidx] : 0, DESC ? leaf_mult[sidx] : 0);
+				}
+			}
 		if (DESC && mu.desc4) finish_target(t, s, cnt, nf, nq, lane);
 	};
 	for (int t = blockIdx.x * (kBlock / 64) + wv; t < ntargets; t += gridDim.x * (kBlock / 64))

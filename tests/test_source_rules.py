@@ -77,7 +77,7 @@ def _kernel_descriptors(blob, base):
                 continue
             sec = secs[shndx]
             kd = base + sec["off"] + (value - sec["addr"])
-            yield name[:-3], struct.unpack_from("<H", blob, kd + 56)[0]
+            yield name[:-3], struct.unpack_from("<H", blob, kd + 56)[0], struct.unpack_from("<I", blob, kd + 4)[0]
 
 
 def test_no_kernel_reads_the_dispatch_packet():
@@ -88,9 +88,36 @@ def test_no_kernel_reads_the_dispatch_packet():
     blob = open(lib, "rb").read()
     seen, bad = 0, []
     for base in _device_elfs(blob):
-        for name, props in _kernel_descriptors(blob, base):
+        for name, props, _scratch in _kernel_descriptors(blob, base):
             seen += 1
             if props & 0x6:   # ENABLE_SGPR_DISPATCH_PTR | ENABLE_SGPR_QUEUE_PTR
                 bad.append(name)
     assert seen > 50, "kernel descriptors not found (%d)" % seen
     assert not bad, "kernels that read the dispatch / queue packet from host memory: %s" % bad
+
+
+# The kernels of a step's critical path keep everything in registers: a private (scratch) segment means spills or an indexed
+# private array -- memory round trips inside latency-bound kernels, and a scratch set-up on every launch.  (Round 2: 36 bytes in
+# list_segsort_kernel<true> after two more values per entry were kept across the ranking loop of its 8-entries-per-lane case.)
+# The high orders of the generated far-field operators (p >= 8, fp64 above all) do spill; they are not on this list.
+NO_SCRATCH = ["kd_subtree_kernel", "sel_partition_kernel", "sel_hist_warm_kernel", "sel_hist_kernel", "traverse_kernel", "traverse_init_kernel",
+              "traverse_finish_kernel", "list_fill_kernel", "list_segsort_kernel", "p2p_kernel", "p2p_mutual_kernel", "kd_turnaround_kernel",
+              "kd_prep_kernel", "kd_centres_kernel", "kd_centres_top_kernel", "direct_tiles"]
+
+
+def test_critical_path_kernels_use_no_scratch():
+    lib = os.path.join(ROOT, "coulomb_oscillators_amd", "libnbco_hip.so")
+    if not os.path.exists(lib):
+        import pytest
+        pytest.skip("libnbco_hip.so is not built")
+    blob = open(lib, "rb").read()
+    found, bad = set(), []
+    for base in _device_elfs(blob):
+        for name, _props, scratch in _kernel_descriptors(blob, base):
+            for k in NO_SCRATCH:
+                if k in name:
+                    found.add(k)
+                    if scratch:
+                        bad.append((name, scratch))
+    assert found == set(NO_SCRATCH), "kernels not found in the library: %s" % sorted(set(NO_SCRATCH) - found)
+    assert not bad, "critical-path kernels with a scratch segment (bytes per lane): %s" % bad
