@@ -1485,6 +1485,30 @@ __global__ __launch_bounds__(kBlock) void list_fill_kernel(const int2 *__restric
 #define NBCO_P2P_CHUNK 16
 #endif
 constexpr int kP2PChunk = NBCO_P2P_CHUNK;   // source leaves per near-field work unit (see the P2P section)
+
+// diagnostics only: the near-field launch's arrays as one binary file {header 8 x int64: n, entries, chunks, mlt_max, stride, 0, 0, 0;
+// float4 pos[n]; int2 desc[entries]; int4 chunk[chunks]; float4 partial[chunks * stride]} for tools/p2p_lab.hip.  Synchronises.
+static int p2p_dump(nbco_ctx *c, const char *path, const float4 *pos, const int2 *desc, const int4 *chunk, const int *nchunks, const int *nentries, int mlt_max,
+                    const float4 *partial, long long n)
+{
+	NBCO_HIP(hipStreamSynchronize(c->stream));
+	int hc = 0, he = 0;
+	NBCO_HIP(hipMemcpy(&hc, nchunks, sizeof(int), hipMemcpyDeviceToHost));
+	NBCO_HIP(hipMemcpy(&he, nentries, sizeof(int), hipMemcpyDeviceToHost));
+	FILE *f = std::fopen(path, "wb");
+	if (!f) return c->fail(NBCO_ERR_ARG, "NBCO_P2P_DUMP: cannot open the file");
+	const long long head[8] = {n, he, hc, mlt_max, mlt_max, 0, 0, 0};
+	std::fwrite(head, sizeof head, 1, f);
+	auto put = [&](const void *dev, size_t bytes) {
+		std::vector<char> h(bytes);
+		if (hipMemcpy(h.data(), dev, bytes, hipMemcpyDeviceToHost) != hipSuccess) return false;
+		return std::fwrite(h.data(), 1, bytes, f) == bytes;
+	};
+	const bool ok = put(pos, sizeof(float4) * (size_t)n) && put(desc, sizeof(int2) * (size_t)he) && put(chunk, sizeof(int4) * (size_t)hc) &&
+	                put(partial, sizeof(float4) * (size_t)hc * (size_t)mlt_max);
+	std::fclose(f);
+	return ok ? NBCO_OK : c->fail(NBCO_ERR_HIP, "NBCO_P2P_DUMP: copy failed");
+}
 // DESC: the list is the P2P list -- also emit the source descriptor (first particle, multiplicity) of every sorted entry,
 // so the pair kernel does no dependent index -> mult -> position loads
 // what the per-target sort of the P2P list also produces for the mutual near-field kernel (k_p2p.hpp); desc4 == nullptr: off
@@ -2167,6 +2191,9 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		else if (mlt_max <= 32) launch_p2p<32>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near, n);
 		else launch_p2p<64>(c, pos, pd, pc, pt, chunks_hint, mlt_max, mlt_max, near, n);
 		NBCO_HIP(hipGetLastError());
+		// diagnostics (tools/p2p_lab.hip): NBCO_P2P_DUMP=<file> writes the inputs and the partial sums of the near-field launch
+		static const char *dump_path = std::getenv("NBCO_P2P_DUMP");
+		if (dump_path && !mutual) NBCO_TRY(p2p_dump(c, dump_path, pos, pd, pc, pt, c->p2p_start.as<int>() + nleaf, mlt_max, near, n));
 		return NBCO_OK;
 	};
 	// ---- directed sorted lists --------------------------------------------------------------------------

@@ -115,6 +115,9 @@ class SingleComm:
         return t
 
 
+_ERR_UNSUPPORTED = 4   # NBCO_ERR_UNSUPPORTED (include/nbco.h)
+
+
 def run_dist_step(comm, work, st):
     """the collective a nbco_dist_step describes, on the uint8 workspace tensor `work` (include/nbco.h)"""
     G = comm.world
@@ -159,6 +162,7 @@ class DomainRun:
         self.state_all = None if self.dpart else torch.empty(6 * self.n_global, dtype=f32, device=self.device)
         self.work = torch.empty(engine.dist_repartition_workspace(self.n_global, self.world), dtype=u8, device=self.device) if self.dpart else None
         self.partition_bytes = None
+        self.partition_fallbacks = 0   # cuts that fell back from the distributed re-partition to the gathered one (pivot ties)
         self.nodes_send = torch.empty(int(self.lay.nodes_bytes), dtype=u8, device=self.device)
         self.pos_send = torch.empty(int(self.lay.pos_bytes), dtype=u8, device=self.device)
         self.nodes_all = torch.empty(G * int(self.lay.nodes_bytes), dtype=u8, device=self.device)
@@ -231,19 +235,29 @@ class DomainRun:
             if vel_mine.data_ptr() != self.vel.data_ptr():
                 self.vel.copy_(vel_mine.reshape(-1))
             moved = 0
-            st = self.eng.dist_repartition_begin(self.buf, N, self.world, self.rank, self.work)
-            while st.op != 0:
-                run_dist_step(self.comm, self.work, st)
-                if st.op == 4:
-                    moved += st.row_bytes * (sum(int(st.rows_recv[r]) for r in range(self.world)) - int(st.rows_recv[self.rank]))
-                elif st.op == 3:
-                    moved += (self.world - 1) * st.count
-                else:
-                    moved += 2 * 4 * st.count   # (an all-reduce moves about twice its payload per rank)
-                st = self.eng.dist_repartition_next()
-            self.partition_bytes = moved
-            self.evals = 0
-            return
+            try:
+                st = self.eng.dist_repartition_begin(self.buf, N, self.world, self.rank, self.work)
+                while st.op != 0:
+                    run_dist_step(self.comm, self.work, st)
+                    if st.op == 4:
+                        moved += st.row_bytes * (sum(int(st.rows_recv[r]) for r in range(self.world)) - int(st.rows_recv[self.rank]))
+                    elif st.op == 3:
+                        moved += (self.world - 1) * st.count
+                    else:
+                        moved += 2 * 4 * st.count   # (an all-reduce moves about twice its payload per rank)
+                    st = self.eng.dist_repartition_next()
+                self.partition_bytes = moved
+                self.evals = 0
+                return
+            except Exception as e:
+                # More pivot ties on one rank than the distributed select resolves (lattice / planar / duplicated coordinates):
+                # NBCO_ERR_UNSUPPORTED.  Every rank sees the same gathered tie counts, so the failure is collective, and it is
+                # reported before the local state has been touched: all ranks switch to the gathered form, which takes any input.
+                if getattr(e, "status", None) != _ERR_UNSUPPORTED:
+                    raise
+                self.use_gather_partition()
+                self.partition_fallbacks += 1
+                pos_mine, vel_mine = self.pos, self.vel
         self.partition_bytes = (self.world - 1) * 24 * nl
         self.comm.all_gather(self.state_all[: 3 * N], pos_mine.contiguous().view(-1))
         self.comm.all_gather(self.state_all[3 * N:], vel_mine.contiguous().view(-1))
@@ -444,7 +458,15 @@ class LoopbackWorld:
 
     def partition(self, pos_parts, vel_parts):
         if all(r.dpart for r in self.runs):
-            return self._repartition(pos_parts, vel_parts)
+            try:
+                return self._repartition(pos_parts, vel_parts)
+            except Exception as e:   # pivot ties beyond the distributed select: the gathered form, as DomainRun.partition does
+                if getattr(e, "status", None) != _ERR_UNSUPPORTED:
+                    raise
+                for r in self.runs:
+                    r.use_gather_partition()
+                    r.partition_fallbacks += 1
+                pos_parts, vel_parts = [r.pos for r in self.runs], [r.vel for r in self.runs]
         state = torch.cat([torch.cat([p.reshape(-1) for p in pos_parts]), torch.cat([v.reshape(-1) for v in vel_parts])])
         for r in self.runs:
             r.state_all.copy_(state)

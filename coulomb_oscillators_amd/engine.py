@@ -24,7 +24,14 @@ KD_FIELDS = {"mult": 0, "index": 1, "splitdim": 2, "center": 3, "lbound": 4, "rb
 
 
 class EngineError(RuntimeError):
-    pass
+    """status is the NBCO_ERR_* code of include/nbco.h when the error came from the library (None otherwise)"""
+
+    def __init__(self, msg, status=None):
+        super().__init__(msg)
+        self.status = status
+
+
+ERR_UNSUPPORTED = 4   # NBCO_ERR_UNSUPPORTED
 
 
 class Opts(C.Structure):
@@ -202,7 +209,7 @@ class Engine:
 
     def _chk(self, rc):
         if rc != 0:
-            raise EngineError("nbco status %d: %s" % (rc, self.lib.nbco_last_error(self.ctx).decode()))
+            raise EngineError("nbco status %d: %s" % (rc, self.lib.nbco_last_error(self.ctx).decode()), status=rc)
 
     # ---- options --------------------------------------------------------------------------------
     def opts(self):

@@ -4,11 +4,14 @@
 // line, the initial state and the snapshot format -- a snapshot of a G-GPU run is the same [pos | vel] file, in the tree order
 // of the global kd-tree (rank r's particles are rows [r N/G, (r+1) N/G)).
 //
-//   nbco3_dist -gpus G [-n N] [-p order] [-ds dt] [-iters n] [-steps n] [-r radius] [-i dens] [-rebalance k] [-o folder]
-//              [-exchange let|gather] [-partition dist|gather]
+//   nbco3_dist -gpus G [-n N] [-p order] [-ds dt] [-iters n] [-steps n] [-r radius] [-i dens] [-rebalance k] [-tree-steps k]
+//              [-o folder] [-exchange let|gather] [-partition dist|gather]
 //
-// The launcher process forks the G ranks BEFORE anything touches the GPU; rank 0's ncclUniqueId reaches the others through
-// pipes.  Per evaluation: subtree build -> all-gather of positions and traversal records ->
+// The launcher process is a SUPERVISOR, not a rank: it forks all G ranks before anything touches the GPU, never makes a HIP or
+// RCCL call itself, waits for the ranks, and when one of them exits with a failure (or is killed) it kills the others -- which
+// would otherwise block in their next collective for ever -- and returns non-zero.  Nothing is restarted or re-exec'ed.  Rank
+// 0's ncclUniqueId reaches the other ranks through pipes.  Between two snapshots the leapfrog steps run with ONE pass over the
+// domain's state between two force evaluations (nbco_dist_turnaround), as nbco3 does on one GPU (nbco_integrate_steps).  Per evaluation: subtree build -> all-gather of positions and traversal records ->
 // multipoles -> all-gather of the multipoles, on a communication stream of their own, under the traversal -> lists, near and
 // far field, L2P.  Every `rebalance` evaluations the domains are cut again from the gathered state (nbco_dist_partition).
 // Defaults since round 2 (INTEGRATION.md sections 4a, 4b): the locally-essential-tree exchange -- all-gather of the traversal
@@ -17,11 +20,15 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <signal.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include <cerrno>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -45,7 +52,9 @@ namespace {
 
 struct Args
 {
-	int gpus = 1, n = 1 << 20, order = 3, iters = 30001, steps = 200, rebalance = 16;
+	int gpus = 1, n = 1 << 20, order = 3, iters = 30001, steps = 200, rebalance = 16, tree_steps = 1;
+	int fail_rank = -1, fail_iter = 0;   // test hook (NBCO3_DIST_FAIL=rank:iteration): that rank exits with status 9 before that iteration
+	int hang_rank = -1;                  // test hook (NBCO3_DIST_HANG=rank): that rank sleeps for ever instead of running
 	bool let = true, dist_partition = true;
 	float dt = 5.e-4f, radius = 1.f, dens = 1.f, xi = 2.e-6f;
 	std::string out = "out";
@@ -62,6 +71,7 @@ struct Rank
 	float *buf = nullptr, *state_all = nullptr, *par = nullptr;
 	char *pos_send = nullptr, *nodes_send = nullptr, *pos_all = nullptr, *nodes_all = nullptr;
 	long long evals = 0;
+	int partition_fallbacks = 0;
 	bool let = true, dist_partition = true;
 	// LET exchange: count blocks (device + host), record buffers sized for the worst case (everything needed by everyone)
 	long long *counts_send = nullptr, *counts_all_dev = nullptr;
@@ -100,8 +110,11 @@ struct Rank
 		NCCLCHK(ncclGroupEnd());
 	}
 
-	// nbco_dist_repartition_*: every collective the library names runs on the compute stream, in order
-	void repartition()
+	// nbco_dist_repartition_*: every collective the library names runs on the compute stream, in order.  Returns false when the
+	// library reports more pivot ties on one rank than the distributed select resolves (NBCO_ERR_UNSUPPORTED: lattice, planar or
+	// duplicated coordinates).  The tie counts are gathered, so every rank gets the same answer at the same stage, and the local
+	// state has not been touched at that point.
+	bool repartition()
 	{
 		nbco_dist_step st{};
 		check(nbco_dist_repartition_begin(ctx, buf, lay.n_global, world, rank, work, work_bytes, &st), "nbco_dist_repartition_begin");
@@ -115,13 +128,16 @@ struct Rank
 			case NBCO_COLL_ALLTOALL: all_to_all(work + st.send_off, work + st.recv_off, st.rows_send, st.rows_recv, (size_t)st.row_bytes, nullptr); break;
 			default: std::cerr << "rank " << rank << ": unknown collective " << st.op << std::endl; std::exit(4);
 			}
-			check(nbco_dist_repartition_next(ctx, &st), "nbco_dist_repartition_next");
+			const int rc = nbco_dist_repartition_next(ctx, &st);
+			if (rc == NBCO_ERR_UNSUPPORTED) return false;
+			check(rc, "nbco_dist_repartition_next");
 		}
 		evals = 0;
+		return true;
 	}
 
 	// one force evaluation with the LET exchange
-	void force_let()
+	void force_let(bool elastic)
 	{
 		const long long nl = lay.n_local;
 		const int S = lay.let_counts;
@@ -158,14 +174,22 @@ struct Rank
 		all_to_all(let_pos_send, let_pos_recv, ps.data(), pr.data(), 16, nullptr);
 		all_to_all(let_mp_send, let_mp_recv, ms.data(), mr.data(), (size_t)lay.let_node_bytes, nullptr);
 		check(nbco_dist_let_finish(ctx, counts_all.data(), let_pos_recv, let_mp_recv, buf, buf + 6 * nl, par), "nbco_dist_let_finish");
-		check(nbco_add_elastic(ctx, buf, buf + 6 * nl, nl, par + 3), "nbco_add_elastic");
+		if (elastic) check(nbco_add_elastic(ctx, buf, buf + 6 * nl, nl, par + 3), "nbco_add_elastic");
 		++evals;
 	}
 
 	void partition()
 	{
-		if (dist_partition) { repartition(); return; }
+		if (dist_partition)
+		{
+			if (repartition()) return;
+			// pivot ties beyond the distributed select, on every rank alike: from here on the gathered form, which takes any input
+			if (rank == 0) std::cerr << "nbco3_dist: " << nbco_last_error(ctx) << " -- switching to -partition gather" << std::endl;
+			dist_partition = false;
+			++partition_fallbacks;
+		}
 		const long long nl = lay.n_local, N = lay.n_global;
+		if (!state_all) HIPCHK(hipMalloc((void **)&state_all, sizeof(float) * 6 * (size_t)N));
 		gather(buf, state_all, sizeof(float) * 3 * nl, ev_geom);                   // positions
 		gather(buf + 3 * nl, state_all + 3 * N, sizeof(float) * 3 * nl, ev_geom);   // velocities
 		HIPCHK(hipStreamWaitEvent(nullptr, ev_geom, 0));
@@ -173,10 +197,10 @@ struct Rank
 		evals = 0;
 	}
 
-	void force(int rebalance)
+	void force(int rebalance, bool elastic)
 	{
 		if (rebalance > 0 && evals >= rebalance) partition();
-		if (let) { force_let(); return; }
+		if (let) { force_let(elastic); return; }
 		const long long nl = lay.n_local;
 		char *csz_send = nodes_send, *mp_send = nodes_send + lay.csz_bytes;
 		char *csz_all = nodes_all, *mp_all = nodes_all + (size_t)world * lay.csz_bytes;
@@ -192,16 +216,25 @@ struct Rank
 		check(nbco_aux_stream(ctx, &aux), "nbco_aux_stream");
 		HIPCHK(hipStreamWaitEvent((hipStream_t)aux, ev_mpole, 0));
 		check(nbco_dist_finish_rest(ctx, mp_all, buf, buf + 6 * nl, par), "nbco_dist_finish_rest");
-		check(nbco_add_elastic(ctx, buf, buf + 6 * nl, nl, par + 3), "nbco_add_elastic");
+		if (elastic) check(nbco_add_elastic(ctx, buf, buf + 6 * nl, nl, par + 3), "nbco_add_elastic");
 		++evals;
 	}
 
-	void leapfrog(float dt, int rebalance)   // integrator.cuh:68-96
+	// `steps` leapfrog steps (integrator.cuh:68-96).  Between two force evaluations ONE pass over the domain's state does the
+	// elastic term, the half kick that ends a step, the half kick and the drift that begin the next, and the next local build's
+	// prologue (nbco_dist_turnaround; bit-identical to nbco_add_elastic + three nbco_step calls).
+	void leapfrog_steps(float dt, int rebalance, int steps)
 	{
 		const long long nl = lay.n_local;
+		if (steps <= 0) return;
 		check(nbco_step(ctx, buf + 3 * nl, buf + 6 * nl, 0.5f * dt, nl), "step");
 		check(nbco_step(ctx, buf, buf + 3 * nl, dt, nl), "step");
-		force(rebalance);
+		for (int s = 0; s < steps; ++s)
+		{
+			force(rebalance, false);
+			if (s + 1 < steps) check(nbco_dist_turnaround(ctx, buf, nl, par, (double)dt, 1.0, 1), "nbco_dist_turnaround");
+		}
+		check(nbco_add_elastic(ctx, buf, buf + 6 * nl, nl, par + 3), "nbco_add_elastic");
 		check(nbco_step(ctx, buf + 3 * nl, buf + 6 * nl, 0.5f * dt, nl), "step");
 	}
 };
@@ -222,7 +255,7 @@ int run_rank(const Args &a, int rank, const ncclUniqueId &id)
 	nbco_opts o;
 	nbco_opts_default(&o);
 	o.fmm_order = a.order; o.tree_radius = a.radius; o.dens_inhom = a.dens;
-	o.unsort = 0; o.sync = 0; o.tree_steps = 1;
+	o.unsort = 0; o.sync = 0; o.tree_steps = a.tree_steps;
 	if (nbco_create(&r.ctx, &o) != NBCO_OK) { std::cerr << "nbco_create failed" << std::endl; return -1; }
 	r.check(nbco_dist_layout_query(r.ctx, a.n, a.gpus, rank, &r.lay), "nbco_dist_layout_query");
 	const long long N = a.n, nl = r.lay.n_local;
@@ -231,11 +264,15 @@ int run_rank(const Args &a, int rank, const ncclUniqueId &id)
 	std::vector<float> host(6 * (size_t)N);
 	const float sx[3] = {0.003f, 0.001f, 0.01f}, su[3] = {1.095f * 0.003f, 0.001f, 0.01f};
 	if (nbco_init_gaussian(host.data(), N, sx, su, NBCO_REF_SEED, NBCO_REF_DISCARD, 0) != NBCO_OK) return -1;
+	if (const char *q = getenv("NBCO3_DIST_QUANTISE"))   // test hook: positions on a lattice (many exact ties with every pivot)
+	{
+		const float step = (float)atof(q);
+		if (step > 0) for (size_t i = 0; i < 3 * (size_t)N; ++i) host[i] = step * std::nearbyint(host[i] / step);
+	}
 	const float parh[6] = {a.xi / (float)N, 0, 0, 1.095f * 1.095f, 1.f, 1.f};
 	HIPCHK(hipMalloc((void **)&r.buf, sizeof(float) * 9 * (size_t)nl));
 	r.let = a.let; r.dist_partition = a.dist_partition && a.gpus <= 32;
-	if (!r.dist_partition) HIPCHK(hipMalloc((void **)&r.state_all, sizeof(float) * 6 * (size_t)N));
-	else
+	if (r.dist_partition)   // (the gathered form allocates its 24 N bytes on first use)
 	{
 		r.check(nbco_dist_repartition_workspace(r.ctx, N, a.gpus, &r.work_bytes), "nbco_dist_repartition_workspace");
 		HIPCHK(hipMalloc((void **)&r.work, (size_t)r.work_bytes));
@@ -263,29 +300,40 @@ int run_rank(const Args &a, int rank, const ncclUniqueId &id)
 	HIPCHK(hipMemcpy(r.par, parh, sizeof parh, hipMemcpyHostToDevice));
 
 	r.partition();
-	r.force(0);   // precompute accelerations (main3.cu:836-839)
+	r.force(0, true);   // precompute accelerations (main3.cu:836-839)
+	HIPCHK(hipDeviceSynchronize());
 	std::vector<float> slice(6 * (size_t)nl);
-	for (int iter = 0; iter < a.iters; ++iter)
+	int *flag = nullptr;
+	HIPCHK(hipMalloc((void **)&flag, sizeof(int)));
+	auto loop_t0 = std::chrono::steady_clock::now();
+	int loop_first = 0;
+	// snapshots follow the iterations 0, steps, 2 steps, ..: the iterations in between run as one leapfrog_steps call (main3.cu:840-870)
+	for (int iter = 0; iter < a.iters;)
 	{
-		r.leapfrog(a.dt, a.rebalance);
-		if (iter % a.steps != 0) continue;
+		const int run = iter % a.steps == 0 ? 1 : std::min(a.steps - iter % a.steps, a.iters - iter);
+		if (rank == a.fail_rank && a.fail_iter >= iter && a.fail_iter < iter + run)
+		{
+			std::cerr << "rank " << rank << ": NBCO3_DIST_FAIL requested a failure before iteration " << a.fail_iter << std::endl;
+			std::_Exit(9);
+		}
+		r.leapfrog_steps(a.dt, a.rebalance, run);
+		iter += run;
+		if ((iter - 1) % a.steps != 0) continue;
+		const int snap = iter - 1;
 		// every rank writes its rows of the one snapshot file (rank 0 creates it first; the barrier is a tiny all-reduce)
 		HIPCHK(hipDeviceSynchronize());
 		HIPCHK(hipMemcpy(slice.data(), r.buf, sizeof(float) * 6 * nl, hipMemcpyDeviceToHost));
-		const std::string name = a.out + "/out" + std::to_string(iter) + '_' + std::to_string(a.dt) + ".bin";
+		const std::string name = a.out + "/out" + std::to_string(snap) + '_' + std::to_string(a.dt) + ".bin";
 		if (rank == 0)
 		{
-			std::cout << iter << ' ' << std::flush;
+			std::cout << snap << ' ' << std::flush;
 			FILE *f = std::fopen(name.c_str(), "wb");
 			if (!f) { std::cerr << "Error: cannot write on output location. Check that \"" << a.out << "\" folder exists. Create it if not." << std::endl; return -1; }
 			std::fclose(f);
 		}
-		int *flag = nullptr;
-		HIPCHK(hipMalloc((void **)&flag, sizeof(int)));
 		HIPCHK(hipMemset(flag, 0, sizeof(int)));
 		NCCLCHK(ncclAllReduce(flag, flag, 1, ncclInt, ncclSum, r.comm, r.comm_stream));
 		HIPCHK(hipStreamSynchronize(r.comm_stream));
-		HIPCHK(hipFree(flag));
 		FILE *f = std::fopen(name.c_str(), "r+b");
 		if (!f) { std::cerr << "rank " << rank << ": cannot open " << name << std::endl; return -1; }
 		std::fseek(f, (long)(sizeof(float) * 3 * (size_t)rank * nl), SEEK_SET);
@@ -293,9 +341,21 @@ int run_rank(const Args &a, int rank, const ncclUniqueId &id)
 		std::fseek(f, (long)(sizeof(float) * 3 * ((size_t)N + (size_t)rank * nl)), SEEK_SET);
 		std::fwrite(slice.data() + 3 * (size_t)nl, sizeof(float), 3 * (size_t)nl, f);
 		std::fclose(f);
+		if (snap == 0) { loop_t0 = std::chrono::steady_clock::now(); loop_first = 1; }   // the timer below starts behind the first snapshot
 	}
 	HIPCHK(hipDeviceSynchronize());
-	if (rank == 0) std::cout << std::endl;
+	// all ranks have finished their loops when this all-reduce returns: rank 0's clock then covers the slowest rank
+	HIPCHK(hipMemset(flag, 0, sizeof(int)));
+	NCCLCHK(ncclAllReduce(flag, flag, 1, ncclInt, ncclSum, r.comm, r.comm_stream));
+	HIPCHK(hipStreamSynchronize(r.comm_stream));
+	HIPCHK(hipFree(flag));
+	if (rank == 0)
+	{
+		std::cout << std::endl;
+		// (not in the reference: wall time of the integration loop behind the first snapshot -- what bench.py's `cli_dist` leg reads)
+		std::cout << "Loop time: " << std::chrono::duration<double>(std::chrono::steady_clock::now() - loop_t0).count() << " s, " << a.iters - loop_first
+		          << " iterations, " << a.gpus << " ranks, partition fallbacks " << r.partition_fallbacks << std::endl;
+	}
 	nbco_destroy(r.ctx);
 	ncclCommDestroy(r.comm);
 	return 0;
@@ -320,6 +380,7 @@ int main(int argc, char **argv)
 		else if (f == "-i") a.dens = (float)atof(val());
 		else if (f == "-xi") a.xi = (float)atof(val());
 		else if (f == "-rebalance") a.rebalance = atoi(val());
+		else if (f == "-tree-steps") a.tree_steps = atoi(val());
 		else if (f == "-exchange") { const std::string v = val(); if (v != "let" && v != "gather") { std::cerr << "Error: -exchange let|gather\n"; return -1; } a.let = v == "let"; }
 		else if (f == "-partition") { const std::string v = val(); if (v != "dist" && v != "gather") { std::cerr << "Error: -partition dist|gather\n"; return -1; } a.dist_partition = v == "dist"; }
 		else if (f == "-o") a.out = val();
@@ -333,41 +394,81 @@ int main(int argc, char **argv)
 		}
 		else { std::cerr << "Error: unrecognised option '" << argv[i] << "'\n"; return -1; }
 	}
-	if (a.gpus < 1 || (a.gpus & (a.gpus - 1)) || a.n <= 0 || a.n % a.gpus || a.steps <= 0 || a.iters <= 0)
+	if (const char *e = getenv("NBCO3_DIST_HANG")) a.hang_rank = atoi(e);
+	if (const char *e = getenv("NBCO3_DIST_FAIL")) { if (sscanf(e, "%d:%d", &a.fail_rank, &a.fail_iter) != 2) a.fail_rank = -1; }
+	if (a.gpus < 1 || (a.gpus & (a.gpus - 1)) || a.n <= 0 || a.n % a.gpus || a.steps <= 0 || a.iters <= 0 || a.tree_steps < 1)
 	{
 		std::cerr << "Error: -gpus must be a power of two dividing -n\n";
 		return -1;
 	}
-	// the ranks are forked before this process makes any HIP / RCCL call; rank 0 creates the id and passes it down the pipes
-	std::vector<int> to_child(a.gpus, -1);
-	std::vector<pid_t> kids;
-	int my_rank = 0, from_parent = -1;
+	// The supervisor forks ALL ranks before any HIP / RCCL call is made anywhere and makes none itself.  Rank 0 creates the
+	// ncclUniqueId and writes it into one pipe per sibling (the pipes are created first, so every child inherits them).
+	std::vector<int> rd(a.gpus, -1), wr(a.gpus, -1);
 	for (int r = 1; r < a.gpus; ++r)
 	{
 		int fd[2];
 		if (pipe(fd) != 0) { perror("pipe"); return -1; }
-		const pid_t pid = fork();
-		if (pid < 0) { perror("fork"); return -1; }
-		if (pid == 0) { my_rank = r; from_parent = fd[0]; close(fd[1]); kids.clear(); break; }
-		close(fd[0]);
-		to_child[r] = fd[1];
-		kids.push_back(pid);
+		rd[r] = fd[0]; wr[r] = fd[1];
 	}
-	ncclUniqueId id;
-	if (my_rank == 0)
+	std::vector<pid_t> kids(a.gpus, (pid_t)-1);
+	auto kill_all = [&](int sig) { for (pid_t k : kids) if (k > 0) kill(k, sig); };
+	for (int r = 0; r < a.gpus; ++r)
 	{
-		NCCLCHK(ncclGetUniqueId(&id));
-		for (int r = 1; r < a.gpus; ++r)
-			if (write(to_child[r], &id, sizeof id) != (ssize_t)sizeof id) { perror("write"); return -1; }
-	}
-	else if (read(from_parent, &id, sizeof id) != (ssize_t)sizeof id) { perror("read"); return -1; }
-	int rc = run_rank(a, my_rank, id);
-	if (my_rank == 0)
-		for (pid_t k : kids)
+		const pid_t pid = fork();
+		if (pid < 0) { perror("fork"); kill_all(SIGKILL); return -1; }
+		if (pid == 0)
 		{
-			int st = 0;
-			waitpid(k, &st, 0);
-			if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = rc ? rc : -1;
+			if (r == a.hang_rank) for (;;) pause();   // test hook: a rank that never comes back (as one blocked in a collective)
+			ncclUniqueId id;
+			if (r == 0)
+			{
+				for (int q = 1; q < a.gpus; ++q) close(rd[q]);
+				NCCLCHK(ncclGetUniqueId(&id));
+				for (int q = 1; q < a.gpus; ++q)
+				{
+					if (write(wr[q], &id, sizeof id) != (ssize_t)sizeof id) { perror("write"); std::_Exit(5); }
+					close(wr[q]);
+				}
+			}
+			else
+			{
+				for (int q = 1; q < a.gpus; ++q) { close(wr[q]); if (q != r) close(rd[q]); }
+				if (read(rd[r], &id, sizeof id) != (ssize_t)sizeof id) { std::cerr << "rank " << r << ": no RCCL id from rank 0" << std::endl; std::_Exit(5); }
+				close(rd[r]);
+			}
+			const int rc = run_rank(a, r, id);
+			std::cout << std::flush;
+			std::_Exit(rc == 0 ? 0 : 1);
 		}
+		kids[r] = pid;
+	}
+	for (int r = 1; r < a.gpus; ++r) { close(rd[r]); close(wr[r]); }
+	// supervise: the first rank that fails (non-zero status or a signal) ends the run -- the others would wait in a collective
+	// for ever.  They are told to stop (SIGTERM), given two seconds, and then killed; each by its PID.
+	int alive = a.gpus, rc = 0;
+	while (alive > 0)
+	{
+		int st = 0;
+		const pid_t pid = waitpid(-1, &st, 0);
+		if (pid < 0) { if (errno == EINTR) continue; break; }
+		int rank = -1;
+		for (int r = 0; r < a.gpus; ++r) if (kids[r] == pid) rank = r;
+		if (rank < 0) continue;
+		kids[rank] = -1;
+		--alive;
+		const bool ok = WIFEXITED(st) && WEXITSTATUS(st) == 0;
+		if (ok || rc != 0) continue;
+		rc = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + WTERMSIG(st);
+		std::cerr << "nbco3_dist: rank " << rank << (WIFEXITED(st) ? " exited with status " : " was killed by signal ") << (WIFEXITED(st) ? WEXITSTATUS(st) : WTERMSIG(st))
+		          << "; stopping the other " << alive << " rank(s)" << std::endl;
+		kill_all(SIGTERM);
+		for (int waited = 0; waited < 20 && alive > 0; ++waited)
+		{
+			usleep(100000);
+			for (int r = 0; r < a.gpus; ++r)
+				if (kids[r] > 0 && waitpid(kids[r], &st, WNOHANG) == kids[r]) { kids[r] = -1; --alive; }
+		}
+		kill_all(SIGKILL);
+	}
 	return rc;
 }

@@ -206,6 +206,51 @@ def test_dist_host_argument_errors(nbco3):
         assert run(tool, *args).returncode != 0, args
 
 
+def test_dist_host_supervisor_stops_the_other_ranks_when_one_fails(nbco3, tmp_path):
+    """The launcher is a supervisor, not a rank: when a rank exits with a failure, the ranks that would otherwise wait in their
+    next collective for ever are killed and the exit status is non-zero.  Here (no GPU needed): rank 1 never comes back
+    (NBCO3_DIST_HANG), rank 0 fails on its own -- without a GPU at its first HIP / RCCL call, with ONE GPU because two were asked
+    for -- and the command must return promptly with a failure instead of hanging."""
+    import time
+    tool = os.path.join(HOST, "nbco3_dist")
+    t0 = time.time()
+    r = subprocess.run([tool, "-gpus", "2", "-n", "8192", "-iters", "2", "-o", str(tmp_path)], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, NBCO3_DIST_HANG="1"))
+    assert r.returncode != 0
+    assert "stopping the other 1 rank(s)" in r.stderr, r.stderr[-1000:]
+    assert time.time() - t0 < 60
+
+
+@pytest.mark.gpu
+def test_dist_host_failing_rank_gives_a_failing_exit_status(nbco3, tmp_path):
+    """a rank that dies in the middle of the loop (test hook: status 9 before iteration 2) -> the launcher reports it"""
+    tool = os.path.join(HOST, "nbco3_dist")
+    r = subprocess.run([tool, "-gpus", "1", "-n", "8192", "-p", "3", "-iters", "4", "-steps", "4", "-o", str(tmp_path)], capture_output=True, text=True,
+                       timeout=300, env=dict(os.environ, NBCO3_DIST_FAIL="0:2"))
+    assert r.returncode == 9, (r.returncode, r.stderr[-1000:])
+    assert "rank 0 exited with status 9" in r.stderr
+
+
+@pytest.mark.gpu
+def test_dist_host_falls_back_to_the_gathered_partition_on_pivot_ties(nbco3, tmp_path):
+    """Positions on a lattice: far more than 64 particles tie with every pivot, which the distributed re-partition reports as
+    NBCO_ERR_UNSUPPORTED.  The host switches to nbco_dist_partition for the rest of the run instead of exiting, and the run equals
+    one started with -partition gather bit for bit.  -tree-steps is exercised on the way."""
+    tool = os.path.join(HOST, "nbco3_dist")
+    env = dict(os.environ, NBCO3_DIST_QUANTISE="2e-4")
+    snaps = []
+    for mode in (("-partition", "dist"), ("-partition", "gather")):
+        out = tmp_path / mode[1]
+        out.mkdir()
+        r = subprocess.run([tool, "-gpus", "1", "-n", "16384", "-p", "3", "-iters", "5", "-steps", "5", "-rebalance", "2", "-tree-steps", "2", "-o", str(out), *mode],
+                           capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert ("partition fallbacks 1" if mode[1] == "dist" else "partition fallbacks 0") in r.stdout, r.stdout[-300:]
+        snaps.append(np.fromfile(out / "out5_0.000500.bin", dtype=np.float32))
+    assert np.isfinite(snaps[0]).all()
+    np.testing.assert_array_equal(snaps[0], snaps[1])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", [(), ("-exchange", "gather", "-partition", "gather"), ("-exchange", "let", "-partition", "gather")])
 def test_dist_host_one_rank_over_rccl(nbco3, engine, oracle32, tmp_path, mode):
