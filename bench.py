@@ -61,6 +61,16 @@ def parse(argv=None):
     ap.add_argument("--step-calls", action="store_true", help="one nbco_integrate call per step instead of one nbco_integrate_steps call for the timed region")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the tree-reuse, strong-scaling, octree and nbco3 CLI legs after the timed region")
     ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed region (warm-up + K steps between two barriers) is run this many times from the same initial state; "
+                         "value / ms_per_step are the median, every repeat is listed")
+    ap.add_argument("--dump-state", metavar="PREFIX", default=None,
+                    help="tests: every rank writes its [pos | vel | acc] rows after the last timed step to PREFIX.rank<r>.npy")
+    ap.add_argument("--strict", action="store_true",
+                    help="exit with status 3 (after printing the line) when the run fell back from the distributed re-partition or the LET "
+                         "exchange to their all-gather forms (`fallbacks` in the output says so either way)")
+    ap.add_argument("--late-from", type=int, default=1000,
+                    help="extra leg `late_phase`: the same K steps timed again after this many steps of the simulation (0 = skip)")
     ap.add_argument("--profile-all", action="store_true", help="record HIP events around every phase (perturbs value)")
     ap.add_argument("--engine-opt", action="append", default=[], metavar="KEY=VALUE",
                     help="diagnostics: an nbco_opts field for the engine, e.g. p2p_mutual=0 (one-directional near-field kernel) or m2l_first=1")
@@ -265,10 +275,11 @@ def cpu_baseline(args, n):
 
 
 def cli_leg(n, order, iters):
-    """Throughput of the drop-in binary itself over the same stretch of the simulation the library legs time: `nbco3 -n N -p P
-    -iters K` prints the wall time of its integration loop (device-synchronised at both ends, the one snapshot at iteration 0
-    included).  (The cost of a step grows as the ball evolves -- 0.5 ms per step over the first 200 steps, 2.8 ms around
-    step 2000, where the cloud has focused -- so runs of different length must not be differenced.)"""
+    """Throughput of the drop-in binary itself: `nbco3 -n N -p P -iters K` prints the wall time of its integration loop behind the
+    first snapshot and, separately, from iteration 9 on (`Steady loop time`: behind the cold builds of a fresh process) -- the
+    figure to hold against `tree_reuse`, which times the library in its stride with the same options (tree_steps 8, m2l_first).
+    (The cost of a step grows as the ball evolves -- 0.5 ms per step over the first 200 steps, 2.8 ms around step 2000, where the
+    cloud has focused -- so runs of different length must not be differenced.)"""
     import re
     import tempfile
     exe = os.path.join(ROOT, "coulomb_oscillators_amd", "host", "nbco3")
@@ -283,8 +294,35 @@ def cli_leg(n, order, iters):
     if not m:
         return {"error": "no loop time in the output"}
     per_iter = float(m.group(1)) / int(m.group(2))
-    return {"command": "nbco3 -n %d -p %d -iters %d -steps 100000 (tree_steps 8, m2l_first: the reference GPU driver's defaults)" % (n, order, iters),
-            "loop_s": float(m.group(1)), "ms_per_step": 1e3 * per_iter, "cli_particle_steps_per_s": n / per_iter}
+    out = {"command": "nbco3 -n %d -p %d -iters %d -steps 100000 (tree_steps 8, m2l_first: the reference GPU driver's defaults)" % (n, order, iters),
+           "loop_s": float(m.group(1)), "ms_per_step": 1e3 * per_iter, "cli_particle_steps_per_s": n / per_iter}
+    m = re.search(r"Steady loop time: ([0-9.eE+-]+) s, (\d+) iterations", r.stdout)
+    if m:
+        out["steady_ms_per_step"] = 1e3 * float(m.group(1)) / int(m.group(2))
+        out["steady_iterations"] = int(m.group(2))
+    return out
+
+
+def cli_dist_leg(gpus, n_system, order, iters, tree_steps, rebalance):
+    """The C++ multi-GPU host (one process per GPU over RCCL directly, host/nbco3_dist.cpp) on the same system: its own loop time
+    next to the Python-orchestrated number.  Runs while this benchmark's ranks sit idle."""
+    import re
+    import tempfile
+    exe = os.path.join(ROOT, "coulomb_oscillators_amd", "host", "nbco3_dist")
+    if not os.path.exists(exe):
+        return None
+    with tempfile.TemporaryDirectory() as tmp:
+        cmd = [exe, "-gpus", str(gpus), "-n", str(n_system), "-p", str(order), "-iters", str(iters), "-steps", "100000", "-tree-steps", str(tree_steps),
+               "-rebalance", str(rebalance), "-o", tmp]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    if r.returncode != 0:
+        return {"error": (r.stderr or r.stdout)[-300:], "status": r.returncode}
+    m = re.search(r"Loop time: ([0-9.eE+-]+) s, (\d+) iterations, (\d+) ranks, partition fallbacks (\d+)", r.stdout)
+    if not m:
+        return {"error": "no loop time in the output"}
+    per_iter = float(m.group(1)) / int(m.group(2))
+    return {"command": " ".join(["nbco3_dist"] + cmd[1:-2]), "loop_s": float(m.group(1)), "iterations": int(m.group(2)), "ranks": int(m.group(3)),
+            "partition_fallbacks": int(m.group(4)), "ms_per_step": 1e3 * per_iter, "value": n_system / per_iter, "unit": "particle-steps/s"}
 
 
 def main():
@@ -343,13 +381,17 @@ def main():
         dist.all_reduce(t, op=op)
         return float(t.item())
 
-    def timed_run(n_local, steps, warmup, profile):
-        """warm-up, then `steps` leapfrog steps between two barriers; (elapsed max over ranks, engine, run, state, profile)"""
+    fallbacks = []     # every switch from a default form to its all-gather form, with the reason (empty = the defaults ran)
+
+    def timed_run(n_local, steps, warmup, profile, repeats=1):
+        """`repeats` times from the same initial state: accelerations, warm-up, then `steps` leapfrog steps between two barriers.
+        Returns (elapsed of every repeat, max over ranks; engine, run, run_steps, profile, particles of the system)"""
         n_sys = world * n_local if sharded else n_local      # particles of ONE physical system
         # every rank draws n_local particles of the same Gaussian ball from its own stream; sharded run: their union is the
         # N = world * n_local system, the kd-domains are cut by the first partition
         buf = gaussian_ball(n_local, 0 if slabbed else rank)
-        d = torch.from_numpy(buf).cuda()
+        d0 = torch.from_numpy(buf).cuda()
+        d = d0.clone()
         prm = torch.from_numpy(coulomb_params(n_sys)).cuda()
         extra_opts = {}
         for kv in args.engine_opt:
@@ -361,79 +403,107 @@ def main():
         if sharded:
             run = DomainRun(eng, n_sys, TorchComm(always_collective=args.sharded_one), rebalance=args.rebalance, let=not args.no_let,
                             gather_partition=args.gather_partition or None)
-            # The re-partition without gathering the state and the LET exchange are the two stages no single-card rehearsal can run
-            # over RCCL: should one fail on every rank alike, agree on that and carry on with its all-gather form (said in `config`)
-            ok = 1
-            try:
-                run.partition(d[0].reshape(-1), d[1].reshape(-1))
-            except Exception as e:   # noqa: BLE001
-                if not run.dpart:
-                    raise
-                print("rank %d: distributed re-partition failed (%s)" % (rank, e), file=sys.stderr)
-                ok = 0
-            if run.dpart and reduce(float(ok), dist.ReduceOp.MIN) < 1:
-                run.use_gather_partition()
-                run.partition(d[0].reshape(-1), d[1].reshape(-1))
-            # precompute accelerations (main3.cu:836-839)
-            ok = 1
-            try:
+        elif slabbed:
+            run = SlabRun(eng, n_local, TorchComm())
+
+        def note(what):
+            if what not in fallbacks:
+                fallbacks.append(what)
+
+        def start():
+            """state := the initial state; accelerations (main3.cu:836-839)"""
+            d.copy_(d0)
+            if sharded:
+                # The re-partition without gathering the state and the LET exchange are the two stages no single-card rehearsal can
+                # run over RCCL between several cards: should one fail on every rank alike, the run agrees on that, carries on with
+                # its all-gather form and SAYS SO (`fallbacks`; --strict turns it into a failing exit status).  Pivot ties beyond the
+                # distributed select are handled inside DomainRun.partition and counted there.
+                ok, why = 1, ""
+                before = run.partition_fallbacks
+                try:
+                    run.partition(d[0].reshape(-1), d[1].reshape(-1))
+                except Exception as e:   # noqa: BLE001
+                    if not run.dpart:
+                        raise
+                    print("rank %d: distributed re-partition failed (%s)" % (rank, e), file=sys.stderr)
+                    ok, why = 0, str(e)[:160]
+                if run.dpart and reduce(float(ok), dist.ReduceOp.MIN) < 1:
+                    note("partition: distributed selection failed, all-gather of the state instead (%s)" % (why or "on another rank"))
+                    run.use_gather_partition()
+                    run.partition(d[0].reshape(-1), d[1].reshape(-1))
+                if run.partition_fallbacks > before:
+                    note("partition: more pivot ties than the distributed selection resolves, all-gather of the state instead")
+                ok, why = 1, ""
+                try:
+                    run.force(prm)
+                    if run.let:
+                        eng.dist_let_check()
+                except Exception as e:   # noqa: BLE001
+                    if not run.let:
+                        raise
+                    print("rank %d: LET exchange failed (%s)" % (rank, e), file=sys.stderr)
+                    ok, why = 0, str(e)[:160]
+                if run.let and reduce(float(ok), dist.ReduceOp.MIN) < 1:
+                    note("exchange: LET exchange failed, all-gather of whole node and position blocks instead (%s)" % (why or "on another rank"))
+                    run.let = False
+                    run.last_exchange_bytes = None
+                    run.partition(d[0].reshape(-1), d[1].reshape(-1))
+                    run.force(prm)
+            elif slabbed:
+                run.set_state(d[0], d[1])
                 run.force(prm)
-                if run.let:
-                    eng.dist_let_check()
-            except Exception as e:   # noqa: BLE001
-                if not run.let:
-                    raise
-                print("rank %d: LET exchange failed (%s)" % (rank, e), file=sys.stderr)
-                ok = 0
-            if run.let and reduce(float(ok), dist.ReduceOp.MIN) < 1:
-                run.let = False
-                run.last_exchange_bytes = None
-                run.partition(d[0].reshape(-1), d[1].reshape(-1))
-                run.force(prm)
+            else:
+                eng.compute_force(kind, d, n_local, prm)
+
+        if sharded:
             step = lambda: run.leapfrog(prm, args.dt)
             # K steps with ONE pass between two force evaluations (nbco_dist_turnaround), as the single-GPU path does
             run_steps = (lambda k: run.leapfrog_steps(prm, args.dt, k)) if not args.step_calls else (lambda k: [step() for _ in range(k)])
         elif slabbed:
-            run = SlabRun(eng, n_local, TorchComm())
-            run.set_state(d[0], d[1])
-            run.force(prm)
             step = lambda: run.leapfrog(prm, args.dt)
 
             def run_steps(k):
                 for _ in range(k):
                     step()
         else:
-            eng.compute_force(kind, d, n_local, prm)
             step = lambda: eng.integrate(INTEG_LEAPFROG, kind, d, n_local, prm, args.dt)
             # K steps = one nbco_integrate_steps call (the reference's loop between two snapshots, main3.cu:840-870): same final
             # state as K calls of nbco_integrate, bit for bit (tests/test_gpu_integrate_steps.py)
             run_steps = (lambda k: eng.integrate_steps(INTEG_LEAPFROG, kind, d, n_local, prm, args.dt, k)) if not args.step_calls else \
                 (lambda k: [step() for _ in range(k)])
-        run_steps(warmup)
-        if profile:
-            eng.profile(True if args.profile_all else [dom])
-            eng.profile_reset()
-        barrier()
-        t0 = time.perf_counter()
-        if os.environ.get("NBCO_BENCH_PYPROFILE") and rank == int(os.environ["NBCO_BENCH_PYPROFILE"]) - 1:   # 1 = rank 0, 2 = rank 1, ..
-            # diagnostics: where the host spends the timed steps (python side of a sharded run), top of the cumulative list to stderr
-            import cProfile, pstats
-            pr = cProfile.Profile()
-            pr.enable()
-            run_steps(steps)
-            pr.disable()
-            pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(30)
-        else:
-            run_steps(steps)
-        barrier()
-        elapsed = reduce(time.perf_counter() - t0, dist.ReduceOp.MAX)
+        times = []
+        for rep in range(max(1, repeats)):
+            start()
+            run_steps(warmup)
+            if profile:      # HIP events around the near-field launches of the timed steps only (all repeats accumulate)
+                eng.profile(True if args.profile_all else [dom])
+                if rep == 0:
+                    eng.profile_reset()
+            barrier()
+            t0 = time.perf_counter()
+            if rep == 0 and os.environ.get("NBCO_BENCH_PYPROFILE") and rank == int(os.environ["NBCO_BENCH_PYPROFILE"]) - 1:   # 1 = rank 0, 2 = rank 1, ..
+                # diagnostics: where the host spends the timed steps (python side of a sharded run), top of the cumulative list to stderr
+                import cProfile, pstats
+                pr = cProfile.Profile()
+                pr.enable()
+                run_steps(steps)
+                pr.disable()
+                pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(30)
+            else:
+                run_steps(steps)
+            barrier()
+            times.append(reduce(time.perf_counter() - t0, dist.ReduceOp.MAX))
+            if profile:
+                eng.profile(False)
         prof = eng.profile_get() if profile else None
-        eng.profile(False)
         state = run.buf if (sharded or slabbed) else d
         assert torch.isfinite(state).all(), "non-finite state after the timed steps"
-        return elapsed, eng, run, run_steps, prof, n_sys
+        if args.dump_state and profile:
+            np.save("%s.rank%d.npy" % (args.dump_state, rank), state.detach().cpu().numpy().reshape(3, -1, 3))
+        return times, eng, run, run_steps, prof, n_sys
 
-    elapsed, eng, run, run_steps, prof, n_sys = timed_run(n, args.steps, args.warmup, True)
+    times, eng, run, run_steps, prof, n_sys = timed_run(n, args.steps, args.warmup, True, args.repeats)
+    elapsed = sorted(times)[len(times) // 2]       # the median repeat is the value
 
     if args.workload == "fmm_kd":
         info = eng.kd_info()
@@ -469,7 +539,7 @@ def main():
     # headline value above rebuilds every step (CPU-driver semantics), this is the amortised figure beside it
     reuse = None
     if legs and world == 1 and args.workload == "fmm_kd" and args.tree_steps == 1:
-        eng.set(tree_steps=8)
+        eng.set(tree_steps=8, m2l_first=1)       # exactly what `nbco3` runs with (host/nbco3.cpp; the `cli` leg below)
         run_steps(8)
         barrier()
         t1 = time.perf_counter()
@@ -478,9 +548,9 @@ def main():
         barrier()
         e8 = time.perf_counter() - t1
         i8 = eng.kd_info()
-        reuse = {"tree_steps": 8, "steps": k8, "ms_per_step": 1e3 * e8 / k8, "value": n * k8 / e8, "unit": "particle-steps/s",
+        reuse = {"tree_steps": 8, "m2l_first": 1, "steps": k8, "ms_per_step": 1e3 * e8 / k8, "value": n * k8 / e8, "unit": "particle-steps/s",
                  "warm_builds": int(i8.warm_builds), "warm_misses": int(i8.warm_misses)}
-        eng.set(tree_steps=1)
+        eng.set(tree_steps=1, m2l_first=0)
 
     # the same steps with the mutual (Newton III) near-field kernel, opts.p2p_mutual: its pair kernel runs at a higher fraction of
     # the fp32 peak, the step as a whole is slower (reaction records: written, linked, summed) -- which is why it is not the default
@@ -505,12 +575,34 @@ def main():
                       "frac": pairs_m * FLOP_PER_PAIR / avg_m / 1e12 / FP32_VECTOR_PEAK_TFLOPS}
         eng.set(p2p_mutual=0)
 
+    # The headline times the first steps of a simulation whose lists grow as it evolves (the ball focuses, a few ejected particles
+    # stretch the outer leaves): the same K steps, rebuilt every step, timed again `--late-from` steps in.  The stretch in between
+    # runs with the reference GPU driver's tree_steps = 8 (cheaper, same physics to its accuracy).
+    late = None
+    if legs and world == 1 and args.workload == "fmm_kd" and args.late_from > 0:
+        done = args.warmup + args.steps + (8 + max(8, (args.steps // 8) * 8) if reuse else 0) + ((max(2, args.warmup) + args.steps) if mutual else 0)
+        todo = max(0, args.late_from - done)
+        eng.set(tree_steps=8)
+        run_steps(todo - todo % 8)
+        eng.set(tree_steps=args.tree_steps)
+        run_steps(todo % 8 + 2)
+        barrier()
+        tl = time.perf_counter()
+        run_steps(args.steps)
+        barrier()
+        el = time.perf_counter() - tl
+        il = eng.kd_info()
+        late = {"steps_from": done + todo + 2, "steps": args.steps, "tree_steps": args.tree_steps, "ms_per_step": 1e3 * el / args.steps,
+                "value": n * args.steps / el, "unit": "particle-steps/s", "directed_pairs_per_eval": int(il.directed_p2p), "p2p_pairs": int(il.p2p_pairs),
+                "warm_builds": int(il.warm_builds), "warm_misses": int(il.warm_misses)}
+
     # the metric reads "N = 1M ... at 1/2/4/8 GPUs": ONE system of --particles cut into `world` kd-domains (strong scaling),
     # next to the headline value, which keeps --particles per GPU (weak scaling)
     strong = None
     if legs and sharded and n % world == 0 and n // world >= 4096:
         eng.close()
-        e_s, eng_s, run_s, _, _, nsys_s = timed_run(n // world, args.steps, args.warmup, False)
+        t_s, eng_s, run_s, _, _, nsys_s = timed_run(n // world, args.steps, args.warmup, False)
+        e_s = t_s[0]
         strong = {"scaling": "strong", "n_system": nsys_s, "n_per_gpu": n // world, "ms_per_step": 1e3 * e_s / args.steps,
                   "value": nsys_s * args.steps / e_s, "unit": "particle-steps/s",
                   "exchange_bytes_per_eval_per_gpu": run_s.exchange_bytes(), "allgather_bytes_per_eval_per_gpu": run_s.allgather_bytes()}
@@ -535,20 +627,33 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
+        "repeats": {"n": len(times), "what": "warm-up + K steps between two barriers, each repeat from the same initial state; value = the median repeat",
+                    "ms_per_step": [1e3 * t / args.steps for t in times],
+                    "spread": (max(times) - min(times)) / elapsed if len(times) > 1 else None},
         "higher_is_better": True,
         "scaling": "strong" if slabbed else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "gpair_per_s": pairs_all * args.steps / elapsed / 1e9,
+        "fallbacks": fallbacks,
+        "rccl_ranks": (dist.get_world_size() if (dist.is_initialized() and args.backend == "nccl") else None),
         "tree_reuse": reuse,
         "near_field_mutual": mutual,
+        "late_phase": late,
         "strong": strong,
         "config": {"workload": wl, "n_per_gpu": n, "order": args.order, "dt": args.dt,
                    "init": "reference stream mt19937_64(%d + rank), discard %d (main3.cu:662-664)" % (REF_SEED, REF_DISCARD),
                    "parallelism": ("kd-domain sharding x%d, %s per evaluation" % (world, "LET exchange (all-gather of traversal records, all-to-all of the listed multipoles + positions)" if run.let else "one all-gather of nodes + positions")) if sharded
                    else ("single GPU" if world == 1 else "independent replicas x%d" % world), **extra},
     }
+    # the near-field launch of every rank: (average duration, directed pairs) -> min / max fraction of the peak over the ranks
+    rank_fracs = None
+    if world > 1 and pairs_per_eval and prof[dom][1]:
+        mine = torch.tensor([prof[dom][0] * 1e-3 / prof[dom][1], float(pairs_per_eval)], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rank_fracs = [float(t[1]) * FLOP_PER_PAIR / float(t[0]) / 1e12 / FP32_VECTOR_PEAK_TFLOPS for t in allr]
     if rank == 0:
         ms, launches = prof[dom]
         if launches and pairs_per_eval:
@@ -565,7 +670,9 @@ def main():
                                "frac_of_measured_ceiling": (ach / FP32_VECTOR_PEAK_TFLOPS / ceil_frac) if ceil_frac else None,
                                "measured_ceiling_frac": ceil_frac, "measured_ceilings": ceil, "measured_ceiling_source": ceil_src,
                                "traffic": traffic, "traffic_unit": "B/launch", "traffic_source": src,
-                               "pairs_per_launch": pairs_per_eval, "avg_launch_ms": avg_s * 1e3, "flop_per_pair": FLOP_PER_PAIR}
+                               "pairs_per_launch": pairs_per_eval, "avg_launch_ms": avg_s * 1e3, "flop_per_pair": FLOP_PER_PAIR,
+                               "launches_averaged": int(launches), "rank": 0,
+                               "frac_over_ranks": {"min": min(rank_fracs), "max": max(rank_fracs), "all": rank_fracs} if rank_fracs else None}
         if args.profile_all:
             out["phase_ms_per_step"] = {k: v[0] / args.steps for k, v in prof.items() if v[1]}
     # further single-GPU legs, outside the timed region (rank 0 of a one-GPU run only)
@@ -596,14 +703,25 @@ def main():
             out["cli"] = cli_leg(n, args.order, args.warmup + args.steps + 26)   # (about the stretch the legs above cover)
         except Exception as e:
             out["cli"] = {"error": str(e)[:200]}
+    if world > 1 or args.sharded_one:
+        barrier()
+        dist.destroy_process_group()       # the other ranks are done; what follows runs on rank 0 with the GPUs idle
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline and args.workload != "fmm_oct":
+        if legs and args.workload == "fmm_kd" and (sharded or world == 1):
+            # the C++ multi-GPU host on the same system (weak-scaling shape: world x --particles), same rebuild cadence
+            try:
+                eng.close()
+                out["cli_dist"] = cli_dist_leg(world, n_sys, args.order, args.warmup + args.steps, args.tree_steps, args.rebalance)
+            except Exception as e:
+                out["cli_dist"] = {"error": str(e)[:200]}
+        if not args.no_cpu_baseline and args.workload != "fmm_oct":
+            # (also on the N > 1 lines: rank 0's host, after the timed region; the per-GPU workload of --particles)
             out["cpu_baseline"] = cpu_baseline(args, n)
         sys.stdout.flush()
         os.dup2(json_fd, 1)
         print(json.dumps(out), flush=True)
-    if world > 1 or args.sharded_one:
-        dist.destroy_process_group()
+        if args.strict and fallbacks:
+            sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -536,6 +536,7 @@ int dpart_begin(nbco_ctx *c, float *state_local, long long n_global, int world, 
 	if (world > 32) return c->fail(NBCO_ERR_UNSUPPORTED, "nbco_dist_repartition: at most 32 domains (use nbco_dist_partition)");
 	nbco_ctx::DPart &s = c->dpart;
 	s = nbco_ctx::DPart{};
+	c->last_eval.valid = false;   // pos4 is this stage's scratch from here on: the last evaluation's lists no longer have their positions
 	s.world = world; s.rank = rank; s.d = lay.d; s.n_global = n_global; s.n_local = lay.n_local; s.state = state_local; s.work = work;
 	const long long nl = lay.n_local;
 	hipStream_t st = c->stream;

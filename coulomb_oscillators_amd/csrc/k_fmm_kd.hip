@@ -2513,6 +2513,7 @@ int kd_turnaround(nbco_ctx *c, float *p, const float *v_in, const float **v_now,
 	NBCO_HIP(hipGetLastError());
 	c->skip_prep = next_rebuild ? 1 : 2;
 	c->order_n = -1;
+	c->last_eval.valid = false;   // the particles have moved (and pos4 may hold the next build's input): nbco_energy_fmm must follow an evaluation
 	*v_now = v_out;
 	return NBCO_OK;
 }

@@ -116,6 +116,10 @@ struct Rank
 	// state has not been touched at that point.
 	bool repartition()
 	{
+		// test hook: with one rank no pivot is ever selected, so the library cannot be made to report ties; NBCO3_DIST_FAKE_TIES=1
+		// answers the first cut as the library would (the library's own report is covered by tests/test_gpu_dist.py, in lockstep)
+		static bool faked = false;
+		if (!faked && getenv("NBCO3_DIST_FAKE_TIES")) { faked = true; return false; }
 		nbco_dist_step st{};
 		check(nbco_dist_repartition_begin(ctx, buf, lay.n_global, world, rank, work, work_bytes, &st), "nbco_dist_repartition_begin");
 		while (st.op != NBCO_COLL_DONE)
@@ -184,7 +188,7 @@ struct Rank
 		{
 			if (repartition()) return;
 			// pivot ties beyond the distributed select, on every rank alike: from here on the gathered form, which takes any input
-			if (rank == 0) std::cerr << "nbco3_dist: " << nbco_last_error(ctx) << " -- switching to -partition gather" << std::endl;
+			if (rank == 0) std::cerr << "nbco3_dist: distributed re-partition not possible (" << nbco_last_error(ctx) << "): switching to -partition gather" << std::endl;
 			dist_partition = false;
 			++partition_fallbacks;
 		}

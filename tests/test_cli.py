@@ -233,11 +233,12 @@ def test_dist_host_failing_rank_gives_a_failing_exit_status(nbco3, tmp_path):
 
 @pytest.mark.gpu
 def test_dist_host_falls_back_to_the_gathered_partition_on_pivot_ties(nbco3, tmp_path):
-    """Positions on a lattice: far more than 64 particles tie with every pivot, which the distributed re-partition reports as
-    NBCO_ERR_UNSUPPORTED.  The host switches to nbco_dist_partition for the rest of the run instead of exiting, and the run equals
-    one started with -partition gather bit for bit.  -tree-steps is exercised on the way."""
+    """Positions on a lattice: with several ranks far more than 64 particles tie with every pivot, which the distributed
+    re-partition reports as NBCO_ERR_UNSUPPORTED (tests/test_gpu_dist.py checks that report, in lockstep).  One rank selects no
+    pivot, so here the report is injected (NBCO3_DIST_FAKE_TIES): the host switches to nbco_dist_partition for the rest of the run
+    instead of exiting, and the run equals one started with -partition gather bit for bit.  -tree-steps is exercised on the way."""
     tool = os.path.join(HOST, "nbco3_dist")
-    env = dict(os.environ, NBCO3_DIST_QUANTISE="2e-4")
+    env = dict(os.environ, NBCO3_DIST_QUANTISE="2e-4", NBCO3_DIST_FAKE_TIES="1")
     snaps = []
     for mode in (("-partition", "dist"), ("-partition", "gather")):
         out = tmp_path / mode[1]

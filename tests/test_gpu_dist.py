@@ -312,6 +312,38 @@ def test_distributed_repartition_orders_pivot_ties_like_the_sort_chain(oracle32)
         np.testing.assert_array_equal(_rows(ra.buf, nl), _rows(rb.buf, nl))
 
 
+def test_distributed_repartition_falls_back_to_the_gathered_form_on_heavy_ties(oracle32):
+    """Coordinates on a lattice: far more than 64 particles of every rank tie with each pivot, which nbco_dist_repartition_*
+    reports as NBCO_ERR_UNSUPPORTED -- on every rank alike, before the local state is touched.  The world switches to
+    nbco_dist_partition (which takes any input) instead of failing, cuts the same domains as a world that used the gathered
+    form from the start, and stays on it for later cuts (DomainRun.partition, which force() calls for the periodic rebalance,
+    takes the same path)."""
+    import torch
+    n, G = 32768, 4
+    pos, vel = make_state(oracle32, n, "uniform")
+    q = (pos.max(0) - pos.min(0)).max() / 24.0
+    pos = (np.round(pos / q) * q).astype(np.float32)       # ~25 distinct values per axis: thousands of ties per pivot
+    par = torch.from_numpy(oracle32.params(n)).cuda()
+    opts = dict(fmm_order=3, unsort=0, tree_steps=1)
+    a = loopback(n, G, pos, vel, gather_partition=True, **opts)
+    b = loopback(n, G, pos, vel, **opts)
+    assert all(r.partition_fallbacks == 1 and not r.dpart for r in b.runs)
+    assert all(r.partition_fallbacks == 0 for r in a.runs)
+    nl = n // G
+    for ra, rb in zip(a.runs, b.runs):
+        np.testing.assert_array_equal(_rows(ra.buf, nl), _rows(rb.buf, nl))
+    for w in (a, b):
+        w.force(par, elastic=False)
+        for r in w.runs:
+            r.eng.step(r.pos, r.vel, 0.05, nl)
+        w.partition([r.pos for r in w.runs], [r.vel for r in w.runs])      # a later cut: the gathered form, no second fallback
+        w.force(par, elastic=False)
+    torch.cuda.synchronize()
+    assert all(r.partition_fallbacks == 1 and not r.dpart for r in b.runs)
+    for ra, rb in zip(a.runs, b.runs):
+        assert torch.equal(ra.buf, rb.buf) and bool(torch.isfinite(rb.acc).all())
+
+
 def test_sharded_matches_oracle(oracle32):
     """end to end against the CPU oracle (1e-5 relative, the bar of the single-GPU path)"""
     import torch
@@ -579,3 +611,27 @@ def test_sharded_turnaround_equals_step_kernels(oracle32, tree_steps, recut):
         # (the fused pass does not write the accelerations of the steps in between: compare positions, velocities and the last ones)
         out.append(torch.cat([r.buf for r in w.runs]))
     assert torch.equal(out[0], out[1])
+
+
+def test_energy_after_a_turnaround_fails_loudly(oracle32):
+    """nbco_dist_turnaround (like the fused pass of nbco_integrate_steps) drifts the particles and may overwrite the tree-ordered
+    position copy with the next build's input: the interaction lists of the last evaluation no longer belong to any state the
+    caller can hand in, so nbco_energy_fmm must refuse instead of combining old lists with new positions.  The same holds once a
+    re-partition has begun (its first stage packs into the same buffer)."""
+    import torch
+    from coulomb_oscillators_amd import EngineError
+    n, G, dt = 32768, 2, 5e-4
+    pos, vel = make_state(oracle32, n, "reference")
+    par = torch.from_numpy(oracle32.params(n)).cuda()
+    w = loopback(n, G, pos, vel, fmm_order=4, unsort=0, tree_steps=1)
+    w.force(par, elastic=False, let=True)
+    r = w.runs[0]
+    assert np.isfinite(r.eng.energy_fmm(r.buf, r.n_local, par)).all()          # right behind an evaluation: fine
+    r.eng.dist_turnaround(r.buf, r.n_local, par, dt)
+    with pytest.raises(EngineError, match="no kd-tree evaluation"):
+        r.eng.energy_fmm(r.buf, r.n_local, par)
+    r1 = w.runs[1]
+    assert np.isfinite(r1.eng.energy_fmm(r1.buf, r1.n_local, par)).all()
+    r1.eng.dist_repartition_begin(r1.buf, n, G, 1, r1.work)
+    with pytest.raises(EngineError, match="no kd-tree evaluation"):
+        r1.eng.energy_fmm(r1.buf, r1.n_local, par)

@@ -121,3 +121,68 @@ def test_critical_path_kernels_use_no_scratch():
                         bad.append((name, scratch))
     assert found == set(NO_SCRATCH), "kernels not found in the library: %s" % sorted(set(NO_SCRATCH) - found)
     assert not bad, "critical-path kernels with a scratch segment (bytes per lane): %s" % bad
+
+
+# ---- particles are loaded whole ------------------------------------------------------------------------------------------------
+# for `axis_of(P[i], axis)` -- a float4 load followed by a three-way select -- hipcc 7.2 narrowed the load to ONE dword at
+# a SELECTED ADDRESS and left the address register unset on the axis == 2 path: a GPU memory fault that only inputs splitting
+# along z reached.  The kernels that pick a coordinate by a run-time axis therefore load the particle as a whole
+# (k_dpart.hip: load_particle) or take it from registers / LDS that hold whole vectors.  This rule reads the ISA of the built
+# library: in those kernels (a) the particle array is read with global_load_dwordx4 / dwordx3 (all three coordinates) and (b) no narrower global / flat load uses an
+# address register that a v_cndmask wrote just before it -- the shape of the miscompiled select.
+PARTICLE_KERNELS = ["dp_hist_kernel", "dp_ties_kernel", "dp_count_kernel", "dp_scatter_kernel", "sel_hist_kernel", "sel_hist_warm_kernel",
+                    "sel_partition_kernel", "kd_subtree_kernel"]
+
+
+def _disassemble(blob, base):
+    import struct
+    import subprocess
+    import tempfile
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        return None
+    shoff = struct.unpack_from("<Q", blob, base + 0x28)[0]
+    shentsize, shnum = struct.unpack_from("<HH", blob, base + 0x3A)
+    with tempfile.NamedTemporaryFile(suffix=".elf") as f:
+        f.write(blob[base:base + shoff + shentsize * shnum])
+        f.flush()
+        return subprocess.run([objdump, "-d", "--no-show-raw-insn", f.name], capture_output=True, text=True).stdout
+
+
+def test_run_time_axis_kernels_load_whole_particles():
+    import pytest
+    lib = os.path.join(ROOT, "coulomb_oscillators_amd", "libnbco_hip.so")
+    if not os.path.exists(lib):
+        pytest.skip("libnbco_hip.so is not built")
+    blob = open(lib, "rb").read()
+    narrow = re.compile(r"(?:global|flat)_load_(?:dword|dwordx2|ubyte|sbyte|ushort|sshort)\s+v\d+(?:\[[^\]]+\])?, (?:v\[(\d+):(\d+)\]|v(\d+))")
+    seen, wide, bad = set(), set(), []
+    for base in _device_elfs(blob):
+        text = _disassemble(blob, base)
+        if text is None:
+            pytest.skip("llvm-objdump not found")
+        kern, hist = None, []
+        for line in text.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
+            if m:
+                hits = [k for k in PARTICLE_KERNELS if k in m.group(1)]
+                kern, hist = (hits[0] if hits else None), []
+                if kern:
+                    seen.add(kern)
+                continue
+            ins = line.split("//")[0].strip()
+            if not kern or not ins:
+                continue
+            if ins.startswith("global_load_dwordx4") or ins.startswith("global_load_dwordx3"):   # x, y, z (the unused w may be dropped)
+                wide.add(kern)
+            m = narrow.match(ins)
+            if m:
+                regs = {int(m.group(1)), int(m.group(2))} if m.group(1) else {int(m.group(3))}
+                for h in hist[-12:]:
+                    c = re.match(r"v_cndmask_b32\S*\s+v(\d+),", h)
+                    if c and int(c.group(1)) in regs:
+                        bad.append((kern, ins, h))
+            hist.append(ins)
+    assert seen == set(PARTICLE_KERNELS), "kernels not found in the library: %s" % sorted(set(PARTICLE_KERNELS) - seen)
+    assert wide == seen, "kernels that never read a whole particle (global_load_dwordx3 / x4): %s" % sorted(seen - wide)
+    assert not bad, "narrow loads at a selected address (the shape of the DESIGN 9a miscompile): %s" % bad[:4]
