@@ -300,6 +300,26 @@ def cli_leg(n, order, iters):
     if m:
         out["steady_ms_per_step"] = 1e3 * float(m.group(1)) / int(m.group(2))
         out["steady_iterations"] = int(m.group(2))
+        # the library over the SAME stretch: a fresh context, the binary's options, the same initial state, iterations 9 .. K
+        try:
+            import torch
+            from coulomb_oscillators_amd import Engine, EVAL_FMM_KDTREE, INTEG_LEAPFROG
+            eng = Engine(fmm_order=order, unsort=0, tree_steps=8, m2l_first=1, sync=0)
+            d = torch.from_numpy(gaussian_ball(n)).cuda()
+            prm = torch.from_numpy(coulomb_params(n)).cuda()
+            eng.compute_force(EVAL_FMM_KDTREE, d, n, prm)
+            for k in (1, 8):
+                eng.integrate_steps(INTEG_LEAPFROG, EVAL_FMM_KDTREE, d, n, prm, 5e-4, k)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eng.integrate_steps(INTEG_LEAPFROG, EVAL_FMM_KDTREE, d, n, prm, 5e-4, int(m.group(2)))
+            torch.cuda.synchronize()
+            lib = 1e3 * (time.perf_counter() - t0) / int(m.group(2))
+            eng.close()
+            out["library_same_stretch_ms_per_step"] = lib
+            out["cli_over_library"] = out["steady_ms_per_step"] / lib
+        except Exception as e:   # noqa: BLE001
+            out["library_same_stretch_error"] = str(e)[:200]
     return out
 
 

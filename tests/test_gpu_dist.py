@@ -635,3 +635,29 @@ def test_energy_after_a_turnaround_fails_loudly(oracle32):
     r1.eng.dist_repartition_begin(r1.buf, n, G, 1, r1.work)
     with pytest.raises(EngineError, match="no kd-tree evaluation"):
         r1.eng.energy_fmm(r1.buf, r1.n_local, par)
+
+
+def test_distributed_repartition_at_8m_particles(oracle32):
+    """n_global = 2^23 (BASELINE config 4 is made of such sizes): the windows of the distributed median selection need their
+    THIRD histogram pass (11 + 11 + 10 bits) at a size where the first two leave thousands of keys -- the same particle sets as
+    the gathered selection (whose level-0 node, above 2^22 particles, takes the three-pass select of k_kdselect.hip)"""
+    import torch
+    n, G = 1 << 23, 2
+    pos, vel = make_state(oracle32, n, "uniform")
+    opts = dict(fmm_order=3, unsort=0, tree_steps=1)
+    a = loopback(n, G, pos, vel, gather_partition=True, **opts)
+    b = loopback(n, G, pos, vel, **opts)
+    assert all(r.dpart and r.partition_fallbacks == 0 for r in b.runs)
+    nl = n // G
+    for ra, rb in zip(a.runs, b.runs):
+        # (a 4M-row lexsort per domain would take most of the test's time: compare the sets through order-independent sums of the
+        # rows' bit patterns and, exactly, through the sorted split coordinate)
+        A, B = ra.buf[:6 * nl].view(torch.int32).to(torch.int64), rb.buf[:6 * nl].view(torch.int32).to(torch.int64)
+        assert int(A.sum()) == int(B.sum()) and int((A * A).sum()) == int((B * B).sum())
+        for ax in range(3):
+            assert torch.equal(torch.sort(ra.buf[ax:3 * nl:3]).values, torch.sort(rb.buf[ax:3 * nl:3]).values)
+    # the cut itself: everything of rank 0 lies on one side of everything of rank 1 along the root's split axis
+    lo, hi = b.runs[0].pos.view(nl, 3), b.runs[1].pos.view(nl, 3)
+    ax = int(torch.argmax(torch.from_numpy(pos.max(0) - pos.min(0))))
+    assert float(lo[:, ax].max()) <= float(hi[:, ax].min())
+    assert sum(r.partition_bytes for r in b.runs) < sum(r.partition_bytes for r in a.runs)

@@ -338,7 +338,7 @@ def test_baseline_config_2_by_name_properties(engine, oracle32):
     too long to be the checker: the sorted cell keys against the key formula itself (appel.cuh:44-55: row-major
     flatten of the clipped integer cell coordinates, fp32, no contraction) in numpy, bit for bit; the permutation is one and
     carries the state; every acceleration finite; and the accelerations of a sample of particles against an fp64 direct sum
-    over all 2^20 sources.  On this input (anisotropic ball in a cubic grid) the octree is an almost all-pairs run: 625 of
+    over all 2^20 sources.  On this input (anisotropic ball in a cubic grid) the octree is an almost all-pairs run: ~600 of
     32 768 leaf cells are occupied, so the far field carries little and the result is close to the direct sum."""
     import torch
     o = oracle32
@@ -365,7 +365,8 @@ def test_baseline_config_2_by_name_properties(engine, oracle32):
     np.testing.assert_array_equal(engine.oct_array("perm").astype(np.int64), order)
     np.testing.assert_array_equal(got_pv[0], pos[order])
     np.testing.assert_array_equal(got_pv[1], buf[1][order])
-    assert len(np.unique(keys)) == 625 and L == 5                       # the figure SURVEY quotes for this input
+    # (SURVEY's numpy estimate for a ball of this shape was 625 occupied cells of 32 768; the reference's own stream gives 588)
+    assert L == 5 and 400 < len(np.unique(keys)) < 800
     # sampled fp64 direct sum (the evaluator's convention: a_i = param[0] sum_j (x_i - x_j) / (|x_i - x_j|^2 + eps2)^(3/2))
     rng = np.random.default_rng(11)
     pick = rng.choice(n, 192, replace=False)
