@@ -20,27 +20,29 @@ __device__ inline float ld_agent(const float *p) { return __hip_atomic_load(p, _
 __device__ inline int ld_agent(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // ---- P2M: one thread per leaf ----------------------------------------------------------------------
-template <int P>
+// T = scalar type of the expansions and of the far-field arithmetic: float, or double with opts.far_fp64 (positions, centres and
+// the whole tree geometry stay fp32 in both: the differences are formed in T from the fp32 values)
+template <int P, typename T>
 __global__ __launch_bounds__(kBlock) void p2m_gen_kernel(const float4 *__restrict__ pos, const float *__restrict__ center,
-                                                         const int *__restrict__ mult, const int *__restrict__ index, float *__restrict__ mpole,
+                                                         const int *__restrict__ mult, const int *__restrict__ index, T *__restrict__ mpole,
                                                          int beg, int nleaf)
 {
 	constexpr int offM = P * (P + 1) * (P + 2) / 6;
 	const int i = blockIdx.x * kBlock + threadIdx.x;
 	if (i >= nleaf) return;
 	const int leaf = beg + i, mlt = mult[leaf], ind = index[leaf];
-	const float cx = center[3 * leaf], cy = center[3 * leaf + 1], cz = center[3 * leaf + 2];
-	float A[offM > 0 ? offM : 1];
+	const T cx = (T)center[3 * leaf], cy = (T)center[3 * leaf + 1], cz = (T)center[3 * leaf + 2];
+	T A[offM > 0 ? offM : 1];
 #pragma unroll
-	for (int k = 0; k < (offM > 0 ? offM : 1); ++k) A[k] = 0.f;
+	for (int k = 0; k < (offM > 0 ? offM : 1); ++k) A[k] = T(0);
 	for (int j = 0; j < mlt; ++j)
 	{
 		const float4 p = pos[ind + j];
-		p2m_accum<P>(p.x - cx, p.y - cy, p.z - cz, A);
+		p2m_accum<P>((T)p.x - cx, (T)p.y - cy, (T)p.z - cz, A);
 	}
-	float *M = mpole + (size_t)leaf * offM;
-	if (offM > 0) M[0] = (float)mlt;
-	if (offM > 1) { M[1] = 0.f; M[2] = 0.f; M[3] = 0.f; }
+	T *M = mpole + (size_t)leaf * offM;
+	if (offM > 0) M[0] = (T)mlt;
+	if (offM > 1) { M[1] = T(0); M[2] = T(0); M[3] = T(0); }
 	p2m_store<P>(A, M);
 }
 
@@ -162,26 +164,27 @@ __global__ __launch_bounds__(kBlock) void kd_centres_top_kernel(float *center, i
 // Levels ltop .. lroot of the subtrees hanging off level lroot, one workgroup per subtree (lroot = 0: the top of the tree in
 // one workgroup).  The expansions, centres and multiplicities of the level just built stay in LDS (node i of a subtree's
 // level sits in slot i), so a level costs LDS latency instead of a launch and HBM round trips.
-template <int P>
-__global__ __launch_bounds__(kTopNodes) void m2m_top_kernel(float *center, float *mpole, int *mult, int ltop, int lroot, int write_geom)
+template <int P, typename T>
+__global__ __launch_bounds__(kTopNodes) void m2m_top_kernel(float *center, T *mpole, int *mult, int ltop, int lroot, int write_geom)
 {
 	constexpr int offM = P * (P + 1) * (P + 2) / 6, offS = offM > 0 ? offM : 1;
-	extern __shared__ float lds[];
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	const int width = 1 << (ltop - lroot);            // nodes of this subtree at level ltop
-	float *Ml = lds;                                  // [width][offS]
-	float *Cl = Ml + (size_t)width * offS;            // [width][3]
+	T *Ml = reinterpret_cast<T *>(lds_raw);           // [width][offS]
+	float *Cl = reinterpret_cast<float *>(Ml + (size_t)width * offS);   // [width][3]
 	int *Nl = (int *)(Cl + (size_t)width * 3);        // [width]
 	const int t = threadIdx.x;
 	for (int l = ltop; l >= lroot; --l)
 	{
 		const bool on = t < (1 << (l - lroot));
 		const int k = (1 << l) - 1 + ((int)blockIdx.x << (l - lroot)) + t;
-		float A[offS], c[3] = {0.f, 0.f, 0.f};
+		T A[offS];
+		float c[3] = {0.f, 0.f, 0.f};
 		int mlt = 0;
 		if (on)
 		{
 #pragma unroll
-			for (int q = 0; q < offS; ++q) A[q] = 0.f;
+			for (int q = 0; q < offS; ++q) A[q] = T(0);
 			if (l == ltop)
 			{
 				// children are in HBM (written by the previous launch)
@@ -190,8 +193,8 @@ __global__ __launch_bounds__(kTopNodes) void m2m_top_kernel(float *center, float
 					for (int ch = 0; ch < 2; ++ch)
 					{
 						const int child = 2 * k + 1 + ch;
-						m2m_accum<P>(mpole + (size_t)child * offM, c[0] - center[3 * child], c[1] - center[3 * child + 1],
-						             c[2] - center[3 * child + 2], A);
+						m2m_accum<P>(mpole + (size_t)child * offM, (T)c[0] - (T)center[3 * child], (T)c[1] - (T)center[3 * child + 1],
+						             (T)c[2] - (T)center[3 * child + 2], A);
 					}
 			}
 			else
@@ -204,20 +207,20 @@ __global__ __launch_bounds__(kTopNodes) void m2m_top_kernel(float *center, float
 					for (int ch = 0; ch < 2; ++ch)
 					{
 						const int sl = 2 * t + ch;
-						m2m_accum<P>(Ml + (size_t)sl * offS, c[0] - Cl[3 * sl], c[1] - Cl[3 * sl + 1], c[2] - Cl[3 * sl + 2], A);
+						m2m_accum<P>(Ml + (size_t)sl * offS, (T)c[0] - (T)Cl[3 * sl], (T)c[1] - (T)Cl[3 * sl + 1], (T)c[2] - (T)Cl[3 * sl + 2], A);
 					}
 			}
 		}
 		__syncthreads();   // all reads of the child slots are done
 		if (on)
 		{
-			float *M = mpole + (size_t)k * offM;
-			float *Ms = Ml + (size_t)t * offS;
-			if (offM > 0) M[0] = (float)mlt;
-			if (offM > 1) { M[1] = 0.f; M[2] = 0.f; M[3] = 0.f; }
+			T *M = mpole + (size_t)k * offM;
+			T *Ms = Ml + (size_t)t * offS;
+			if (offM > 0) M[0] = (T)mlt;
+			if (offM > 1) { M[1] = T(0); M[2] = T(0); M[3] = T(0); }
 			m2m_store<P>(A, M);
-			if (offM > 0) Ms[0] = (float)mlt;
-			if (offM > 1) { Ms[1] = 0.f; Ms[2] = 0.f; Ms[3] = 0.f; }
+			if (offM > 0) Ms[0] = (T)mlt;
+			if (offM > 1) { Ms[1] = T(0); Ms[2] = T(0); Ms[3] = T(0); }
 			m2m_store<P>(A, Ms);
 			if (write_geom)
 			{
@@ -232,34 +235,35 @@ __global__ __launch_bounds__(kTopNodes) void m2m_top_kernel(float *center, float
 }
 
 // ---- L2L ---------------------------------------------------------------------------------------------
-template <int P, bool AGENT>
-__device__ inline void l2l_node(const float *center, float *local, int c)
+template <int P, typename T, bool AGENT>
+__device__ inline void l2l_node(const float *center, T *local, int c)
 {
 	constexpr int offL = (P + 1) * (P + 1);
 	const int p = (c - 1) >> 1;
-	float Lp[offL], O[offL];
+	T Lp[offL], O[offL];
 #pragma unroll
-	for (int q = 0; q < offL; ++q) Lp[q] = AGENT ? ld_agent(&local[(size_t)p * offL + q]) : local[(size_t)p * offL + q];
-	l2l_body<P>(Lp, center[3 * c] - center[3 * p], center[3 * c + 1] - center[3 * p + 1], center[3 * c + 2] - center[3 * p + 2], O);
-	float *Lc = local + (size_t)c * offL;
+	for (int q = 0; q < offL; ++q) Lp[q] = local[(size_t)p * offL + q];
+	l2l_body<P>(Lp, (T)center[3 * c] - (T)center[3 * p], (T)center[3 * c + 1] - (T)center[3 * p + 1], (T)center[3 * c + 2] - (T)center[3 * p + 2], O);
+	T *Lc = local + (size_t)c * offL;
 #pragma unroll
 	for (int q = 1; q < offL; ++q) Lc[q] += O[q];
 }
 
-template <int P>
-__global__ __launch_bounds__(kBlock) void l2l_gen_kernel(const float *__restrict__ center, float *local, int lchild, int first, int count)
+template <int P, typename T>
+__global__ __launch_bounds__(kBlock) void l2l_gen_kernel(const float *__restrict__ center, T *local, int lchild, int first, int count)
 {
 	const int i = blockIdx.x * kBlock + threadIdx.x;
 	if (i >= count) return;
-	l2l_node<P, false>(center, local, (1 << lchild) - 1 + first + i);
+	l2l_node<P, T, false>(center, local, (1 << lchild) - 1 + first + i);
 }
 
 // child levels 2 .. ltop in one workgroup; the level just finished stays in LDS as the next level's parents
-template <int P>
-__global__ __launch_bounds__(kTopNodes) void l2l_top_kernel(const float *__restrict__ center, float *local, int ltop)
+template <int P, typename T>
+__global__ __launch_bounds__(kTopNodes) void l2l_top_kernel(const float *__restrict__ center, T *local, int ltop)
 {
 	constexpr int offL = (P + 1) * (P + 1);
-	extern __shared__ float lds[];   // [2^ltop][offL]
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+	T *lds = reinterpret_cast<T *>(lds_raw);   // [2^ltop][offL]
 	const int t = threadIdx.x;
 	// level-1 nodes are the first parents
 	if (t < 2)
@@ -269,23 +273,23 @@ __global__ __launch_bounds__(kTopNodes) void l2l_top_kernel(const float *__restr
 	{
 		const bool on = t < (1 << lc);
 		const int c = (1 << lc) - 1 + t, p = (c - 1) >> 1;
-		float O[offL];
+		T O[offL];
 		if (on)
 		{
-			float Lp[offL];
-			const float *src = lds + (size_t)(t >> 1) * offL;
+			T Lp[offL];
+			const T *src = lds + (size_t)(t >> 1) * offL;
 #pragma unroll
 			for (int q = 0; q < offL; ++q) Lp[q] = src[q];
-			l2l_body<P>(Lp, center[3 * c] - center[3 * p], center[3 * c + 1] - center[3 * p + 1], center[3 * c + 2] - center[3 * p + 2], O);
-			float *Lc = local + (size_t)c * offL;
+			l2l_body<P>(Lp, (T)center[3 * c] - (T)center[3 * p], (T)center[3 * c + 1] - (T)center[3 * p + 1], (T)center[3 * c + 2] - (T)center[3 * p + 2], O);
+			T *Lc = local + (size_t)c * offL;
 #pragma unroll
 			for (int q = 1; q < offL; ++q) { O[q] += Lc[q]; Lc[q] = O[q]; }
-			O[0] = 0.f;
+			O[0] = T(0);
 		}
 		__syncthreads();
 		if (on)
 		{
-			float *dst = lds + (size_t)t * offL;
+			T *dst = lds + (size_t)t * offL;
 #pragma unroll
 			for (int q = 0; q < offL; ++q) dst[q] = O[q];
 		}
@@ -297,11 +301,16 @@ __global__ __launch_bounds__(kTopNodes) void l2l_top_kernel(const float *__restr
 // finished stays in LDS as the next level's parents, so the whole lower part of the downward pass is one launch
 // (per-level launches cost 10-25 us each while the near-field kernel fills the chip on the other stream).
 // Same arithmetic per node as l2l_node: bit-identical locals.
-template <int P>
-__global__ __launch_bounds__(256) void l2l_sub_kernel(const float *__restrict__ center, float *local, int lroot, int L, int first)
+// (Requesting a node's own tuple one level ahead takes the HBM round trip out of the level chain and this kernel from 36 to 26 us
+// in a kernel trace -- and the step gains nothing: with 217 registers per lane instead of 128 its workgroups wait longer for room
+// beside the near-field kernel's waves, which hold 480 of a SIMD's 512 registers.  The one-workgroup l2l_top_kernel went from 35
+// to 89 us with the same change.  Kept simple.)
+template <int P, typename T>
+__global__ __launch_bounds__(256) void l2l_sub_kernel(const float *__restrict__ center, T *local, int lroot, int L, int first)
 {
 	constexpr int offL = (P + 1) * (P + 1);
-	extern __shared__ float lds[];   // [2^(L - lroot - 1)][offL]
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+	T *lds = reinterpret_cast<T *>(lds_raw);   // [2^(L - lroot - 1)][offL]
 	const int t = threadIdx.x, r = first + blockIdx.x;
 	for (int q = t; q < offL; q += blockDim.x) lds[q] = local[(size_t)((1 << lroot) - 1 + r) * offL + q];
 	__syncthreads();
@@ -309,24 +318,24 @@ __global__ __launch_bounds__(256) void l2l_sub_kernel(const float *__restrict__ 
 	{
 		const bool on = t < (1 << (lc - lroot));
 		const int c = (1 << lc) - 1 + (r << (lc - lroot)) + t, p = (c - 1) >> 1;
-		float O[offL];
+		T O[offL];
 		if (on)
 		{
-			float Lp[offL];
-			const float *src = lds + (size_t)(t >> 1) * offL;
+			T Lp[offL];
+			const T *src = lds + (size_t)(t >> 1) * offL;
 #pragma unroll
 			for (int q = 0; q < offL; ++q) Lp[q] = src[q];
-			l2l_body<P>(Lp, center[3 * c] - center[3 * p], center[3 * c + 1] - center[3 * p + 1], center[3 * c + 2] - center[3 * p + 2], O);
-			float *Lc = local + (size_t)c * offL;
+			l2l_body<P>(Lp, (T)center[3 * c] - (T)center[3 * p], (T)center[3 * c + 1] - (T)center[3 * p + 1], (T)center[3 * c + 2] - (T)center[3 * p + 2], O);
+			T *Lc = local + (size_t)c * offL;
 #pragma unroll
 			for (int q = 1; q < offL; ++q) { O[q] += Lc[q]; Lc[q] = O[q]; }
-			O[0] = 0.f;
+			O[0] = T(0);
 		}
 		if (lc == L) break;
 		__syncthreads();
 		if (on)
 		{
-			float *dst = lds + (size_t)t * offL;
+			T *dst = lds + (size_t)t * offL;
 #pragma unroll
 			for (int q = 0; q < offL; ++q) dst[q] = O[q];
 		}
@@ -336,9 +345,9 @@ __global__ __launch_bounds__(256) void l2l_sub_kernel(const float *__restrict__ 
 
 // ---- L2P + near field + rescale + (un)sort -------------------------------------------------------------
 // one thread per particle in tree order; its leaf is floor(2^L i / n) (the inverse of evalBox's ranges)
-template <int P>
+template <int P, typename T>
 __global__ __launch_bounds__(kBlock) void l2p_gen_kernel(const float4 *__restrict__ pos, const float *__restrict__ center,
-                                                         const float *__restrict__ local, const float4 *__restrict__ near,
+                                                         const T *__restrict__ local, const float4 *__restrict__ near,
                                                          const int *__restrict__ chunk_off, const int *__restrict__ index, int mlt_max,
                                                          const int *__restrict__ unsort, int scatter, const float *__restrict__ param,
                                                          float *__restrict__ a_out, int have_near, long long n, int L, long long own0,
@@ -351,11 +360,11 @@ __global__ __launch_bounds__(kBlock) void l2p_gen_kernel(const float4 *__restric
 	const long long i = own0 + io;
 	const int lf = (int)(((1LL << L) * i) / n), leaf = (1 << L) - 1 + lf;
 	const float4 p = pos[i];
-	float Lp[offL];
+	T Lp[offL];
 #pragma unroll
 	for (int q = 0; q < offL; ++q) Lp[q] = local[(size_t)leaf * offL + q];
-	float fx, fy, fz;
-	l2p_body<P>(Lp, p.x - center[3 * leaf], p.y - center[3 * leaf + 1], p.z - center[3 * leaf + 2], fx, fy, fz);
+	T fx, fy, fz;
+	l2p_body<P>(Lp, (T)p.x - (T)center[3 * leaf], (T)p.y - (T)center[3 * leaf + 1], (T)p.z - (T)center[3 * leaf + 2], fx, fy, fz);
 	if (have_near)
 	{
 		const int j = (int)(i - index[leaf]);
@@ -381,30 +390,30 @@ __global__ __launch_bounds__(kBlock) void l2p_gen_kernel(const float4 *__restric
 				nx += rr.x; ny += rr.y; nz += rr.z;
 			}
 		}
-		fx += nx; fy += ny; fz += nz;
+		fx += (T)nx; fy += (T)ny; fz += (T)nz;   // (fp64 far field: the fp32 near-field sums join it in double, one narrowing at the end)
 	}
-	const float scale = param ? param[0] : 1.f;
+	const T scale = param ? (T)param[0] : T(1);
 	const long long o = scatter ? (long long)unsort[io] : io;
-	a_out[3 * o] = fx * scale; a_out[3 * o + 1] = fy * scale; a_out[3 * o + 2] = fz * scale;
+	a_out[3 * o] = (float)(fx * scale); a_out[3 * o + 1] = (float)(fy * scale); a_out[3 * o + 2] = (float)(fz * scale);
 }
 
 static int grid_for(long long n) { return (int)((n + kBlock - 1) / kBlock); }
 
-template <int P>
-static int run_upward(nbco_ctx *c, const float4 *pos, float *center, float *mpole, int *mult, const int *index, int L, int write_geom)
+template <int P, typename T>
+static int run_upward(nbco_ctx *c, const float4 *pos, float *center, T *mpole, int *mult, const int *index, int L, int write_geom)
 {
 	const int nleaf = 1 << L, beg = nleaf - 1;
-	hipLaunchKernelGGL(p2m_gen_kernel<P>, dim3(grid_for(nleaf)), dim3(kBlock), 0, c->stream, pos, (const float *)center, (const int *)mult, index,
+	hipLaunchKernelGGL((p2m_gen_kernel<P, T>), dim3(grid_for(nleaf)), dim3(kBlock), 0, c->stream, pos, (const float *)center, (const int *)mult, index,
 	                   mpole, beg, nleaf);
 	constexpr int offM = P * (P + 1) * (P + 2) / 6, offS = offM > 0 ? offM : 1;
 	// a workgroup walks as many levels of its subtree as fit its LDS (up to 256 nodes at the bottom level: 8 levels at
 	// p <= 5, 7 at p = 6): two or three launches for the whole upward shift instead of one per level
 	int depth = 8;
-	while (depth > 0 && (size_t)(1 << depth) * (offS + 4) * sizeof(float) > 60 * 1024) --depth;
+	while (depth > 0 && (size_t)(1 << depth) * (offS * sizeof(T) + 16) > 60 * 1024) --depth;
 	for (int l = L - 1; l >= 0;)
 	{
 		const int lroot = std::max(l - depth, 0), width = 1 << (l - lroot);
-		hipLaunchKernelGGL(m2m_top_kernel<P>, dim3(1 << lroot), dim3(std::max(64, width)), (size_t)width * (offS + 4) * sizeof(float), c->stream, center, mpole,
+		hipLaunchKernelGGL((m2m_top_kernel<P, T>), dim3(1 << lroot), dim3(std::max(64, width)), (size_t)width * (offS * sizeof(T) + 16), c->stream, center, mpole,
 		                   mult, l, lroot, write_geom);
 		l = lroot - 1;
 	}
@@ -413,58 +422,58 @@ static int run_upward(nbco_ctx *c, const float4 *pos, float *center, float *mpol
 }
 
 // levels ltop .. 0 of a tree whose level ltop + 1 is already in place (the levels above the kd-domains)
-template <int P>
-static int run_m2m_top(nbco_ctx *c, float *center, float *mpole, int *mult, int ltop, int write_geom)
+template <int P, typename T>
+static int run_m2m_top(nbco_ctx *c, float *center, T *mpole, int *mult, int ltop, int write_geom)
 {
 	constexpr int offM = P * (P + 1) * (P + 2) / 6, offS = offM > 0 ? offM : 1;
-	if ((1 << ltop) > kTopNodes || (size_t)(1 << ltop) * (offS + 4) * sizeof(float) > 60 * 1024)
+	if ((1 << ltop) > kTopNodes || (size_t)(1 << ltop) * (offS * sizeof(T) + 16) > 60 * 1024)
 		return c->fail(NBCO_ERR_UNSUPPORTED, "launch_m2m_top_gen: too many top levels");
-	hipLaunchKernelGGL(m2m_top_kernel<P>, dim3(1), dim3(kTopNodes), (size_t)(1 << ltop) * (offS + 4) * sizeof(float), c->stream, center, mpole, mult, ltop, 0,
+	hipLaunchKernelGGL((m2m_top_kernel<P, T>), dim3(1), dim3(kTopNodes), (size_t)(1 << ltop) * (offS * sizeof(T) + 16), c->stream, center, mpole, mult, ltop, 0,
 	                   write_geom);
 	NBCO_HIP(hipGetLastError());
 	return NBCO_OK;
 }
 
-template <int P>
-static int run_downward(nbco_ctx *c, const float *center, float *local, int L, int dom_d, int dom_g)
+template <int P, typename T>
+static int run_downward(nbco_ctx *c, const float *center, T *local, int L, int dom_d, int dom_g)
 {
 	constexpr int offL = (P + 1) * (P + 1);
 	int top = kTopNodes;
-	while (top > 4 && (size_t)top * offL * sizeof(float) > 60 * 1024) top >>= 1;
+	while (top > 4 && (size_t)top * offL * sizeof(T) > 60 * 1024) top >>= 1;
 	int ltop = 1;
 	while (ltop + 1 <= L && (1 << (ltop + 1)) <= top) ++ltop;
 	if (ltop >= 2)
-		hipLaunchKernelGGL(l2l_top_kernel<P>, dim3(1), dim3(kTopNodes), (size_t)(1 << ltop) * offL * sizeof(float), c->stream, center, local, ltop);
+		hipLaunchKernelGGL((l2l_top_kernel<P, T>), dim3(1), dim3(kTopNodes), (size_t)(1 << ltop) * offL * sizeof(T), c->stream, center, local, ltop);
 	// the lowest levels in one launch, a workgroup per subtree (<= 256 leaves, parents' tuples in <= 60 KB of LDS)
 	int lroot = L;
 	if (ltop >= 2)
 	{
 		lroot = std::max(ltop, L - 8);
-		while (lroot < L && (size_t)(1 << (L - lroot - 1)) * offL * sizeof(float) > 60 * 1024) ++lroot;
+		while (lroot < L && (size_t)(1 << (L - lroot - 1)) * offL * sizeof(T) > 60 * 1024) ++lroot;
 		if (lroot < dom_d) lroot = L;   // never with <= 8 domains; keep the per-level path for that case
 	}
 	for (int lc = ltop + 1; lc <= lroot; ++lc)
 	{
 		// below the domain level only the own subtree's nodes are needed
 		const int first = lc >= dom_d ? dom_g << (lc - dom_d) : 0, count = lc >= dom_d ? 1 << (lc - dom_d) : 1 << lc;
-		hipLaunchKernelGGL(l2l_gen_kernel<P>, dim3(grid_for(count)), dim3(kBlock), 0, c->stream, center, local, lc, first, count);
+		hipLaunchKernelGGL((l2l_gen_kernel<P, T>), dim3(grid_for(count)), dim3(kBlock), 0, c->stream, center, local, lc, first, count);
 	}
 	if (lroot < L)
 	{
 		const int first = dom_g << (lroot - dom_d), count = 1 << (lroot - dom_d);
-		hipLaunchKernelGGL(l2l_sub_kernel<P>, dim3(count), dim3(std::max(64, 1 << (L - lroot))), (size_t)(1 << (L - lroot - 1)) * offL * sizeof(float),
+		hipLaunchKernelGGL((l2l_sub_kernel<P, T>), dim3(count), dim3(std::max(64, 1 << (L - lroot))), (size_t)(1 << (L - lroot - 1)) * offL * sizeof(T),
 		                   c->stream, center, local, lroot, L, first);
 	}
 	NBCO_HIP(hipGetLastError());
 	return NBCO_OK;
 }
 
-template <int P>
-static int run_l2p(nbco_ctx *c, const float4 *pos, const float *center, const float *local, const float4 *near, const int *chunk_off,
+template <int P, typename T>
+static int run_l2p(nbco_ctx *c, const float4 *pos, const float *center, const T *local, const float4 *near, const int *chunk_off,
                    const int *index, int mlt_max, const int *unsort, int scatter, const float *param, float *a, int have_near, long long n, int L,
                    long long own0, long long own_n, const int2 *sec_range, const float4 *react, long long react_cap, int react_stride)
 {
-	hipLaunchKernelGGL(l2p_gen_kernel<P>, dim3(grid_for(own_n)), dim3(kBlock), 0, c->stream, pos, center, local, near, chunk_off, index, mlt_max,
+	hipLaunchKernelGGL((l2p_gen_kernel<P, T>), dim3(grid_for(own_n)), dim3(kBlock), 0, c->stream, pos, center, local, near, chunk_off, index, mlt_max,
 	                   unsort, scatter, param, a, have_near, n, L, own0, own_n, sec_range, react, (int)std::min<long long>(react_cap, 0x7fffffff), react_stride);
 	NBCO_HIP(hipGetLastError());
 	return NBCO_OK;
@@ -505,9 +514,17 @@ int launch_kd_centres(nbco_ctx *c, float *center, int *mult, int L, const float 
 	return NBCO_OK;
 }
 
-int launch_upward_gen(nbco_ctx *c, int P, const float4 *pos, float *center, float *mpole, int *mult, const int *index, int L, int write_geom)
+// (f64 != 0: mpole / local point at double tuples -- opts.far_fp64; orders above 8 in double are not instantiated for the upward /
+// downward shifts' fused kernels beyond what fits their LDS: the launchers size themselves from sizeof(T))
+int launch_upward_gen(nbco_ctx *c, int P, const float4 *pos, float *center, void *mpole, int *mult, const int *index, int L, int write_geom, int f64)
 {
-#define CALL(PP) run_upward<PP>(c, pos, center, mpole, mult, index, L, write_geom)
+	if (f64)
+	{
+#define CALL(PP) run_upward<PP, double>(c, pos, center, (double *)mpole, mult, index, L, write_geom)
+		NBCO_DISPATCH_P(P, CALL)
+#undef CALL
+	}
+#define CALL(PP) run_upward<PP, float>(c, pos, center, (float *)mpole, mult, index, L, write_geom)
 	NBCO_DISPATCH_P(P, CALL)
 #undef CALL
 }
@@ -522,25 +539,43 @@ int launch_kd_centres_top(nbco_ctx *c, float *center, int *mult, int ltop, const
 	return NBCO_OK;
 }
 
-int launch_m2m_top_gen(nbco_ctx *c, int P, float *center, float *mpole, int *mult, int ltop, int write_geom)
+int launch_m2m_top_gen(nbco_ctx *c, int P, float *center, void *mpole, int *mult, int ltop, int write_geom, int f64)
 {
-#define CALL(PP) run_m2m_top<PP>(c, center, mpole, mult, ltop, write_geom)
+	if (f64)
+	{
+#define CALL(PP) run_m2m_top<PP, double>(c, center, (double *)mpole, mult, ltop, write_geom)
+		NBCO_DISPATCH_P(P, CALL)
+#undef CALL
+	}
+#define CALL(PP) run_m2m_top<PP, float>(c, center, (float *)mpole, mult, ltop, write_geom)
 	NBCO_DISPATCH_P(P, CALL)
 #undef CALL
 }
 
-int launch_downward_gen(nbco_ctx *c, int P, const float *center, float *local, int L, int dom_d, int dom_g)
+int launch_downward_gen(nbco_ctx *c, int P, const float *center, void *local, int L, int dom_d, int dom_g, int f64)
 {
-#define CALL(PP) run_downward<PP>(c, center, local, L, dom_d, dom_g)
+	if (f64)
+	{
+#define CALL(PP) run_downward<PP, double>(c, center, (double *)local, L, dom_d, dom_g)
+		NBCO_DISPATCH_P(P, CALL)
+#undef CALL
+	}
+#define CALL(PP) run_downward<PP, float>(c, center, (float *)local, L, dom_d, dom_g)
 	NBCO_DISPATCH_P(P, CALL)
 #undef CALL
 }
 
-int launch_l2p_gen(nbco_ctx *c, int P, const float4 *pos, const float *center, const float *local, const float4 *near, const int *chunk_off,
+int launch_l2p_gen(nbco_ctx *c, int P, const float4 *pos, const float *center, const void *local, const float4 *near, const int *chunk_off,
                    const int *index, int mlt_max, const int *unsort, int scatter, const float *param, float *a, int have_near, long long n, int L,
-                   long long own0, long long own_n, const int2 *sec_range, const float4 *react, long long react_cap, int react_stride)
+                   long long own0, long long own_n, const int2 *sec_range, const float4 *react, long long react_cap, int react_stride, int f64)
 {
-#define CALL(PP) run_l2p<PP>(c, pos, center, local, near, chunk_off, index, mlt_max, unsort, scatter, param, a, have_near, n, L, own0, own_n, sec_range, react, react_cap, react_stride)
+	if (f64)
+	{
+#define CALL(PP) run_l2p<PP, double>(c, pos, center, (const double *)local, near, chunk_off, index, mlt_max, unsort, scatter, param, a, have_near, n, L, own0, own_n, sec_range, react, react_cap, react_stride)
+		NBCO_DISPATCH_P(P, CALL)
+#undef CALL
+	}
+#define CALL(PP) run_l2p<PP, float>(c, pos, center, (const float *)local, near, chunk_off, index, mlt_max, unsort, scatter, param, a, have_near, n, L, own0, own_n, sec_range, react, react_cap, react_stride)
 	NBCO_DISPATCH_P(P, CALL)
 #undef CALL
 }

@@ -1875,15 +1875,21 @@ static int build_directed_list(nbco_ctx *c, const int2 *pairs, const int2 *ranks
 // node arrays of a tree with ntot nodes carved out of `buf`
 static int kd_carve(nbco_ctx *c, DevBuf &buf, KdTreeDev &k, int ntot, int offM, int offL)
 {
-	size_t bytes = (size_t)ntot * (3 * 3 * sizeof(float) + sizeof(float4) + (size_t)(offM + offL) * sizeof(float) + 3 * sizeof(int)) + 256;
+	// (opts.far_fp64: the multipole / local tuples are doubles; everything else of the tree stays fp32)
+	const size_t rb = c->o.far_fp64 ? 8 : 4;
+	k.real_bytes = (int)rb;
+	size_t bytes = (size_t)ntot * (3 * 3 * sizeof(float) + sizeof(float4) + (size_t)(offM + offL) * rb + 3 * sizeof(int)) + 256 + 64;
 	NBCO_TRY(c->reserve(buf, bytes));
 	char *q = (char *)buf.ptr;
 	k.csz = (float4 *)q; q += sizeof(float4) * (size_t)ntot;
 	k.center = (float *)q; q += 12 * (size_t)ntot;
 	k.lbound = (float *)q; q += 12 * (size_t)ntot;
 	k.rbound = (float *)q; q += 12 * (size_t)ntot;
-	k.mpole = (float *)q; q += 4 * (size_t)ntot * offM;
-	k.local = (float *)q; q += 4 * (size_t)ntot * offL;
+	q = (char *)(((uintptr_t)q + 15) & ~(uintptr_t)15);   // (the double tuples want 8-byte alignment: 36 ntot bytes of fp32 geometry precede them)
+	k.mpole = (float *)q; q += rb * (size_t)ntot * offM;
+	q = (char *)(((uintptr_t)q + 15) & ~(uintptr_t)15);
+	k.local = (float *)q; q += rb * (size_t)ntot * offL;
+	q = (char *)(((uintptr_t)q + 15) & ~(uintptr_t)15);
 	k.mult = (int *)q; q += 4 * (size_t)ntot;
 	k.index = (int *)q; q += 4 * (size_t)ntot;
 	k.splitdim = (int *)q;
@@ -1948,8 +1954,9 @@ static int kd_build_upward(nbco_ctx *c, const float *p, long long n, int L, cons
 	{
 		NBCO_TRY(c->join_aux());   // e.g. the multipole chain of an evaluation that is being redone
 		KdTreeDev &k = c->kd;
+		const int old_real = k.real_bytes;
 		NBCO_TRY(kd_carve(c, c->treebuf, k, ntot, sym_off(P), tl_off(P + 1)));
-		const bool topo_change = k.L != L || k.ntot != ntot || k.order != P || k.n != n;
+		const bool topo_change = k.L != L || k.ntot != ntot || k.order != P || k.n != n || k.real_bytes != old_real;
 		if (topo_change) c->tree_valid = false;
 		k.L = L; k.ntot = ntot; k.order = P; k.mlt_max = mlt_max; k.n = n;
 		NBCO_TRY(kd_reserve_particles(c, n));
@@ -2035,7 +2042,7 @@ static int kd_build_upward(nbco_ctx *c, const float *p, long long n, int L, cons
 		NBCO_TRY(c->fork_aux());
 		StreamScope on_aux(c, c->aux);
 		PhaseScope ph(c, NBCO_PH_P2M_M2M);
-		NBCO_TRY(launch_upward_gen(c, P, pos, tv.center, tv.mpole, tv.mult, tv.index, L, 0));
+		NBCO_TRY(launch_upward_gen(c, P, pos, tv.center, tv.mpole, tv.mult, tv.index, L, 0, c->kd.real_bytes == 8));
 	}
 	NBCO_HIP(hipGetLastError());
 	return NBCO_OK;
@@ -2234,7 +2241,8 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		// the far field does not depend on the P2P list: M2L list, M2L and L2L run on the second stream, behind the
 		// multipole chain, and overlap the P2P list chain and the start of P2P
 		// (the locals are cleared on the second stream before it starts waiting for the traversal)
-		NBCO_HIP(hipMemsetAsync(tv.local, 0, sizeof(float) * (size_t)ntot * offL, c->aux));
+		const int f64 = c->o.far_fp64 ? 1 : 0;   // (the tree this view belongs to was carved under the same option)
+		NBCO_HIP(hipMemsetAsync(tv.local, 0, (f64 ? sizeof(double) : sizeof(float)) * (size_t)ntot * offL, c->aux));
 		NBCO_TRY(c->fork_wait());
 		{
 			StreamScope on_aux(c, c->aux);
@@ -2246,11 +2254,12 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 			{
 				PhaseScope ph(c, NBCO_PH_M2L);
 				// register-resident generated bodies, one interaction per lane (k_m2l.hip)
-				NBCO_TRY(launch_m2l_lanes(c, P, tv.csz, tv.mpole, tv.local, c->m2l_keys_alt.as<uint64_t>(), c->m2l_start.as<int>(), shift, ntot));
+				if (f64) NBCO_TRY(launch_m2l_lanes_f64(c, P, tv.csz, (const double *)tv.mpole, (double *)tv.local, c->m2l_keys_alt.as<uint64_t>(), c->m2l_start.as<int>(), shift, ntot));
+				else NBCO_TRY(launch_m2l_lanes(c, P, tv.csz, tv.mpole, tv.local, c->m2l_keys_alt.as<uint64_t>(), c->m2l_start.as<int>(), shift, ntot));
 			}
 			{
 				PhaseScope ph(c, NBCO_PH_L2L);
-				NBCO_TRY(launch_downward_gen(c, P, tv.center, tv.local, L, dm.d, dm.g));
+				NBCO_TRY(launch_downward_gen(c, P, tv.center, tv.local, L, dm.d, dm.g, f64));
 			}
 		}
 		NBCO_HIP(hipGetLastError());
@@ -2261,7 +2270,7 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		PhaseScope ph(c, NBCO_PH_L2P);
 		NBCO_TRY(launch_l2p_gen(c, P, pos, tv.center, tv.local, near, c->p2p_chunk_off.as<int>(), tv.index, mlt_max, unsort, c->o.unsort ? 1 : 0,
 		                        param, a, c->o.coll ? 1 : 0, n, L, own0, own_n, mutual ? c->p2p_sec.as<int2>() : nullptr,
-		                        mutual ? c->p2p_react.as<float4>() : nullptr, react_cap, 32 * mutual_th));
+		                        mutual ? c->p2p_react.as<float4>() : nullptr, react_cap, 32 * mutual_th, c->o.far_fp64 ? 1 : 0));
 	}
 	// ---- now look at what the traversal reported (long finished: the GPU is busy with the work queued above) ----------
 	{
@@ -2287,7 +2296,7 @@ static int kd_interact(nbco_ctx *c, const TreeView &tv, const float4 *pos, long 
 		nbco_ctx::LastEval &le = c->last_eval;
 		le.valid = true;
 		le.center = tv.center; le.csz = tv.csz; le.mpole = tv.mpole; le.mult = tv.mult; le.index = tv.index;
-		le.L = L; le.ntot = ntot; le.order = P; le.shift = shift;
+		le.L = L; le.ntot = ntot; le.order = P; le.shift = shift; le.real_bytes = c->o.far_fp64 ? 8 : 4;
 		le.pos = pos; le.n = n; le.own0 = own0; le.own_n = own_n;
 		le.have_p2p = c->o.coll != 0;
 	}
@@ -2332,8 +2341,8 @@ static int kd_finish_order(nbco_ctx *c, float *p, long long n)
 __host__ __device__ constexpr int sym_index(int x, int z, int n) { return (n * (n + 1) - (n - z) * (n - z + 1)) / 2 + n - x; }
 __host__ __device__ constexpr int sym_offset(int n) { return n * (n + 1) * (n + 2) / 6; }
 
-template <int P>
-__device__ inline double m2p_potential(const float *__restrict__ M, double dx, double dy, double dz, double eps2)
+template <int P, typename T>
+__device__ inline double m2p_potential(const T *__restrict__ M, double dx, double dy, double dz, double eps2)
 {
 	constexpr int offM = sym_offset(P);
 	double B[offM > 0 ? offM : 1];
@@ -2371,7 +2380,7 @@ __device__ inline double m2p_potential(const float *__restrict__ M, double dx, d
 	return phi;
 }
 
-template <int P>
+template <int P, typename T>
 __global__ __launch_bounds__(kBlock) void kd_potential_kernel(nbco_ctx::LastEval le, const uint64_t *__restrict__ m2l_keys, const int *__restrict__ m2l_start,
                                                               const uint64_t *__restrict__ p2p_keys, const int *__restrict__ p2p_start, float eps2f,
                                                               double *__restrict__ part)
@@ -2405,7 +2414,7 @@ __global__ __launch_bounds__(kBlock) void kd_potential_kernel(nbco_ctx::LastEval
 			{
 				const int sn = (int)(m2l_keys[e] & mask);
 				const float4 cs = le.csz[sn];
-				phi += m2p_potential<P>(le.mpole + (size_t)sn * offM, (double)p.x - (double)cs.x, (double)p.y - (double)cs.y, (double)p.z - (double)cs.z, eps2);
+				phi += m2p_potential<P, T>(reinterpret_cast<const T *>(le.mpole) + (size_t)sn * offM, (double)p.x - (double)cs.x, (double)p.y - (double)cs.y, (double)p.z - (double)cs.z, eps2);
 			}
 			if (node == 0) break;
 		}
@@ -2425,9 +2434,15 @@ __global__ __launch_bounds__(kBlock) void kd_potential_kernel(nbco_ctx::LastEval
 
 template <int P> static void launch_potential(nbco_ctx *c, int grid, double *part)
 {
-	hipLaunchKernelGGL(kd_potential_kernel<P>, dim3(grid), dim3(kBlock), 0, c->stream, c->last_eval, (const uint64_t *)c->m2l_keys_alt.as<uint64_t>(),
-	                   (const int *)c->m2l_start.as<int>(), (const uint64_t *)c->p2p_keys_alt.as<uint64_t>(), (const int *)c->p2p_start.as<int>(), c->o.eps2,
-	                   part);
+	// (the multipoles of the last evaluation are doubles when it ran with opts.far_fp64: LastEval::real_bytes)
+	if (c->last_eval.real_bytes == 8)
+		hipLaunchKernelGGL((kd_potential_kernel<P, double>), dim3(grid), dim3(kBlock), 0, c->stream, c->last_eval, (const uint64_t *)c->m2l_keys_alt.as<uint64_t>(),
+		                   (const int *)c->m2l_start.as<int>(), (const uint64_t *)c->p2p_keys_alt.as<uint64_t>(), (const int *)c->p2p_start.as<int>(), c->o.eps2,
+		                   part);
+	else
+		hipLaunchKernelGGL((kd_potential_kernel<P, float>), dim3(grid), dim3(kBlock), 0, c->stream, c->last_eval, (const uint64_t *)c->m2l_keys_alt.as<uint64_t>(),
+		                   (const int *)c->m2l_start.as<int>(), (const uint64_t *)c->p2p_keys_alt.as<uint64_t>(), (const int *)c->p2p_start.as<int>(), c->o.eps2,
+		                   part);
 }
 
 } // namespace
@@ -2522,7 +2537,6 @@ int fmm_kdtree_eval(nbco_ctx *c, float *p, float *a, long long n, const float *p
 {
 	if (n <= 0) return c->fail(NBCO_ERR_ARG, "nbco_fmm_kdtree: n must be positive");
 	if (n > 0x7fffffffLL / 4) return c->fail(NBCO_ERR_UNSUPPORTED, "nbco_fmm_kdtree: n too large for 32-bit tree indices");
-	if (c->o.far_fp64) return c->fail(NBCO_ERR_UNSUPPORTED, "nbco_fmm_kdtree: far_fp64 is implemented by nbco_fmm_traceless only");
 	const int P = c->o.fmm_order;
 	const int L = kd_levels(n, P, c->o.dens_inhom, c->o.tree_L);
 	bool rebuild = false;
@@ -2624,6 +2638,7 @@ __global__ __launch_bounds__(kBlock) void dist_unpack_nodes_kernel(TreeView t, c
 		t.center[3 * gid] = cs.x; t.center[3 * gid + 1] = cs.y; t.center[3 * gid + 2] = cs.z;
 	}
 }
+template <typename T>   // float, or double tuples with opts.far_fp64
 __global__ __launch_bounds__(kBlock) void dist_unpack_mpole_kernel(TreeView t, const char *__restrict__ blocks, size_t block_bytes, int ntot_loc, int G,
                                                                    int r0, int d, int offM)
 {
@@ -2633,8 +2648,8 @@ __global__ __launch_bounds__(kBlock) void dist_unpack_mpole_kernel(TreeView t, c
 		const int r = (int)(i / per);
 		const long long e = i % per;
 		const int k = (int)(e / offM), comp = (int)(e % offM);
-		const float *src = reinterpret_cast<const float *>(blocks + (size_t)r * block_bytes);
-		t.mpole[(size_t)dist_global_id(k, r0 + r, d) * offM + comp] = src[e];
+		const T *src = reinterpret_cast<const T *>(blocks + (size_t)r * block_bytes);
+		reinterpret_cast<T *>(t.mpole)[(size_t)dist_global_id(k, r0 + r, d) * offM + comp] = src[e];
 	}
 }
 // ranges of evalBox's rule for every node of the global tree (fmm_cart3_kdtree.cuh:109-137)
@@ -2675,7 +2690,6 @@ TopView top_view(nbco_ctx *c, int ntop)
 
 int kd_dist_layout(nbco_ctx *c, long long n_global, int world, int rank, nbco_dist_layout *out)
 {
-	if (c->o.far_fp64) return c->fail(NBCO_ERR_UNSUPPORTED, "nbco_dist_*: far_fp64 is implemented by nbco_fmm_traceless only");
 	const int d = log2_exact(world);
 	if (d < 0 || world > 64) return c->fail(NBCO_ERR_ARG, "nbco_dist: the number of domains must be a power of two <= 64");
 	if (rank < 0 || rank >= world) return c->fail(NBCO_ERR_ARG, "nbco_dist: rank out of range");
@@ -2689,10 +2703,11 @@ int kd_dist_layout(nbco_ctx *c, long long n_global, int world, int rank, nbco_di
 	out->ntot_local = (1 << (L - d + 1)) - 1;
 	out->n_global = n_global; out->n_local = n_global / world;
 	out->csz_bytes = (long long)out->ntot_local * (long long)sizeof(float4);
-	out->mpole_bytes = (long long)out->ntot_local * (long long)(sizeof(float) * sym_off(P));
+	const long long rb = c->o.far_fp64 ? 8 : 4;   // bytes per real of a multipole tuple
+	out->mpole_bytes = (long long)out->ntot_local * rb * (long long)sym_off(P);
 	out->nodes_bytes = out->csz_bytes + out->mpole_bytes;
 	out->pos_bytes = (long long)out->n_local * (long long)sizeof(float4);
-	out->let_node_bytes = 4LL * (((sym_off(P) + 1 + 3) / 4) * 4);
+	out->let_node_bytes = rb * (((sym_off(P) + 1 + 3) / 4) * 4);
 	out->let_counts = 2 * world + 2;
 	return NBCO_OK;
 }
@@ -2850,7 +2865,7 @@ int kd_dist_local(nbco_ctx *c, float *buf_local, long long n_local, void *nodes_
 			NBCO_HIP(hipMemcpyAsync(nodes_send, c->kd.csz, sizeof(float4) * (size_t)lay.ntot_local, hipMemcpyDeviceToDevice, st));
 			mpole_send = (char *)nodes_send + sizeof(float4) * (size_t)lay.ntot_local;
 		}
-		NBCO_HIP(hipMemcpyAsync(mpole_send, c->kd.mpole, sizeof(float) * (size_t)lay.ntot_local * offM, hipMemcpyDeviceToDevice, st));
+		NBCO_HIP(hipMemcpyAsync(mpole_send, c->kd.mpole, (size_t)c->kd.real_bytes * (size_t)lay.ntot_local * offM, hipMemcpyDeviceToDevice, st));
 		c->dist.local_done = true;
 	}
 	return NBCO_OK;
@@ -2971,10 +2986,16 @@ __global__ void let_counts_kernel(const int *__restrict__ cursors, const int *__
 
 struct LetBases { long long v[65]; };   // first record of every receiver's (sender's) segment
 
-// node records: {bits(global node id), multipole[offM]} padded to rec floats; blockIdx.y = receiver
-__global__ __launch_bounds__(kBlock) void let_pack_mpole_kernel(const float *__restrict__ mpole, int offM, int rec, int ntot_loc, int d, int g,
+// the node id in a record of reals: its bit pattern in a float, its value in a double (exact up to 2^53)
+__device__ inline float let_id_enc(int id, float) { return __int_as_float(id); }
+__device__ inline double let_id_enc(int id, double) { return (double)id; }
+__device__ inline int let_id_dec(float v) { return __float_as_int(v); }
+__device__ inline int let_id_dec(double v) { return (v >= 0.0 && v < 2147483648.0) ? (int)v : -1; }
+// node records: {global node id, multipole[offM]} padded to rec reals (floats, or doubles with opts.far_fp64); blockIdx.y = receiver
+template <typename T>
+__global__ __launch_bounds__(kBlock) void let_pack_mpole_kernel(const T *__restrict__ mpole, int offM, int rec, int ntot_loc, int d, int g,
                                                                 const int *__restrict__ sel_node, const int *__restrict__ cursors, LetBases nb,
-                                                                float *__restrict__ out)
+                                                                T *__restrict__ out)
 {
 	const int r = blockIdx.y;
 	const long long total = (long long)cursors[4 * r] * rec;
@@ -2982,8 +3003,8 @@ __global__ __launch_bounds__(kBlock) void let_pack_mpole_kernel(const float *__r
 	{
 		const int comp = (int)(i % rec), slot = (int)(i / rec);
 		const int k = sel_node[(size_t)r * ntot_loc + slot];
-		float v = 0.f;
-		if (comp == 0) v = __int_as_float(dist_global_id(k, g, d));
+		T v = T(0);
+		if (comp == 0) v = let_id_enc(dist_global_id(k, g, d), T());
 		else if (comp <= offM) v = mpole[(size_t)k * offM + comp - 1];
 		out[(nb.v[r] + slot) * rec + comp] = v;
 	}
@@ -3019,15 +3040,16 @@ __global__ __launch_bounds__(kBlock) void let_unpack_pos_kernel(const float4 *__
 		have_leaf[(int)(((1LL << L) * idx) / n_global)] = 1;
 	}
 }
-__global__ __launch_bounds__(kBlock) void let_unpack_mpole_kernel(const float *__restrict__ recs, long long count, int rec, int offM, int ntot,
-                                                                  float *__restrict__ mpole, unsigned char *__restrict__ have_node)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void let_unpack_mpole_kernel(const T *__restrict__ recs, long long count, int rec, int offM, int ntot,
+                                                                  T *__restrict__ mpole, unsigned char *__restrict__ have_node)
 {
 	const long long total = count * rec;
 	for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock)
 	{
 		const int comp = (int)(i % rec);
 		const long long q = i / rec;
-		const int gid = __float_as_int(recs[q * rec]);
+		const int gid = let_id_dec(recs[q * rec]);
 		if (gid < 0 || gid >= ntot) continue;
 		if (comp == 0) have_node[gid] = 1;
 		else if (comp <= offM) mpole[(size_t)gid * offM + comp - 1] = recs[i];
@@ -3172,8 +3194,14 @@ int kd_dist_let_pack(nbco_ctx *c, const long long *counts_all, void *pos_send, v
 		                   (const int *)v.cursors, pb, (float4 *)pos_send);
 	NBCO_TRY(c->join_aux());   // the upward pass
 	if (nmax > 0)
-		hipLaunchKernelGGL(let_pack_mpole_kernel, dim3(grid1d(nmax * rec, 2048), G), dim3(kBlock), 0, c->stream, (const float *)c->kd.mpole, offM, rec, lay.ntot_local,
-		                   lay.d, lay.rank, (const int *)v.sel_node, (const int *)v.cursors, nb, (float *)mpole_send);
+	{
+		if (c->kd.real_bytes == 8)
+			hipLaunchKernelGGL(let_pack_mpole_kernel<double>, dim3(grid1d(nmax * rec, 2048), G), dim3(kBlock), 0, c->stream, (const double *)c->kd.mpole, offM, rec,
+			                   lay.ntot_local, lay.d, lay.rank, (const int *)v.sel_node, (const int *)v.cursors, nb, (double *)mpole_send);
+		else
+			hipLaunchKernelGGL(let_pack_mpole_kernel<float>, dim3(grid1d(nmax * rec, 2048), G), dim3(kBlock), 0, c->stream, (const float *)c->kd.mpole, offM, rec,
+			                   lay.ntot_local, lay.d, lay.rank, (const int *)v.sel_node, (const int *)v.cursors, nb, (float *)mpole_send);
+	}
 	NBCO_HIP(hipGetLastError());
 	c->dist.let_packed = true;
 	return NBCO_OK;
@@ -3275,19 +3303,28 @@ static int dist_finish_rest(nbco_ctx *c, const char *mp_blocks, size_t mp_stride
 	// on the second stream, ahead of the M2L list: multipoles into the global arrays, M2M for the levels above the domains
 	const std::function<int()> pre_far = [&]() -> int {
 		PhaseScope ph(c, NBCO_PH_P2M_M2M);
-		if (offM > 0 && !let_counts)
-			hipLaunchKernelGGL(dist_unpack_mpole_kernel, dim3(grid1d((long long)G * lay.ntot_local * offM)), dim3(kBlock), 0, c->stream, tv, mp_blocks, mp_stride,
-			                   lay.ntot_local, G, 0, d, offM);
+		const bool f64 = g.real_bytes == 8;   // (dist_global_tree carved the global arrays under the same opts.far_fp64 as the local tree)
+		auto unpack_blocks = [&](const char *blocks, size_t stride, int nblocks, int r0) {
+			const int grid = grid1d((long long)nblocks * lay.ntot_local * offM);
+			if (f64) hipLaunchKernelGGL(dist_unpack_mpole_kernel<double>, dim3(grid), dim3(kBlock), 0, c->stream, tv, blocks, stride, lay.ntot_local, nblocks, r0, d, offM);
+			else hipLaunchKernelGGL(dist_unpack_mpole_kernel<float>, dim3(grid), dim3(kBlock), 0, c->stream, tv, blocks, stride, lay.ntot_local, nblocks, r0, d, offM);
+		};
+		if (offM > 0 && !let_counts) unpack_blocks(mp_blocks, mp_stride, G, 0);
 		if (offM > 0 && let_counts)
 		{
 			// the own subtree straight from the local tree, the rest from the records
-			hipLaunchKernelGGL(dist_unpack_mpole_kernel, dim3(grid1d((long long)lay.ntot_local * offM)), dim3(kBlock), 0, c->stream, tv, (const char *)c->kd.mpole, (size_t)0,
-			                   lay.ntot_local, 1, lay.rank, d, offM);
+			unpack_blocks((const char *)c->kd.mpole, (size_t)0, 1, lay.rank);
 			if (nodes_in > 0)
-				hipLaunchKernelGGL(let_unpack_mpole_kernel, dim3(grid1d(nodes_in * rec, 4096)), dim3(kBlock), 0, c->stream, (const float *)mp_blocks, nodes_in, rec, offM, g.ntot,
-				                   tv.mpole, const_cast<unsigned char *>(have.node));
+			{
+				if (f64)
+					hipLaunchKernelGGL(let_unpack_mpole_kernel<double>, dim3(grid1d(nodes_in * rec, 4096)), dim3(kBlock), 0, c->stream, (const double *)mp_blocks, nodes_in, rec,
+					                   offM, g.ntot, (double *)tv.mpole, const_cast<unsigned char *>(have.node));
+				else
+					hipLaunchKernelGGL(let_unpack_mpole_kernel<float>, dim3(grid1d(nodes_in * rec, 4096)), dim3(kBlock), 0, c->stream, (const float *)mp_blocks, nodes_in, rec,
+					                   offM, g.ntot, tv.mpole, const_cast<unsigned char *>(have.node));
+			}
 		}
-		if (d > 0) NBCO_TRY(launch_m2m_top_gen(c, P, tv.center, tv.mpole, tv.mult, d - 1, 0));
+		if (d > 0) NBCO_TRY(launch_m2m_top_gen(c, P, tv.center, tv.mpole, tv.mult, d - 1, 0, f64 ? 1 : 0));
 		NBCO_HIP(hipGetLastError());
 		return NBCO_OK;
 	};
@@ -3367,8 +3404,8 @@ int kd_copy_out(nbco_ctx *c, int which, void *dst, long long bytes)
 	case NBCO_KD_CENTER: src = k.center; need = 12 * (size_t)k.ntot; break;
 	case NBCO_KD_LBOUND: src = k.lbound; need = 12 * (size_t)k.ntot; break;
 	case NBCO_KD_RBOUND: src = k.rbound; need = 12 * (size_t)k.ntot; break;
-	case NBCO_KD_MPOLE: src = k.mpole; need = 4 * (size_t)k.ntot * offM; break;
-	case NBCO_KD_LOCAL: src = k.local; need = 4 * (size_t)k.ntot * offL; break;
+	case NBCO_KD_MPOLE: src = k.mpole; need = (size_t)k.real_bytes * (size_t)k.ntot * offM; break;   // doubles after an evaluation with opts.far_fp64
+	case NBCO_KD_LOCAL: src = k.local; need = (size_t)k.real_bytes * (size_t)k.ntot * offL; break;
 	case NBCO_KD_P2P_LIST:
 	case NBCO_KD_M2L_LIST:
 	{

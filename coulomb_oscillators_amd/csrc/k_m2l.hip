@@ -67,29 +67,48 @@ __global__ __launch_bounds__(64) void m2l_lane_kernel(const float4 *__restrict__
 		tg[lane] = tgt;
 		__syncthreads();
 		const int rows = min(64, i1 - base);
-		for (int r = 0; r < rows; ++r)
+		// Lane c adds component c of the rows in list order.  The rows are read eight at a time (independent LDS reads, one wait)
+		// and then added one after the other: the chain is eight additions long per wait instead of one LDS round trip per row
+		// (the walk used to take as long as the 650-instruction body in front of it).  Same additions in the same order.
+		constexpr int RB = 8;
+		for (int r0 = 0; r0 < rows; r0 += RB)
 		{
-			const int t = tg[r];
-			if (t != cur)
+			T v[RB][CPL];
+			int tt[RB];
+#pragma unroll
+			for (int k = 0; k < RB; ++k)
 			{
-				if (cur >= 0)
+				const int r = min(r0 + k, 63);
+				tt[k] = tg[r];
+#pragma unroll
+				for (int q = 0; q < CPL; ++q)
 				{
-#pragma unroll
-					for (int q = 0; q < CPL; ++q)
-					{
-						const int c = lane + 64 * q;
-						if (c < NOUT) local[(size_t)cur * offL + 1 + c] = acc[q];
-					}
+					const int c = lane + 64 * q;
+					v[k][q] = c < NOUT ? buf[r][c] : T(0);
 				}
-#pragma unroll
-				for (int q = 0; q < CPL; ++q) acc[q] = T(0);
-				cur = t;
 			}
 #pragma unroll
-			for (int q = 0; q < CPL; ++q)
+			for (int k = 0; k < RB; ++k)
 			{
-				const int c = lane + 64 * q;
-				if (c < NOUT) acc[q] += buf[r][c];
+				if (r0 + k >= rows) break;
+				const int t = tt[k];
+				if (t != cur)
+				{
+					if (cur >= 0)
+					{
+#pragma unroll
+						for (int q = 0; q < CPL; ++q)
+						{
+							const int c = lane + 64 * q;
+							if (c < NOUT) local[(size_t)cur * offL + 1 + c] = acc[q];
+						}
+					}
+#pragma unroll
+					for (int q = 0; q < CPL; ++q) acc[q] = T(0);
+					cur = t;
+				}
+#pragma unroll
+				for (int q = 0; q < CPL; ++q) acc[q] += v[k][q];
 			}
 		}
 		__syncthreads();

@@ -52,14 +52,6 @@ int nbco_ctx::fork_mark()
 		NBCO_HIP_M(this, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
 		if (getenv("NBCO_AUX_PRIO") && atoi(getenv("NBCO_AUX_PRIO")) == 0) prio_hi = prio_lo;   // A/B switch (diagnostics)
 		if (getenv("NBCO_AUX_SERIAL") && atoi(getenv("NBCO_AUX_SERIAL")) != 0) { aux = stream; aux_is_main = true; }   // diagnostics: one stream
-		else if (getenv("NBCO_AUX_CUMASK"))
-		{
-			// diagnostics: the far-field stream confined to the CUs of a 256-bit mask given as 8 hex words, least significant first
-			// (does the near-field kernel lose less to the far-field chain when that chain cannot spread over the whole chip?)
-			uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-			sscanf(getenv("NBCO_AUX_CUMASK"), "%x,%x,%x,%x,%x,%x,%x,%x", &mask[0], &mask[1], &mask[2], &mask[3], &mask[4], &mask[5], &mask[6], &mask[7]);
-			NBCO_HIP_M(this, hipExtStreamCreateWithCUMask(&aux, 8, mask));
-		}
 		else NBCO_HIP_M(this, hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, prio_hi));
 		NBCO_HIP_M(this, hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
 		NBCO_HIP_M(this, hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
@@ -698,6 +690,7 @@ int nbco_kd_get_info(nbco_ctx *c, nbco_kd_info *info)
 	*info = c->info;
 	info->build_mode = c->force_sort_build ? 2 : (c->sel_three_pass ? 1 : 0);
 	info->warm_builds = c->sel_warm_builds; info->warm_misses = c->sel_warm_misses;
+	info->real_bytes = c->kd.real_bytes;
 	return NBCO_OK;
 }
 int nbco_kd_copy(nbco_ctx *c, int which, void *host_dst, long long host_bytes)

@@ -87,8 +87,9 @@ struct KdTreeDev
 	long long n = 0;
 	float *center = nullptr, *lbound = nullptr, *rbound = nullptr;   // [ntot][3]
 	float4 *csz = nullptr;                                           // [ntot] centre xyz + box diagonal^2
-	float *mpole = nullptr, *local = nullptr;                        // [ntot][offM], [ntot][offL]
+	float *mpole = nullptr, *local = nullptr;                        // [ntot][offM], [ntot][offL]; DOUBLE tuples behind these pointers when real_bytes == 8
 	int *mult = nullptr, *index = nullptr, *splitdim = nullptr;      // [ntot]
+	int real_bytes = 4;                                              // element size of mpole / local: 8 with opts.far_fp64
 };
 
 // uniform-octree state of the last nbco_fmm_traceless call (fmmTree of fmm_cart3_symmetric.cuh:24-30)
@@ -252,7 +253,7 @@ struct nbco_ctx
 		const float *center = nullptr, *mpole = nullptr;
 		const float4 *csz = nullptr, *pos = nullptr;
 		const int *mult = nullptr, *index = nullptr;
-		int L = 0, ntot = 0, order = 0, shift = 0;
+		int L = 0, ntot = 0, order = 0, shift = 0, real_bytes = 4;   // real_bytes: element size of mpole (8 after an evaluation with opts.far_fp64)
 		long long n = 0, own0 = 0, own_n = 0;
 	} last_eval;
 	// bookkeeping of the last evaluation
@@ -350,15 +351,15 @@ int kd_select_begin(nbco_ctx *c, int l0, bool zero = true, long long *words_a = 
 int kd_select_level(nbco_ctx *c, int l, long long n, const float4 *pos_in, const int *unsort_in, float4 *pos_out, int *unsort_out,
                     float *lbound, float *rbound, int *splitdim, int *index, int *flag, bool warm = false);
 // k_farfield.hip
-int launch_upward_gen(nbco_ctx *c, int P, const float4 *pos, float *center, float *mpole, int *mult, const int *index, int L, int write_geom);
+int launch_upward_gen(nbco_ctx *c, int P, const float4 *pos, float *center, void *mpole, int *mult, const int *index, int L, int write_geom, int f64 = 0);
 int launch_kd_centres(nbco_ctx *c, float *center, int *mult, int L, const float *lbound, const float *rbound, float4 *csz);
-int launch_downward_gen(nbco_ctx *c, int P, const float *center, float *local, int L, int dom_d, int dom_g);
-int launch_m2m_top_gen(nbco_ctx *c, int P, float *center, float *mpole, int *mult, int ltop, int write_geom);
+int launch_downward_gen(nbco_ctx *c, int P, const float *center, void *local, int L, int dom_d, int dom_g, int f64 = 0);
+int launch_m2m_top_gen(nbco_ctx *c, int P, float *center, void *mpole, int *mult, int ltop, int write_geom, int f64 = 0);
 int launch_kd_centres_top(nbco_ctx *c, float *center, int *mult, int ltop, const float *lbound, const float *rbound, float4 *csz);
-int launch_l2p_gen(nbco_ctx *c, int P, const float4 *pos, const float *center, const float *local, const float4 *near, const int *chunk_off,
+int launch_l2p_gen(nbco_ctx *c, int P, const float4 *pos, const float *center, const void *local, const float4 *near, const int *chunk_off,
                    const int *index, int mlt_max, const int *unsort, int scatter, const float *param, float *a, int have_near, long long n, int L,
                    long long own0, long long own_n, const int2 *sec_range = nullptr, const float4 *react = nullptr, long long react_cap = 0,
-                   int react_stride = 32);
+                   int react_stride = 32, int f64 = 0);
 // k_m2l.hip
 // mstride: reals per multipole tuple in `mpole` (0 = the offM(P) of the kd-tree layout; the symmetric octree evaluator keeps orders 0..P)
 int launch_m2l_lanes(nbco_ctx *c, int P, const float4 *csz, const float *mpole, float *local, const uint64_t *keys, const int *start,

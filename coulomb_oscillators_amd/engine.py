@@ -44,7 +44,8 @@ class Opts(C.Structure):
 class KdInfo(C.Structure):
     _fields_ = [("L", C.c_int), ("ntot", C.c_int), ("order", C.c_int), ("mlt_max", C.c_int), ("n", C.c_longlong),
                 ("p2p_pairs", C.c_longlong), ("m2l_pairs", C.c_longlong), ("directed_p2p", C.c_longlong),
-                ("rebuilt", C.c_int), ("build_mode", C.c_int), ("p2p_halves", C.c_int), ("warm_builds", C.c_longlong), ("warm_misses", C.c_longlong)]
+                ("rebuilt", C.c_int), ("build_mode", C.c_int), ("p2p_halves", C.c_int), ("warm_builds", C.c_longlong), ("warm_misses", C.c_longlong),
+                ("real_bytes", C.c_int)]
 
 
 class OctInfo(C.Structure):
@@ -401,10 +402,11 @@ class Engine:
         info = self.kd_info()
         p = info.order
         offM, offL = p * (p + 1) * (p + 2) // 6, (p + 1) ** 2
+        real = np.float64 if info.real_bytes == 8 else np.float32      # doubles after an evaluation with far_fp64
         shapes = {"mult": ((info.ntot,), np.int32), "index": ((info.ntot,), np.int32), "splitdim": ((info.ntot,), np.int32),
                   "center": ((info.ntot, 3), np.float32), "lbound": ((info.ntot, 3), np.float32),
-                  "rbound": ((info.ntot, 3), np.float32), "mpole": ((info.ntot, offM), np.float32),
-                  "local": ((info.ntot, offL), np.float32), "p2p": ((info.p2p_pairs, 2), np.int32),
+                  "rbound": ((info.ntot, 3), np.float32), "mpole": ((info.ntot, offM), real),
+                  "local": ((info.ntot, offL), real), "p2p": ((info.p2p_pairs, 2), np.int32),
                   "m2l": ((info.m2l_pairs, 2), np.int32), "unsort": ((info.n,), np.int32), "order": ((info.n,), np.int32)}
         shape, dt = shapes[name]
         out = np.empty(shape, dtype=dt)

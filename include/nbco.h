@@ -81,12 +81,13 @@ typedef struct nbco_opts {
 	                       list_factor, and at most 2^31 pairs) and repeats the evaluation instead of failing:
 	                       long runs change shape -- a ball that starts with 2.7e5 leaf pairs at N = 1M holds 6e6
 	                       after 1200 steps, when a few ejected particles have stretched the outer leaves */
-	int   far_fp64;     /* != 0: nbco_fmm_traceless keeps multipole / local expansions in double and does
-	                       P2M, M2M, M2L, L2L and L2P in fp64 (BASELINE config 5: fp64 far field, fp32 P2P).
-	                       Positions, cell centres and the near field stay fp32.  The fp32 far field overflows
+	int   far_fp64;     /* != 0: the FMM evaluators (nbco_fmm_kdtree, nbco_fmm_traceless, nbco_fmm_symmetric and the sharded
+	                       nbco_dist_* forms) keep multipole / local expansions in double and do P2M, M2M, M2L, L2L and L2P
+	                       in fp64 (BASELINE config 5: fp64 far field, fp32 P2P).  Positions, the tree geometry (centres,
+	                       boxes, lists -- unchanged, bit for bit) and the near field stay fp32.  The fp32 far field overflows
 	                       beyond N ~ 1e5 at orders 9-10 (r^-11 19!! ~ 1e40); this mode does not.
-	                       No reference counterpart other than the -DSCAL=double build.  nbco_fmm_kdtree
-	                       rejects it (NBCO_ERR_UNSUPPORTED). */
+	                       No reference counterpart other than the -DSCAL=double build.  Sharded runs: the exchanged
+	                       multipole blocks / LET node records are doubles (nbco_dist_layout sizes follow the option). */
 	int   p2p_mutual;   /* != 0: nbco_fmm_kdtree evaluates every leaf pair of its near field once and applies the force to both
 	                       leaves (Newton III), as the reference's GPU pair kernel does (fmm_cart3_kdtree.cuh:874-959) -- here
 	                       without atomics: the second leaf's sums go to fixed-order "reaction" records, bit-reproducible.
@@ -172,6 +173,7 @@ typedef struct nbco_kd_info {
 	                               leaves taken as that many halves of up to 32 particles (opts.p2p_mutual) */
 	long long warm_builds;      /* builds whose median selection ran ONE histogram pass per level around the previous build's pivots */
 	long long warm_misses;      /* .. of which a window missed the median: the evaluation was repeated with the two-pass select */
+	int real_bytes;             /* element size of NBCO_KD_MPOLE / NBCO_KD_LOCAL: 4, or 8 when the tree was built with opts.far_fp64 */
 } nbco_kd_info;
 int nbco_kd_get_info(nbco_ctx *c, nbco_kd_info *info);
 

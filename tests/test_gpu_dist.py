@@ -661,3 +661,23 @@ def test_distributed_repartition_at_8m_particles(oracle32):
     ax = int(torch.argmax(torch.from_numpy(pos.max(0) - pos.min(0))))
     assert float(lo[:, ax].max()) <= float(hi[:, ax].min())
     assert sum(r.partition_bytes for r in b.runs) < sum(r.partition_bytes for r in a.runs)
+
+
+@pytest.mark.parametrize("let", [False, True])
+def test_sharded_far_fp64_equals_single_gpu(oracle32, let):
+    """opts.far_fp64 in the sharded evaluation (G = 4): the exchanged multipole blocks / LET node records are doubles, and the
+    accelerations, the tree order and the double tuples of the own subtree equal the single-GPU far_fp64 evaluation bit for bit"""
+    import torch
+    n, G, p = 32768, 4, 10
+    pos, vel = make_state(oracle32, n, "reference")
+    par = torch.from_numpy(oracle32.params(n)).cuda()
+    opts = dict(fmm_order=p, unsort=0, tree_steps=1, far_fp64=1)
+    e1, ref = single_gpu(n, pos, vel, par, **opts)
+    assert e1.kd_info().real_bytes == 8
+    world = loopback(n, G, pos, vel, **opts)
+    assert int(world.runs[0].lay.mpole_bytes) == int(world.runs[0].lay.ntot_local) * 8 * (p * (p + 1) * (p + 2) // 6)
+    world.force(par, elastic=False, let=let)
+    torch.cuda.synchronize()
+    got = torch.cat([r.buf.view(3, -1, 3) for r in world.runs], dim=1).reshape(-1)
+    assert torch.equal(got, ref)
+    assert bool(torch.isfinite(got).all())

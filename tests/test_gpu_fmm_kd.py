@@ -504,3 +504,94 @@ def test_eight_million_particles_properties(oracle32):
         e2.close()
     assert torch.equal(finals[0], finals[1])
     eng.close()
+
+
+# ---- fp64 far field for the kd-tree evaluator (BASELINE config 5: "fp64 far-field / fp32 P2P"; reference: the -DSCAL=double build,
+#      constants.cuh:22-24, operators fmm_cart_base3.cuh:1181-1208) -------------------------------------------------------------
+@pytest.mark.parametrize("n,p,kind", [(8192, 6, "gauss"), (8192, 10, "gauss"), (20000, 8, "cube"), (4096, 3, "cube")])
+def test_far_fp64_kdtree_against_both_oracles(engine, oracle32, oracle64, n, p, kind):
+    """opts.far_fp64 with nbco_fmm_kdtree: the tree, the permutation and the lists are the fp32 ones, bit for bit (the geometry does
+    not change with the option); the multipole / local tuples are doubles and follow the REAL = double oracle to the rounding of
+    the fp32 centres; the accelerations are within 1e-5 of the double oracle wherever its lists equal the fp32 ones (they differ
+    only when a node pair sits within fp32 rounding of the opening criterion), never further from it than the all-fp32
+    evaluation, and within 1e-5 of the fp32 oracle."""
+    o32, o64 = oracle32, oracle64
+    buf = o32.init_reference(n, test_mode=(kind == "cube"))
+    par = o32.params(n)
+    _, want32 = o32.fmm_kd(buf[:2], par, p=p, threads=8, unsort=True)
+    tree32 = o32.kd_tree()
+    offM, offL = p * (p + 1) * (p + 2) // 6, (p + 1) ** 2
+    _, want64 = o64.fmm_kd(buf[:2].astype(np.float64), par.astype(np.float64), p=p, threads=8, unsort=True)
+    tree64 = o64.kd_tree(offM=offM, offL=offL)
+    _, got32 = run_gpu(engine, buf, par, n, fmm_order=p, unsort=1, far_fp64=0)
+    assert engine.kd_info().real_bytes == 4
+    _, got = run_gpu(engine, buf, par, n, fmm_order=p, unsort=1, far_fp64=1)
+    info = engine.kd_info()
+    assert info.real_bytes == 8 and (info.L, info.ntot) == (tree32["L"], tree32["ntot"])
+    for name in ("index", "mult", "splitdim", "lbound", "rbound", "center"):
+        np.testing.assert_array_equal(engine.kd_array(name), tree32[name], err_msg=name)
+    for name in ("p2p", "m2l"):
+        np.testing.assert_array_equal(canon_pairs(engine.kd_array(name)), canon_pairs(tree32[name]), err_msg=name)
+    mp, lc = engine.kd_array("mpole"), engine.kd_array("local")
+    assert mp.dtype == np.float64 and lc.dtype == np.float64
+    assert np.isfinite(got).all() and np.isfinite(mp).all() and np.isfinite(lc).all()
+    assert force_err(got, want32) < 1e-5
+    same_lists = all(np.array_equal(canon_pairs(tree64[k]), canon_pairs(tree32[k])) for k in ("p2p", "m2l"))
+    if same_lists:
+        e64, e32 = force_err(got, want64), force_err(got32, want64)
+        assert e64 < 1e-5 and e64 < 1.5 * e32 + 2e-7
+        # the tuples differ from the double oracle's by the rounding of the fp32 centres (6e-8 of a coordinate that is ~100 leaf
+        # sizes from the origin), which a term of order k sees k times: 2e-5 up to order 6, 1e-4 at order 10
+        tol = 2e-5 if p <= 6 else 1e-4
+        w = tree64["mpole"]
+        sc = np.abs(w).max(axis=0, keepdims=True).clip(1e-300)
+        assert (np.abs(mp - w) / sc).max() < tol
+        w = tree64["local"]
+        sc = np.abs(w).max(axis=0, keepdims=True).clip(1e-300)
+        assert (np.abs(lc - w) / sc).max() < tol
+    engine.set(far_fp64=0)
+
+
+def test_far_fp64_kdtree_keeps_order_10_in_range_at_a_million_particles(oracle32):
+    """p = 10 at N = 2^20 on the BASELINE ball: the fp32 far field leaves its range (r^-11 19!! ~ 1e40, SURVEY N8: the kd-tree
+    evaluator returns NaN / inf there, as the reference does), the fp64 far field stays finite, follows the fp64 direct sum to the
+    truncation level of the default opening radius, is bit-reproducible, and feeds nbco_energy_fmm."""
+    import torch
+    from coulomb_oscillators_amd import Engine, EVAL_FMM_KDTREE
+    o = oracle32
+    n, p = 1 << 20, 10
+    buf = o.init_reference(n)
+    par = o.params(n)
+    eng = Engine(fmm_order=p, unsort=0, far_fp64=1, sync=0)
+    d = dev(buf)
+    prm = dev(par)
+    eng.fmm_cart3_kdtree(d, d[2], n, prm)
+    torch.cuda.synchronize()
+    assert eng.kd_info().real_bytes == 8
+    a = d[2].clone()
+    assert bool(torch.isfinite(a).all())
+    rows = np.random.default_rng(8).choice(n, 32, replace=False)
+    P64 = d[0].double()
+    want = np.empty((len(rows), 3))
+    for k, i in enumerate(rows):
+        dd = P64[int(i)] - P64
+        w = ((dd * dd).sum(1) + 1e-18) ** -1.5
+        w[int(i)] = 0
+        want[k] = (dd * w[:, None]).sum(0).cpu().numpy() * float(par[0])
+    got = a.cpu().numpy().astype(np.float64)[rows]
+    rel = np.linalg.norm(got - want, axis=1) / (np.linalg.norm(want, axis=1) + np.linalg.norm(want, axis=1).mean())
+    assert np.median(rel) < 2e-3 and rel.max() < 3e-2, (np.median(rel), rel.max())     # p = 10 at the default radius (p = 6: 6e-3)
+    e = eng.energy_fmm(d, n, prm)
+    assert np.isfinite(e).all() and e[2] > 0
+    d2 = dev(buf)
+    eng2 = Engine(fmm_order=p, unsort=0, far_fp64=1, sync=0)
+    eng2.fmm_cart3_kdtree(d2, d2[2], n, prm)
+    torch.cuda.synchronize()
+    assert torch.equal(d2[2], a)
+    # the all-fp32 far field at this order and size: out of range
+    eng2.set(far_fp64=0)
+    d3 = dev(buf)
+    eng2.fmm_cart3_kdtree(d3, d3[2], n, prm)
+    torch.cuda.synchronize()
+    assert not bool(torch.isfinite(d3[2]).all())
+    eng.close(); eng2.close()

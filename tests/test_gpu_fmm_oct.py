@@ -254,22 +254,6 @@ def test_far_fp64_keeps_high_orders_in_range(engine, oracle32):
     engine.set(dens_inhom=1.0)
 
 
-def test_far_fp64_is_rejected_by_the_kdtree_evaluator(engine, oracle32):
-    import torch
-    from coulomb_oscillators_amd import EngineError
-    n = 4096
-    buf = state(oracle32, n, "cube")
-    d = dev(buf[:2])
-    a = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
-    engine.set(far_fp64=1)
-    with pytest.raises(EngineError):
-        engine.fmm_cart3_kdtree(d, a, n, None)
-    engine.set(far_fp64=0)
-    engine.fmm_cart3_kdtree(d, a, n, None)
-    torch.cuda.synchronize()
-    assert bool(torch.isfinite(a).all())
-
-
 # ---- the octree evaluator with SYMMETRIC multipoles, `fmm_cart3` (fmm_cart3_symmetric.cuh:413-580) ----------------------------
 @pytest.mark.parametrize("n,p,kind", [(4096, 6, "cube"), (4096, 6, "gauss"), (30001, 5, "blob"), (5000, 8, "cube"), (20000, 4, "blob"),
                                       (700, 3, "cube"), (3000, 1, "blob"), (3000, 2, "blob"), (8000, 9, "blob")])

@@ -1,5 +1,5 @@
 """Alternating A/B runs of bench.py under different environments on ONE box (the boxes of the pool differ by ~1 %):
-    python tools/ab_env.py [--rounds 3] [--bench-args "..."] "label=ENV1=v,ENV2=w" "label2=" ...
+    python tools/ab_env.py [--rounds 3] [--bench-args "..."] "label=ENV1=v;ENV2=w" "label2=" ...
 Each variant is run once per round, in turn; prints ms_per_step (median repeat), the near-field launch time and the tree-reuse figure."""
 import json
 import os
@@ -22,7 +22,7 @@ def main():
     variants = []
     for a in args:
         label, _, envs = a.partition("=")
-        env = dict(kv.split("=", 1) for kv in envs.split(",") if kv) if envs else {}
+        env = dict(kv.split("=", 1) for kv in envs.split(";") if kv) if envs else {}
         variants.append((label, env))
     res = {label: [] for label, _ in variants}
     for r in range(rounds):

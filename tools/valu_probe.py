@@ -187,6 +187,26 @@ for q in range(4):
     _t += _with_reads(good_pair(0, 1) + good_pair(2, 3), 48 * q)
 add("tile_2way_lds", _t, flop=320, pairs=16, n=192)
 
+# ---- what does a v_rsq_f32 cost inside a stream of other vector instructions?  N independent v_fma per v_rsq, and the same
+#      number of v_rsq issued back to back behind the v_fma (pairs = v_rsq count, so that the rate column counts them) ----------
+for nf in (2, 4, 8, 12, 24, 48):
+    groups = max(1, 48 // nf)
+    lines = []
+    for g in range(groups):
+        lines += [f"v_fma_f32 v{16 + 2 * ((g * nf + k) % 20)}, v{16 + 2 * ((g * nf + k) % 20)}, v1, v3" for k in range(nf)]   # even acc, odd operands
+        lines.append(f"v_rsq_f32 v{5 + 2 * (g % 4)}, v{7 + 2 * (g % 4)}")
+    add(f"mix_fma{nf}_rsq1", lines, flop=2 * nf * groups, pairs=groups)
+add("mix_fma48_rsq4_batched", [f"v_fma_f32 v{16 + 2 * (k % 20)}, v{16 + 2 * (k % 20)}, v1, v3" for k in range(48)] + [f"v_rsq_f32 v{5 + 2 * g}, v{7 + 2 * g}" for g in range(4)],
+    flop=96, pairs=4)
+add("mix_fma48_only", [f"v_fma_f32 v{16 + 2 * (k % 20)}, v{16 + 2 * (k % 20)}, v1, v3" for k in range(48)], flop=96)
+add("mix_rsq16_only", [f"v_rsq_f32 v{16 + 2 * (k % 20)}, v{7 + 2 * (k % 4)}" for k in range(16)], pairs=16)
+# the pair loop with its v_rsq replaced by a move: what the other eleven instructions cost where they stand
+add("tile_2way_norsq", [l.replace("v_rsq_f32", "v_mov_b32") for l in good_pair(0, 1) + good_pair(2, 3)], flop=80, pairs=4)
+# other transcendental / quarter-rate candidates in the same mix
+add("mix_fma12_rcp1", [l.replace("v_rsq_f32", "v_rcp_f32") for l in (lambda: [x for g in range(4) for x in ([f"v_fma_f32 v{16 + 2 * ((g * 12 + k) % 20)}, v{16 + 2 * ((g * 12 + k) % 20)}, v1, v3" for k in range(12)] + [f"v_rsq_f32 v{5 + 2 * g}, v{7 + 2 * g}"])])()], flop=96, pairs=4)
+add("mix_fma12_sqrt1", [l.replace("v_rsq_f32", "v_sqrt_f32") for l in (lambda: [x for g in range(4) for x in ([f"v_fma_f32 v{16 + 2 * ((g * 12 + k) % 20)}, v{16 + 2 * ((g * 12 + k) % 20)}, v1, v3" for k in range(12)] + [f"v_rsq_f32 v{5 + 2 * g}, v{7 + 2 * g}"])])()], flop=96, pairs=4)
+add("mix_fma12_rsqf16", [l.replace("v_rsq_f32", "v_rsq_f16") for l in (lambda: [x for g in range(4) for x in ([f"v_fma_f32 v{16 + 2 * ((g * 12 + k) % 20)}, v{16 + 2 * ((g * 12 + k) % 20)}, v1, v3" for k in range(12)] + [f"v_rsq_f32 v{5 + 2 * g}, v{7 + 2 * g}"])])()], flop=96, pairs=4)
+
 HEADER = r"""// generated by tools/valu_probe.py -- do not edit
 #include <hip/hip_runtime.h>
 #include <cstdio>
