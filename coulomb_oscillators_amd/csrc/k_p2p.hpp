@@ -167,6 +167,8 @@ static void launch_p2p(nbco_ctx *c, const float4 *pos, const int2 *desc, const i
                        int stride, float4 *partial, long long npos)
 {
 	const int grid = (int)std::max<long long>(1, (chunks_hint + kP2PWaves - 1) / kP2PWaves);
+	// (Six workgroups per CU, i.e. six waves per SIMD: capping them at five / four / three with unused LDS -- to leave the far-field
+	// chain on the second stream more of a SIMD's registers -- made the step 1 / 2 / 5 % slower, profiles/r03c_ab_ldspad.txt)
 	hipLaunchKernelGGL(p2p_kernel<TPL>, dim3(grid), dim3(64 * kP2PWaves), 0, c->stream, pos, desc, chunk, ntotal, c->o.eps2, src_max, stride, partial, (int)npos);
 }
 

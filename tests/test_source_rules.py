@@ -12,7 +12,9 @@ CSRC = os.path.join(ROOT, "coulomb_oscillators_amd", "csrc")
 
 # functions whose float arithmetic decides integers (tree structure, list membership)
 MUST_NOT_CONTRACT = {
-    "k_fmm_kd.hip": ["kd_admissible", "kd_admissible_rec", "longest_axis", "parent_centre"],
+    "kd_build_kernels.hpp": ["kd_admissible", "longest_axis", "parent_centre"],      # (sections of k_fmm_kd.hip, included there)
+    "kd_traverse_kernels.hpp": ["kd_admissible_rec"],
+    "k_farfield.hip": ["parent_centre", "centre_of"],
     "k_kdselect.hip": ["ties_and_boxes"],
     "k_fmm_oct.hip": ["oct_scalars_kernel", "oct_keys_kernel"],
     "k_dpart.hip": ["dp_root_kernel", "dp_boxes_kernel"],
