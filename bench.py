@@ -334,7 +334,20 @@ def cli_dist_leg(gpus, n_system, order, iters, tree_steps, rebalance):
     with tempfile.TemporaryDirectory() as tmp:
         cmd = [exe, "-gpus", str(gpus), "-n", str(n_system), "-p", str(order), "-iters", str(iters), "-steps", "100000", "-tree-steps", str(tree_steps),
                "-rebalance", str(rebalance), "-o", tmp]
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        # its own process group and a short leash: should the ranks hang in a collective that the supervisor cannot see (it only
+        # sees exits), the whole group is killed and the leg says so -- an extra leg must not take the line down
+        import signal
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            so, se = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)
+            p.communicate()
+            return {"error": "nbco3_dist did not finish within 240 s (killed)", "command": " ".join(["nbco3_dist"] + cmd[1:-2])}
+
+        class _R:
+            returncode, stdout, stderr = p.returncode, so, se
+        r = _R
     if r.returncode != 0:
         return {"error": (r.stderr or r.stdout)[-300:], "status": r.returncode}
     m = re.search(r"Loop time: ([0-9.eE+-]+) s, (\d+) iterations, (\d+) ranks, partition fallbacks (\d+)", r.stdout)

@@ -799,4 +799,80 @@ int nbco_init_gaussian(float *host_state, long long n, const float *sx, const fl
 	return NBCO_OK;
 }
 
+// The rows [first, first + count) of the state nbco_init_gaussian(n, ..) would produce, without ever holding more than the slice:
+// the generator is run through the whole stream twice (the centring and the RMS rescaling need sums over ALL n particles, taken
+// in the same order and precision as there), so the result equals the corresponding rows of the full state bit for bit.
+int nbco_init_gaussian_slice(float *host_slice, long long n, long long first, long long count, const float *sx, const float *su,
+                             unsigned long long seed, unsigned long long discard, int uniform_positions)
+{
+	if (!host_slice || !sx || !su || n <= 0 || first < 0 || count <= 0 || first + count > n) return NBCO_ERR_ARG;
+	V3 *pos = reinterpret_cast<V3 *>(host_slice), *vel = pos + count;
+	const V3 sc[2] = {{sx[0], sx[1], sx[2]}, {su[0], su[1], su[2]}};
+	V3 mean[2], fac[2];
+	// pass 1: the scaled deviates of the slice, and the running sums of centre_dist
+	{
+		std::mt19937_64 gen(seed);
+		gen.discard(discard);
+		std::normal_distribution<float> dist(0.f, 1.f);
+		for (int part = 0; part < 2; ++part)
+		{
+			V3 *out = part ? vel : pos;
+			V3 c{0, 0, 0};
+			for (long long i = 0; i < n; ++i)
+			{
+				V3 v;
+				v.x = dist(gen); v.y = dist(gen); v.z = dist(gen);
+				v.x *= sc[part].x; v.y *= sc[part].y; v.z *= sc[part].z;
+				c.x += v.x; c.y += v.y; c.z += v.z;
+				if (i >= first && i < first + count) out[i - first] = v;
+			}
+			mean[part] = V3{c.x / (float)n, c.y / (float)n, c.z / (float)n};
+		}
+	}
+	// pass 2: the sums of squares of the centred values (adjust_rms)
+	{
+		std::mt19937_64 gen(seed);
+		gen.discard(discard);
+		std::normal_distribution<float> dist(0.f, 1.f);
+		for (int part = 0; part < 2; ++part)
+		{
+			V3 s{0, 0, 0};
+			for (long long i = 0; i < n; ++i)
+			{
+				V3 v;
+				v.x = dist(gen); v.y = dist(gen); v.z = dist(gen);
+				v.x *= sc[part].x; v.y *= sc[part].y; v.z *= sc[part].z;
+				v.x -= mean[part].x; v.y -= mean[part].y; v.z -= mean[part].z;
+				s.x += v.x * v.x; s.y += v.y * v.y; s.z += v.z * v.z;
+			}
+			s.x = std::sqrt(s.x / (float)n); s.y = std::sqrt(s.y / (float)n); s.z = std::sqrt(s.z / (float)n);
+			fac[part] = V3{sc[part].x / s.x, sc[part].y / s.y, sc[part].z / s.z};
+		}
+		for (int part = 0; part < 2; ++part)
+		{
+			V3 *out = part ? vel : pos;
+			for (long long i = 0; i < count; ++i)
+			{
+				out[i].x -= mean[part].x; out[i].y -= mean[part].y; out[i].z -= mean[part].z;
+				out[i].x *= fac[part].x; out[i].y *= fac[part].y; out[i].z *= fac[part].z;
+			}
+		}
+		if (uniform_positions)   // initU: the generator goes on behind the 6 n normal deviates
+		{
+			std::uniform_real_distribution<float> dx(-1, 1), dy(-1, 1), dz(-1, 1);
+			V3 c{0, 0, 0};
+			for (long long i = 0; i < n; ++i)
+			{
+				V3 v;
+				v.x = dx(gen); v.y = dy(gen); v.z = dz(gen);
+				c.x += v.x; c.y += v.y; c.z += v.z;
+				if (i >= first && i < first + count) pos[i - first] = v;
+			}
+			c.x /= (float)n; c.y /= (float)n; c.z /= (float)n;
+			for (long long i = 0; i < count; ++i) { pos[i].x -= c.x; pos[i].y -= c.y; pos[i].z -= c.z; }
+		}
+	}
+	return NBCO_OK;
+}
+
 } // extern "C"

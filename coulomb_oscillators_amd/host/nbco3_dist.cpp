@@ -264,14 +264,15 @@ int run_rank(const Args &a, int rank, const ncclUniqueId &id)
 	r.check(nbco_dist_layout_query(r.ctx, a.n, a.gpus, rank, &r.lay), "nbco_dist_layout_query");
 	const long long N = a.n, nl = r.lay.n_local;
 
-	// every rank samples the same initial state (the reference's stream) and starts out owning a contiguous slice of it
-	std::vector<float> host(6 * (size_t)N);
+	// every rank draws ITS rows of the one initial state (the reference's stream; rank r starts out owning rows [r nl, (r + 1) nl)):
+	// two passes through the generator, never more than the slice in memory (nbco_init_gaussian_slice)
+	std::vector<float> host(6 * (size_t)nl);
 	const float sx[3] = {0.003f, 0.001f, 0.01f}, su[3] = {1.095f * 0.003f, 0.001f, 0.01f};
-	if (nbco_init_gaussian(host.data(), N, sx, su, NBCO_REF_SEED, NBCO_REF_DISCARD, 0) != NBCO_OK) return -1;
+	if (nbco_init_gaussian_slice(host.data(), N, (long long)rank * nl, nl, sx, su, NBCO_REF_SEED, NBCO_REF_DISCARD, 0) != NBCO_OK) return -1;
 	if (const char *q = getenv("NBCO3_DIST_QUANTISE"))   // test hook: positions on a lattice (many exact ties with every pivot)
 	{
 		const float step = (float)atof(q);
-		if (step > 0) for (size_t i = 0; i < 3 * (size_t)N; ++i) host[i] = step * std::nearbyint(host[i] / step);
+		if (step > 0) for (size_t i = 0; i < 3 * (size_t)nl; ++i) host[i] = step * std::nearbyint(host[i] / step);
 	}
 	const float parh[6] = {a.xi / (float)N, 0, 0, 1.095f * 1.095f, 1.f, 1.f};
 	HIPCHK(hipMalloc((void **)&r.buf, sizeof(float) * 9 * (size_t)nl));
@@ -299,8 +300,8 @@ int run_rank(const Args &a, int rank, const ncclUniqueId &id)
 	HIPCHK(hipMalloc((void **)&r.pos_all, (size_t)r.lay.pos_bytes * a.gpus));
 	HIPCHK(hipMalloc((void **)&r.nodes_all, (size_t)r.lay.nodes_bytes * a.gpus));
 	HIPCHK(hipMemset(r.buf, 0, sizeof(float) * 9 * (size_t)nl));
-	HIPCHK(hipMemcpy(r.buf, host.data() + 3 * (size_t)rank * nl, sizeof(float) * 3 * nl, hipMemcpyHostToDevice));
-	HIPCHK(hipMemcpy(r.buf + 3 * nl, host.data() + 3 * (size_t)N + 3 * (size_t)rank * nl, sizeof(float) * 3 * nl, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(r.buf, host.data(), sizeof(float) * 6 * nl, hipMemcpyHostToDevice));   // [pos nl | vel nl]
+	host = std::vector<float>();
 	HIPCHK(hipMemcpy(r.par, parh, sizeof parh, hipMemcpyHostToDevice));
 
 	r.partition();

@@ -376,6 +376,12 @@ int nbco_debug_violations(nbco_ctx *c, long long *out8);
 #define NBCO_REF_DISCARD 1248ULL
 int nbco_init_gaussian(float *host_state, long long n, const float *sigma_x3, const float *sigma_u3,
                        unsigned long long seed, unsigned long long discard, int uniform_positions);
+/* Rows [first, first + count) of that state -- host_slice = [pos count x 3 | vel count x 3] -- bit for bit, without holding more
+ * than the slice: the generator runs through the whole stream twice (the centring and the RMS rescaling of main3.cu:71-92 are
+ * sums over all n particles).  What a rank of a multi-GPU run calls to draw its share of a system that fits no single host buffer
+ * comfortably (N = 64M: 1.5 GB for the full state). */
+int nbco_init_gaussian_slice(float *host_slice, long long n, long long first, long long count, const float *sigma_x3,
+                             const float *sigma_u3, unsigned long long seed, unsigned long long discard, int uniform_positions);
 
 #ifdef __cplusplus
 }
