@@ -16,6 +16,7 @@
 #include <cmath>
 #include <vector>
 #include <map>
+#include <array>
 #include <string>
 #include <algorithm>
 #include <unistd.h>
@@ -223,6 +224,85 @@ int main(int argc, char **argv)
 			CHK(hipMemcpy(hs.data(), cst, sizeof(lab::WaveStamp) * d.chunks, hipMemcpyDeviceToHost));
 			lab::timeline_report(hs, steps_of, nullptr, cand.name);
 		}
+	}
+	// ---- (5) the order in which the work units are dispatched --------------------------------------------------------------
+	// The library dispatches them in target order; the tail of the launch (timeline above) is as long as the last waves live.
+	// Same kernel, same units, other orders: longest first (what a sort by size would give) and full units first, remainders
+	// behind them in target order (what two output regions of the unit table would give, no sort).
+	{
+		int4 *chunk2;
+		CHK(hipMalloc(&chunk2, sizeof(int4) * d.chunks));
+		auto run_order = [&](const char *name, const char *note, const std::vector<int> &order) {
+			std::vector<int4> perm(d.chunks);
+			for (long long i = 0; i < d.chunks; ++i) perm[i] = d.chunk[order[i]];
+			CHK(hipMemcpy(chunk2, perm.data(), sizeof(int4) * d.chunks, hipMemcpyHostToDevice));
+			auto go = [&]() { hipLaunchKernelGGL(p2p_kernel<32>, dim3(grid), dim3(64 * kP2PWaves), 0, 0, (const float4 *)pos, (const int2 *)desc, (const int4 *)chunk2, (const int *)total, eps2, src_max, stride, partial2, npos); };
+			CHK(hipMemset(partial2, 0, sizeof(float4) * d.chunks * d.stride));
+			go();
+			CHK(hipDeviceSynchronize());
+			fetch(partial2, got);
+			std::vector<float4> back(got.size());
+			for (long long i = 0; i < d.chunks; ++i)
+				for (long long t = 0; t < d.stride; ++t) back[(size_t)order[i] * d.stride + t] = got[(size_t)i * d.stride + t];
+			compare(ref, back, mr, nb);
+			report(name, time_bursts(go), mr, nb, note);
+		};
+		std::vector<int> order(d.chunks);
+		for (long long i = 0; i < d.chunks; ++i) order[i] = (int)i;
+		std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return steps_of[x] > steps_of[y]; });
+		run_order("units longest first", "production kernel, unit table sorted by size", order);
+		std::vector<int> two;
+		long long full = 0;
+		for (long long i = 0; i < d.chunks; ++i) full = std::max(full, steps_of[i]);
+		for (long long i = 0; i < d.chunks; ++i) if (steps_of[i] == full) two.push_back((int)i);
+		for (long long i = 0; i < d.chunks; ++i) if (steps_of[i] != full) two.push_back((int)i);
+		run_order("full units first", "production kernel, full units then remainders in target order", two);
+		std::vector<int> rev(d.chunks);
+		for (long long i = 0; i < d.chunks; ++i) rev[i] = order[d.chunks - 1 - i];
+		run_order("units shortest first", "the wrong way round, for contrast", rev);
+		CHK(hipFree(chunk2));
+	}
+	// ---- (6) equal shares: a target's entries dealt evenly over its units (17 entries -> 9 + 8 instead of 16 + 1) ----------------
+	{
+		// per target (first particle): entry range and particle count, from the dumped units (a target's units are consecutive)
+		std::vector<int4> eq;
+		for (long long c = 0; c < d.chunks;)
+		{
+			long long e = c;
+			while (e + 1 < d.chunks && d.chunk[e + 1].x == d.chunk[c].x) ++e;
+			const int y = d.chunk[c].y, z = d.chunk[e].z, cnt = z - y, n = (int)(e - c + 1);
+			const int per = (cnt + n - 1) / n;
+			for (int k = 0; k < n; ++k) eq.push_back(make_int4(d.chunk[c].x, std::min(y + k * per, z), std::min(y + (k + 1) * per, z), d.chunk[c].w));
+			c = e + 1;
+		}
+		int4 *chunk3;
+		CHK(hipMalloc(&chunk3, sizeof(int4) * eq.size()));
+		CHK(hipMemcpy(chunk3, eq.data(), sizeof(int4) * eq.size(), hipMemcpyHostToDevice));
+		auto go = [&]() { hipLaunchKernelGGL(p2p_kernel<32>, dim3(grid), dim3(64 * kP2PWaves), 0, 0, (const float4 *)pos, (const int2 *)desc, (const int4 *)chunk3, (const int *)total, eps2, src_max, stride, partial2, npos); };
+		CHK(hipMemset(partial2, 0, sizeof(float4) * d.chunks * d.stride));
+		go();
+		CHK(hipDeviceSynchronize());
+		fetch(partial2, got);
+		// per-target totals (double) of both unit tables
+		std::map<int, std::array<double, 3>> tot_ref, tot_got;
+		double scale = 0, worst = 0;
+		for (long long c = 0; c < d.chunks; ++c)
+			for (int t = 0; t < d.chunk[c].w; ++t)
+			{
+				auto &a = tot_ref[d.chunk[c].x + t]; const float4 v = ref[c * d.stride + t]; a[0] += v.x; a[1] += v.y; a[2] += v.z;
+				auto &b = tot_got[eq[c].x + t]; const float4 w = got[c * d.stride + t]; b[0] += w.x; b[1] += w.y; b[2] += w.z;
+			}
+		for (auto &kv : tot_ref) scale += std::sqrt(kv.second[0] * kv.second[0] + kv.second[1] * kv.second[1] + kv.second[2] * kv.second[2]);
+		scale /= (double)tot_ref.size();
+		for (auto &kv : tot_ref)
+		{
+			const auto &b = tot_got[kv.first];
+			const double du = std::sqrt((kv.second[0] - b[0]) * (kv.second[0] - b[0]) + (kv.second[1] - b[1]) * (kv.second[1] - b[1]) + (kv.second[2] - b[2]) * (kv.second[2] - b[2]));
+			const double m = std::sqrt(kv.second[0] * kv.second[0] + kv.second[1] * kv.second[1] + kv.second[2] * kv.second[2]);
+			worst = std::max(worst, du / (m + scale));
+		}
+		report("equal shares", time_bursts(go), worst, -1, "production kernel, a target's entries dealt evenly over its units (per-particle totals compared)");
+		CHK(hipFree(chunk3));
 	}
 	if (js) { fprintf(js, "\n]}\n"); fclose(js); }
 	return 0;
