@@ -350,12 +350,12 @@ def cli_dist_leg(gpus, n_system, order, iters, tree_steps, rebalance):
         r = _R
     if r.returncode != 0:
         return {"error": (r.stderr or r.stdout)[-300:], "status": r.returncode}
-    m = re.search(r"Loop time: ([0-9.eE+-]+) s, (\d+) iterations, (\d+) ranks, partition fallbacks (\d+)", r.stdout)
+    m = re.search(r"Loop time: ([0-9.eE+-]+) s, (\d+) iterations, (\d+) ranks, partition fallbacks (\d+), capped evaluations (\d+), repeated (\d+)", r.stdout)
     if not m:
         return {"error": "no loop time in the output"}
     per_iter = float(m.group(1)) / int(m.group(2))
     return {"command": " ".join(["nbco3_dist"] + cmd[1:-2]), "loop_s": float(m.group(1)), "iterations": int(m.group(2)), "ranks": int(m.group(3)),
-            "partition_fallbacks": int(m.group(4)), "ms_per_step": 1e3 * per_iter, "value": n_system / per_iter, "unit": "particle-steps/s"}
+            "partition_fallbacks": int(m.group(4)), "let_capped_evals": int(m.group(5)), "let_redos": int(m.group(6)), "ms_per_step": 1e3 * per_iter, "value": n_system / per_iter, "unit": "particle-steps/s"}
 
 
 def main():
@@ -549,6 +549,9 @@ def main():
         if sharded:
             extra.update({"n_system": n_sys, "rebalance_every": args.rebalance,
                           "exchange": "LET (all-gather of traversal records + variable all-to-all)" if run.let else "all-gather",
+                          # evaluations of this run (last repeat) in the capped form -- segments sized from the evaluation before, no host
+                          # round trip in the middle -- and capped attempts that were void and repeated in the exact form
+                          "let_capped_evals": getattr(run, "let_capped_evals", 0), "let_redos": getattr(run, "let_redos", 0),
                           "partition": "distributed selection + all-to-all of the movers" if run.dpart else "all-gather of the state + redundant selection",
                           "partition_bytes_per_gpu": run.partition_bytes,
                           "exchange_bytes_per_eval_per_gpu": run.exchange_bytes(),

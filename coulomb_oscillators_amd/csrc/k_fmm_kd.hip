@@ -35,6 +35,7 @@
 #include <functional>
 #include <cmath>
 #include <algorithm>
+#include <vector>
 
 namespace {
 
@@ -378,7 +379,7 @@ static int kd_build_upward(nbco_ctx *c, const float *p, long long n, int L, cons
 
 // LET exchange of the sharded evaluation (see "Locally-essential-tree exchange" below): what has arrived, per global node / leaf
 struct LetHave { const unsigned char *node, *leaf; };
-constexpr int kLetWord = 16;   // h_flags[16], [17]: the guard's two words
+constexpr int kLetWord = 16;   // h_flags[16..19]: the guard's two words, one pair per parity of the attempt (DistState::let_epoch)
 // every source of a sorted directed list (key = target << shift | source) must have arrived; host_word = 1 + a missing id
 __global__ __launch_bounds__(kBlock) void let_guard_kernel(const uint64_t *__restrict__ keys, const int *__restrict__ total, int shift,
                                                            const unsigned char *__restrict__ have, int *__restrict__ host_word)
@@ -395,7 +396,8 @@ __global__ __launch_bounds__(kBlock) void let_guard_kernel(const uint64_t *__res
 }
 static int launch_let_guard(nbco_ctx *c, const uint64_t *keys, const int *total, int shift, const unsigned char *have, int word, long long hint)
 {
-	hipLaunchKernelGGL(let_guard_kernel, dim3(grid1d(hint, 2048)), dim3(kBlock), 0, c->stream, keys, total, shift, have, c->h_flags + kLetWord + word);
+	hipLaunchKernelGGL(let_guard_kernel, dim3(grid1d(hint, 2048)), dim3(kBlock), 0, c->stream, keys, total, shift, have,
+	                   c->h_flags + kLetWord + 2 * (int)(c->dist.let_epoch & 1) + word);
 	NBCO_HIP(hipGetLastError());
 	return NBCO_OK;
 }

@@ -119,7 +119,8 @@ __global__ __launch_bounds__(kBlock) void let_pack_mpole_kernel(const T *__restr
                                                                 T *__restrict__ out)
 {
 	const int r = blockIdx.y;
-	const long long total = (long long)cursors[4 * r] * rec;
+	// (the segment holds exactly cursors[4 r] records, or -- capped form -- what the caller sized it for: records beyond are dropped)
+	const long long total = std::min((long long)cursors[4 * r], nb.v[r + 1] - nb.v[r]) * rec;
 	for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock)
 	{
 		const int comp = (int)(i % rec), slot = (int)(i / rec);
@@ -136,16 +137,31 @@ __global__ __launch_bounds__(kBlock) void let_pack_pos_kernel(const float4 *__re
                                                               const int *__restrict__ cursors, LetBases pb, float4 *__restrict__ out)
 {
 	const int r = blockIdx.y;
-	const long long total = (long long)cursors[4 * r + 1] << wlog;
+	const long long total = (long long)cursors[4 * r + 1] << wlog, room = pb.v[r + 1] - pb.v[r];
 	for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock)
 	{
 		const int j = (int)(i & ((1 << wlog) - 1));
 		const int2 sl = sel_leaf[((size_t)r << L_loc) + (i >> wlog)];
-		if (j >= mult[sl.x]) continue;
+		if (j >= mult[sl.x] || sl.y + j >= room) continue;
 		const int q = index[sl.x] + j;
 		float4 p = pos[q];
 		p.w = __int_as_float((int)(first_global + q));
 		out[pb.v[r] + sl.y + j] = p;
+	}
+}
+// capped form: the records of a segment nobody filled say so (node id / particle index -1; the unpack kernels skip them)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void let_pad_kernel(const int *__restrict__ cursors, LetBases nb, LetBases pb, int rec, T *__restrict__ mp_out,
+                                                         float4 *__restrict__ pos_out)
+{
+	const int r = blockIdx.y;
+	const long long ncap = nb.v[r + 1] - nb.v[r], pcap = pb.v[r + 1] - pb.v[r];
+	const long long n0 = std::min((long long)cursors[4 * r], ncap), p0 = std::min((long long)cursors[4 * r + 2], pcap);
+	const long long nfree = ncap - n0, total = nfree + (pcap - p0);
+	for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += (long long)gridDim.x * kBlock)
+	{
+		if (i < nfree) mp_out[(nb.v[r] + n0 + i) * rec] = let_id_enc(-1, T());
+		else pos_out[pb.v[r] + p0 + (i - nfree)] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
 	}
 }
 __global__ __launch_bounds__(kBlock) void let_unpack_pos_kernel(const float4 *__restrict__ rec, long long count, float4 *__restrict__ pos_all, long long n_global,
@@ -191,11 +207,21 @@ int let_rec_floats(int offM) { return ((offM + 1 + 3) / 4) * 4; }
 
 // what the guard of the evaluation before reported (the caller has synchronised since: it holds counts that the kernels queued
 // behind that evaluation produced)
-int let_report(nbco_ctx *c)
+// settled_only: the last attempt's kernels may still be running (capped form: the caller has waited for its counts, not for
+// its end) -- look at the pair of the attempt before only
+int let_report(nbco_ctx *c, bool settled_only = false)
 {
-	volatile int *w = c->h_flags + kLetWord;
-	const int node = w[0], leaf = w[1];
-	w[0] = 0; w[1] = 0;
+	int node = 0, leaf = 0;
+	for (int par = 0; par < 2; ++par)
+	{
+		if (settled_only && par != (int)(c->dist.let_epoch & 1)) continue;   // (the last attempt was let_epoch - 1)
+		volatile int *w = c->h_flags + kLetWord + 2 * par;
+		const int wn = w[0], wl = w[1];
+		w[0] = 0; w[1] = 0;
+		if (c->dist.let_ignore[par]) { c->dist.let_ignore[par] = false; continue; }   // an attempt the caller has repeated since
+		if (!node) node = wn;
+		if (!leaf) leaf = wl;
+	}
 	if (node || leaf)
 	{
 		char msg[200];
@@ -278,37 +304,37 @@ int kd_dist_let_select(nbco_ctx *c, const void *csz_all, long long *counts)
 	return NBCO_OK;
 }
 
-// counts_all (host): the all-gathered counts, [sender][2 world + 2].  Fills the two send buffers: for receiver r (rank order)
-// counts_all[me][2 r + 1] position records of 16 bytes, counts_all[me][2 r] node records of let_node_bytes.
-int kd_dist_let_pack(nbco_ctx *c, const long long *counts_all, void *pos_send, void *mpole_send)
+// the two send buffers: for receiver r (rank order) room[2 r + 1] position records of 16 bytes, room[2 r] node records of
+// let_node_bytes.  capped: the segments are what the caller sized them for, not what was selected -- records that do not fit
+// are dropped, free records are marked invalid.
+static int let_pack_segments(nbco_ctx *c, const nbco_dist_layout &lay, const long long *room, void *pos_send, void *mpole_send, bool capped)
 {
-	if (!c->dist.let_selected || !c->dist.local_done) return c->fail(NBCO_ERR_ARG, "nbco_dist_let_pack: selection or multipoles missing");
-	NBCO_TRY(let_report(c));
-	nbco_dist_layout lay;
-	NBCO_TRY(kd_dist_layout(c, c->dist.n_global, c->dist.world, c->dist.rank, &lay));
-	const int G = lay.world, S = 2 * G + 2, offM = sym_off(lay.order), rec = let_rec_floats(offM);
-	for (int s = 0; s < G; ++s)
-	{
-		if (counts_all[(size_t)s * S + 2 * G]) return c->fail(NBCO_ERR_CAPACITY, "nbco_dist_let_pack: a rank reported list overflow; repeat nbco_dist_let_select on every rank");
-		if (counts_all[(size_t)s * S + 2 * G + 1])
-			return c->fail(NBCO_ERR_CAPACITY, "nbco_dist_let_pack: a rank's tree build was flagged; repeat the evaluation from nbco_dist_let_local_geom on every rank");
-	}
-	if (c->sel_warm_used && c->dist.rebuilt) c->note_warm_ok();
-	const long long *mine = counts_all + (size_t)lay.rank * S;
+	const int G = lay.world, offM = sym_off(lay.order), rec = let_rec_floats(offM);
 	LetBases nb{}, pb{};
 	long long nmax = 0, lmax = 0;
 	for (int r = 0; r < G; ++r)
 	{
-		nb.v[r + 1] = nb.v[r] + mine[2 * r];
-		pb.v[r + 1] = pb.v[r] + mine[2 * r + 1];
-		nmax = std::max(nmax, mine[2 * r]);
-		lmax = std::max(lmax, mine[2 * r + 1]);
+		if (room[2 * r] < 0 || room[2 * r + 1] < 0 || (r == lay.rank && (room[2 * r] || room[2 * r + 1])))
+			return c->fail(NBCO_ERR_ARG, "nbco_dist_let_pack: negative segment size, or a segment for the own rank");
+		nb.v[r + 1] = nb.v[r] + room[2 * r];
+		pb.v[r + 1] = pb.v[r] + room[2 * r + 1];
+		nmax = std::max(nmax, room[2 * r]);
+		lmax = std::max(lmax, room[2 * r + 1]);
 	}
+	if ((nb.v[G] > 0 && !mpole_send) || (pb.v[G] > 0 && !pos_send)) return c->fail(NBCO_ERR_ARG, "nbco_dist_let_pack: null send buffer");
 	LetView v;
 	NBCO_TRY(let_view(c, lay, v));
 	int wlog = 0;
 	while ((1 << wlog) < c->kd.mlt_max) ++wlog;
 	PhaseScope ph(c, NBCO_PH_P2M_M2M);
+	const bool f64 = c->kd.real_bytes == 8;
+	if (capped && nmax + lmax > 0)
+	{
+		if (f64) hipLaunchKernelGGL(let_pad_kernel<double>, dim3(grid1d(nmax + lmax, 256), G), dim3(kBlock), 0, c->stream, (const int *)v.cursors, nb, pb, rec,
+		                            (double *)mpole_send, (float4 *)pos_send);
+		else hipLaunchKernelGGL(let_pad_kernel<float>, dim3(grid1d(nmax + lmax, 256), G), dim3(kBlock), 0, c->stream, (const int *)v.cursors, nb, pb, rec,
+		                        (float *)mpole_send, (float4 *)pos_send);
+	}
 	if (lmax > 0)   // (an upper bound of the lane count: every selected leaf holds at least one particle)
 		hipLaunchKernelGGL(let_pack_pos_kernel, dim3(grid1d(lmax << wlog, 2048), G), dim3(kBlock), 0, c->stream, (const float4 *)c->pos4.as<float4>(),
 		                   (const int *)c->kd.index, (const int *)c->kd.mult, lay.L_local, wlog, (long long)lay.rank * lay.n_local, (const int2 *)v.sel_leaf,
@@ -316,7 +342,7 @@ int kd_dist_let_pack(nbco_ctx *c, const long long *counts_all, void *pos_send, v
 	NBCO_TRY(c->join_aux());   // the upward pass
 	if (nmax > 0)
 	{
-		if (c->kd.real_bytes == 8)
+		if (f64)
 			hipLaunchKernelGGL(let_pack_mpole_kernel<double>, dim3(grid1d(nmax * rec, 2048), G), dim3(kBlock), 0, c->stream, (const double *)c->kd.mpole, offM, rec,
 			                   lay.ntot_local, lay.d, lay.rank, (const int *)v.sel_node, (const int *)v.cursors, nb, (double *)mpole_send);
 		else
@@ -325,7 +351,41 @@ int kd_dist_let_pack(nbco_ctx *c, const long long *counts_all, void *pos_send, v
 	}
 	NBCO_HIP(hipGetLastError());
 	c->dist.let_packed = true;
+	c->dist.let_capped = capped;
+	c->dist.let_flagged = false;
 	return NBCO_OK;
+}
+
+// counts_all (host): the all-gathered counts, [sender][2 world + 2].  Fills the two send buffers: for receiver r (rank order)
+// counts_all[me][2 r + 1] position records of 16 bytes, counts_all[me][2 r] node records of let_node_bytes.
+int kd_dist_let_pack(nbco_ctx *c, const long long *counts_all, void *pos_send, void *mpole_send)
+{
+	if (!c->dist.let_selected || !c->dist.local_done) return c->fail(NBCO_ERR_ARG, "nbco_dist_let_pack: selection or multipoles missing");
+	NBCO_TRY(let_report(c));
+	nbco_dist_layout lay;
+	NBCO_TRY(kd_dist_layout(c, c->dist.n_global, c->dist.world, c->dist.rank, &lay));
+	const int G = lay.world, S = 2 * G + 2;
+	for (int s = 0; s < G; ++s)
+	{
+		if (counts_all[(size_t)s * S + 2 * G]) return c->fail(NBCO_ERR_CAPACITY, "nbco_dist_let_pack: a rank reported list overflow; repeat nbco_dist_let_select on every rank");
+		if (counts_all[(size_t)s * S + 2 * G + 1])
+			return c->fail(NBCO_ERR_CAPACITY, "nbco_dist_let_pack: a rank's tree build was flagged; repeat the evaluation from nbco_dist_let_local_geom on every rank");
+	}
+	if (c->sel_warm_used && c->dist.rebuilt) c->note_warm_ok();
+	return let_pack_segments(c, lay, counts_all + (size_t)lay.rank * S, pos_send, mpole_send, false);
+}
+
+// The exchange without a host round trip in the middle of the evaluation.  The caller sizes the segments BEFORE it knows this
+// evaluation's counts (from the evaluation before, with head room): caps_out[2 r] node records and caps_out[2 r + 1] position
+// records for receiver r.  It gathers the counts as before, but looks at them only once the whole evaluation is queued, and
+// then says what it found (kd_dist_let_settle): every count within its segment and no flag -- the evaluation stands; else it
+// is void and repeated with exact sizes (nbco_dist_let_pack).  Nothing here reads the counts on the host.
+int kd_dist_let_pack_capped(nbco_ctx *c, const long long *caps_out, void *pos_send, void *mpole_send)
+{
+	if (!c->dist.let_selected || !c->dist.local_done) return c->fail(NBCO_ERR_ARG, "nbco_dist_let_pack_capped: selection or multipoles missing");
+	nbco_dist_layout lay;
+	NBCO_TRY(kd_dist_layout(c, c->dist.n_global, c->dist.world, c->dist.rank, &lay));
+	return let_pack_segments(c, lay, caps_out, pos_send, mpole_send, true);
 }
 
 static int dist_finish_rest(nbco_ctx *c, const char *mp_blocks, size_t mp_stride, float *buf_local, float *a_local, const float *param, const long long *let_counts,
@@ -334,9 +394,56 @@ static int dist_finish_rest(nbco_ctx *c, const char *mp_blocks, size_t mp_stride
 // pos_recv / mpole_recv: the records received from ranks 0, 1, .. (counts_all[s][2 me + 1] / counts_all[s][2 me] from rank s)
 int kd_dist_let_finish(nbco_ctx *c, const long long *counts_all, const void *pos_recv, const void *mpole_recv, float *buf_local, float *a_local, const float *param)
 {
-	if (!c->dist.let_packed) return c->fail(NBCO_ERR_ARG, "nbco_dist_let_finish: call nbco_dist_let_pack first");
+	if (!c->dist.let_packed || c->dist.let_capped) return c->fail(NBCO_ERR_ARG, "nbco_dist_let_finish: call nbco_dist_let_pack first");
 	c->dist.let_packed = false; c->dist.let_selected = false;
-	return dist_finish_rest(c, (const char *)mpole_recv, 0, buf_local, a_local, param, counts_all, pos_recv);
+	const int rc = dist_finish_rest(c, (const char *)mpole_recv, 0, buf_local, a_local, param, counts_all, pos_recv);
+	c->dist.let_epoch += 1;
+	return rc;
+}
+
+// caps_in[2 s], caps_in[2 s + 1]: the sizes of the segments rank s packed for this rank (what it passed as caps_out[2 me ..]);
+// pos_recv / mpole_recv hold those segments in rank order, free records marked
+int kd_dist_let_finish_capped(nbco_ctx *c, const long long *caps_in, const void *pos_recv, const void *mpole_recv, float *buf_local, float *a_local, const float *param)
+{
+	if (!c->dist.let_packed || !c->dist.let_capped) return c->fail(NBCO_ERR_ARG, "nbco_dist_let_finish_capped: call nbco_dist_let_pack_capped first");
+	c->dist.let_packed = false; c->dist.let_selected = false;
+	const int G = c->dist.world, S = 2 * G + 2, me = c->dist.rank;
+	std::vector<long long> as_counts((size_t)G * S, 0);   // (dist_finish_rest sums column `me` of a count matrix)
+	for (int s = 0; s < G; ++s)
+	{
+		if (caps_in[2 * s] < 0 || caps_in[2 * s + 1] < 0) return c->fail(NBCO_ERR_ARG, "nbco_dist_let_finish_capped: negative segment size");
+		as_counts[(size_t)s * S + 2 * me] = caps_in[2 * s];
+		as_counts[(size_t)s * S + 2 * me + 1] = caps_in[2 * s + 1];
+	}
+	const int rc = dist_finish_rest(c, (const char *)mpole_recv, 0, buf_local, a_local, param, as_counts.data(), pos_recv);
+	c->dist.let_epoch += 1;
+	return rc;
+}
+
+// After nbco_dist_let_finish_capped, once the caller has looked at the gathered counts.  ok != 0: every count fitted its
+// segment and no rank raised a flag -- the evaluation stands (and the guard of the evaluation before is reported here).
+// ok == 0: it is void; this rank's build is repeated more conservatively if it was a flagged one, the guard words of the
+// void attempt are dropped when they arrive, and the caller repeats the evaluation from nbco_dist_let_local_geom.
+int kd_dist_let_settle(nbco_ctx *c, int ok)
+{
+	if (!c->dist.let_capped) return c->fail(NBCO_ERR_ARG, "nbco_dist_let_settle: no capped exchange to settle");
+	c->dist.let_capped = false;
+	NBCO_TRY(let_report(c, true));
+	if (ok)
+	{
+		if (c->dist.let_flagged) return c->fail(NBCO_ERR_ARG, "nbco_dist_let_settle: this rank's build was flagged (its counts said so); the evaluation cannot stand");
+		if (c->sel_warm_used && c->dist.rebuilt) c->note_warm_ok();
+		return NBCO_OK;
+	}
+	c->dist.let_ignore[(c->dist.let_epoch - 1) & 1] = true;
+	if (c->dist.let_flagged)
+	{
+		if (c->sel_warm_used) c->note_warm_miss();
+		else if (!c->escalate_build()) return c->fail(NBCO_ERR_UNSUPPORTED, "kd-tree build: tie flag raised by the sorting build");
+	}
+	else c->eval_counter -= 1;   // (the repeat takes the void attempt's place in the rebuild schedule of opts.tree_steps)
+	c->dist.let_flagged = false;
+	return NBCO_OK;
 }
 
 int kd_dist_let_check(nbco_ctx *c)
@@ -459,6 +566,14 @@ static int dist_finish_rest(nbco_ctx *c, const char *mp_blocks, size_t mp_stride
 		rc = kd_interact(c, tv, (const float4 *)c->dist.pos_all, lay.n_global, g.mlt_max, dm, (long long)lay.rank * nl, nl, c->unsort.as<int>(), a_local, param,
 		                 cnt, 0, nullptr, let);
 	if (rc != NBCO_OK) return rc;
+	if (cnt.sel_overflow && c->dist.let_capped)
+	{
+		// capped exchange: the flag travels with the counts the caller is about to look at; it declares the evaluation void
+		// (nbco_dist_let_settle) and everybody repeats it.  buf_local still holds the state in the order before this build.
+		c->dist.let_flagged = true;
+		c->tree_valid = false;
+		return NBCO_OK;
+	}
 	if (cnt.sel_overflow) return c->fail(NBCO_ERR_UNSUPPORTED, "nbco_dist_finish: unresolved tie overflow of the selection build");
 	if (c->dist.rebuilt) NBCO_TRY(kd_finish_order(c, buf_local, nl));
 	c->tree_valid = true;

@@ -416,6 +416,23 @@ int nbco_dist_let_check(nbco_ctx *c)
 	if (!c) return NBCO_ERR_ARG;
 	return kd_dist_let_check(c);
 }
+int nbco_dist_let_pack_capped(nbco_ctx *c, const long long *caps_out, void *pos_send, void *mpole_send)
+{
+	if (!c || !caps_out) return c ? c->fail(NBCO_ERR_ARG, "nbco_dist_let_pack_capped: null pointer") : NBCO_ERR_ARG;
+	return kd_dist_let_pack_capped(c, caps_out, pos_send, mpole_send);
+}
+int nbco_dist_let_finish_capped(nbco_ctx *c, const long long *caps_in, const void *pos_recv, const void *mpole_recv, float *buf_local, float *a_local,
+                                const float *param)
+{
+	if (!c || !caps_in || !buf_local || !a_local) return c ? c->fail(NBCO_ERR_ARG, "nbco_dist_let_finish_capped: null pointer") : NBCO_ERR_ARG;
+	NBCO_TRY(kd_dist_let_finish_capped(c, caps_in, pos_recv, mpole_recv, buf_local, a_local, param));
+	return maybe_sync(c);
+}
+int nbco_dist_let_settle(nbco_ctx *c, int ok)
+{
+	if (!c) return NBCO_ERR_ARG;
+	return kd_dist_let_settle(c, ok);
+}
 int nbco_dist_repartition_workspace(nbco_ctx *c, long long n_global, int world, long long *bytes)
 {
 	if (!c || !bytes) return c ? c->fail(NBCO_ERR_ARG, "nbco_dist_repartition_workspace: null pointer") : NBCO_ERR_ARG;

@@ -192,6 +192,12 @@ struct nbco_ctx
 		long long n_global = 0, n_local = 0;
 		bool partitioned = false, build_done = false, local_done = false, rebuilt = false, traversed = false, let_selected = false, let_packed = false;
 		const void *pos_all = nullptr;   // gathered positions, between the two halves of the finish stage
+		// LET exchange with capped segments (nbco_dist_let_pack_capped): the attempt in flight is one, and its build turned out flagged
+		bool let_capped = false, let_flagged = false;
+		// attempts finished so far; the guard of attempt k reports into word pair k & 1, and a pair whose attempt the caller
+		// declared void (nbco_dist_let_settle(ok = 0)) is dropped unread
+		long long let_epoch = 0;
+		bool let_ignore[2] = {false, false};
 	} dist;
 	// warm select (k_kdselect.hip): one histogram pass per level around the previous build's pivots.  used: this build ran it;
 	// a flagged build that used it is repeated cold before anything is escalated, three misses in a row switch it off
@@ -341,6 +347,9 @@ int kd_dist_let_select(nbco_ctx *c, const void *csz_all, long long *counts);
 int kd_dist_let_pack(nbco_ctx *c, const long long *counts_all, void *pos_send, void *mpole_send);
 int kd_dist_let_finish(nbco_ctx *c, const long long *counts_all, const void *pos_recv, const void *mpole_recv, float *buf_local, float *a_local, const float *param);
 int kd_dist_let_check(nbco_ctx *c);
+int kd_dist_let_pack_capped(nbco_ctx *c, const long long *caps_out, void *pos_send, void *mpole_send);
+int kd_dist_let_finish_capped(nbco_ctx *c, const long long *caps_in, const void *pos_recv, const void *mpole_recv, float *buf_local, float *a_local, const float *param);
+int kd_dist_let_settle(nbco_ctx *c, int ok);
 int kd_dist_local(nbco_ctx *c, float *buf_local, long long n_local, void *nodes_send, void *pos_send, void *csz_send = nullptr,
                   void *mpole_send = nullptr, int let_stage = 0);
 int kd_dist_finish(nbco_ctx *c, const void *nodes_all, const void *pos_all, float *buf_local, float *a_local, const float *param);

@@ -181,6 +181,14 @@ class DomainRun:
             self.counts_all = torch.zeros(G * S, dtype=torch.int64, device=self.device)
             self.rec = int(self.lay.let_node_bytes) // 4
             self._scratch = {}
+        # capped form of the LET exchange (nbco_dist_let_pack_capped): no host round trip in the middle of the evaluation; the
+        # segments are sized from the count matrix of the evaluation before, so the first evaluation (and one whose counts
+        # outgrew them) runs the exact form
+        self.capped = self.let and all(hasattr(engine, m) for m in ("dist_let_pack_capped", "dist_let_finish_capped", "dist_let_settle"))
+        self._prevM = None
+        self._counts_host = None
+        self.let_capped_evals = 0     # evaluations that stood in the capped form
+        self.let_redos = 0            # capped attempts declared void and repeated in the exact form
         self.last_exchange_bytes = None
         self.evals = 0
 
@@ -338,9 +346,90 @@ class DomainRun:
         M2 = M.view(G, S)
         return (M2[me, 0:2 * G:2].tolist(), M2[me, 1:2 * G:2].tolist(), M2[:, 2 * me].tolist(), M2[:, 2 * me + 1].tolist())
 
+    @staticmethod
+    def cap_table(prevM, G, S, lay=None):
+        """segment sizes of the capped exchange from the count matrix of the evaluation before: (nodes, particles), each [sender][receiver]
+        (int64, host).  A quarter of head room plus a constant (never more than a domain holds); every rank holds the same
+        matrix, hence the same table."""
+        M2 = prevM.view(G, S)[:, : 2 * G]
+        nodes, parts = M2[:, 0::2].clone(), M2[:, 1::2].clone()
+        nodes += nodes // 4 + 64
+        parts += parts // 4 + 512
+        if lay is not None:
+            nodes.clamp_(max=int(lay.ntot_local))
+            parts.clamp_(max=int(lay.n_local))
+        idx = torch.arange(G)
+        nodes[idx, idx] = 0
+        parts[idx, idx] = 0
+        return nodes, parts
+
+    @staticmethod
+    def caps_hold(M, capn, capp, G, S):
+        """the verdict on a capped attempt: no flag in the gathered counts and every count within its segment"""
+        M2 = M.view(G, S)
+        if bool(M2[:, 2 * G:].any()):
+            return False
+        return bool((M2[:, 0:2 * G:2] <= capn).all()) and bool((M2[:, 1:2 * G:2] <= capp).all())
+
+    def _counts_to_host(self):
+        """start the copy of the gathered counts to the host; returns wait() -> the matrix (host int64)"""
+        if self.device.type != "cuda":
+            M = self.counts_all.clone()
+            return lambda: M
+        if self._counts_host is None:
+            self._counts_host = torch.empty(self.counts_all.numel(), dtype=torch.int64).pin_memory()
+            self._counts_ev = torch.cuda.Event()
+        self._counts_host.copy_(self.counts_all, non_blocking=True)
+        self._counts_ev.record()
+
+        def wait():
+            self._counts_ev.synchronize()
+            return self._counts_host.clone()
+        return wait
+
+    def _force_let_capped(self, param):
+        """one attempt in the capped form; False = void (the caller repeats the evaluation in the exact form)"""
+        cb, G, S, me = self.csz_bytes, self.world, int(self.lay.let_counts), self.rank
+        csz_send, csz_all = self.nodes_send[:cb], self.nodes_all[: G * cb]
+        capn, capp = self._caps
+        send_n, send_p, recv_n, recv_p = capn[me].tolist(), capp[me].tolist(), capn[:, me].tolist(), capp[:, me].tolist()
+        caps_out = torch.stack([capn[me], capp[me]], 1).reshape(-1).contiguous()
+        caps_in = torch.stack([capn[:, me], capp[:, me]], 1).reshape(-1).contiguous()
+        self.eng.dist_let_local_geom(self.buf, self.n_local, csz_send)
+        h_csz = self.comm.all_gather_start(csz_all, csz_send)
+        self.eng.dist_let_local_mpole(self.buf, self.n_local)
+        h_csz.wait()
+        self.eng.dist_let_select(csz_all, self.counts_send)
+        self.comm.all_gather(self.counts_all, self.counts_send)
+        counts = self._counts_to_host()
+        pos_send, mp_send = self._rows("ps", sum(send_p), 4), self._rows("ms", sum(send_n), self.rec)
+        pos_recv, mp_recv = self._rows("pr", sum(recv_p), 4), self._rows("mr", sum(recv_n), self.rec)
+        self.eng.dist_let_pack_capped(caps_out, pos_send, mp_send)
+        self.comm.all_to_all(pos_recv, pos_send, recv_p, send_p)
+        self.comm.all_to_all(mp_recv, mp_send, recv_n, send_n)
+        self.eng.dist_let_finish_capped(caps_in, pos_recv, mp_recv, self.buf, self.acc, param)
+        # everything is queued: only now look at the counts (they left the GPU long ago)
+        M = counts()
+        ok = self.caps_hold(M, capn, capp, G, S)
+        self.eng.dist_let_settle(ok)
+        if not ok:
+            self.let_redos += 1
+            return False
+        self._set_prev(M)
+        self.let_capped_evals += 1
+        self.last_exchange_bytes = (G - 1) * (cb + 8 * S) + 16 * sum(recv_p) + 4 * self.rec * sum(recv_n)
+        return True
+
+    def _set_prev(self, M):
+        self._prevM = M
+        if self.capped:
+            self._caps = self.cap_table(M, self.world, int(self.lay.let_counts), self.lay)
+
     def _force_let(self, param):
         cb, G = self.csz_bytes, self.world
         csz_send, csz_all = self.nodes_send[:cb], self.nodes_all[: G * cb]
+        if self.capped and self._prevM is not None and self._force_let_capped(param):
+            return
 
         def gather():
             self.comm.all_gather(self.counts_all, self.counts_send)
@@ -362,6 +451,7 @@ class DomainRun:
         self.comm.all_to_all(pos_recv, pos_send, recv_p, send_p)
         self.comm.all_to_all(mp_recv, mp_send, recv_n, send_n)
         self.eng.dist_let_finish(M, pos_recv, mp_recv, self.buf, self.acc, param)
+        self._set_prev(M)
         self.last_exchange_bytes = (G - 1) * (cb + 8 * int(self.lay.let_counts)) + 16 * sum(recv_p) + 4 * self.rec * sum(recv_n)
 
     def _wait_far_field(self, handle):
@@ -455,6 +545,8 @@ class LoopbackWorld:
         self.runs = [DomainRun(e, n_global, LoopbackWorld._Comm(G, r), device=device, rebalance=rebalance, gather_partition=gather_partition)
                      for r, e in enumerate(engines)]
         self.G = G
+        self._prevM = None
+        self.let_capped_evals = self.let_redos = 0
 
     def partition(self, pos_parts, vel_parts):
         if all(r.dpart for r in self.runs):
@@ -520,10 +612,59 @@ class LoopbackWorld:
             r.partition_bytes = moved[r.rank]
             r.evals = 0
 
-    def force_let(self, param=None, elastic=True, tamper=None):
-        """the LET exchange in lockstep; tamper(rank, pos_recv, mp_recv) may damage what a rank received (guard tests)"""
+    def _force_let_capped(self, param, elastic, squeeze):
+        """one attempt in the capped form, in lockstep; squeeze(capn, capp) may shrink the table (tests of the void path)"""
         runs, G = self.runs, self.G
         cb, S = runs[0].csz_bytes, int(runs[0].lay.let_counts)
+        capn, capp = DomainRun.cap_table(self._prevM, G, S, runs[0].lay)
+        if squeeze is not None:
+            squeeze(capn, capp)
+        for r in runs:
+            r.eng.dist_let_local_geom(r.buf, r.n_local, r.nodes_send[:cb])
+        csz = torch.cat([r.nodes_send[:cb] for r in runs])
+        for r in runs:
+            r.eng.dist_let_local_mpole(r.buf, r.n_local)
+            r.nodes_all[: G * cb].copy_(csz)
+            r.eng.dist_let_select(r.nodes_all[: G * cb], r.counts_send)
+        counts = torch.cat([r.counts_send for r in runs])   # (stays on the device until everything is queued)
+        sends = []
+        for r in runs:
+            me = r.rank
+            ps, ms = r._rows("ps", int(capp[me].sum()), 4), r._rows("ms", int(capn[me].sum()), r.rec)
+            r.eng.dist_let_pack_capped(torch.stack([capn[me], capp[me]], 1).reshape(-1).contiguous(), ps, ms)
+            sends.append((ps, ms))
+        for r in runs:
+            me = r.rank
+            pp, mm = [], []
+            for s_, (ps, ms) in enumerate(sends):
+                op, on = int(capp[s_, :me].sum()), int(capn[s_, :me].sum())
+                pp.append(ps[op: op + int(capp[s_, me])])
+                mm.append(ms[on: on + int(capn[s_, me])])
+            pos_recv, mp_recv = torch.cat(pp).contiguous(), torch.cat(mm).contiguous()
+            r.eng.dist_let_finish_capped(torch.stack([capn[:, me], capp[:, me]], 1).reshape(-1).contiguous(), pos_recv, mp_recv, r.buf, r.acc, param)
+        M = counts.cpu()
+        ok = DomainRun.caps_hold(M, capn, capp, G, S)
+        for r in runs:
+            r.eng.dist_let_settle(ok)
+        if not ok:
+            self.let_redos += 1
+            return False
+        self._prevM = M
+        self.let_capped_evals += 1
+        for r in runs:
+            r.last_exchange_bytes = (G - 1) * (cb + 8 * S) + 16 * int(capp[:, r.rank].sum()) + 4 * r.rec * int(capn[:, r.rank].sum())
+            if elastic and param is not None:
+                r.eng.add_elastic(r.pos, r.acc, r.n_local, param[3:])
+            r.evals += 1
+        return True
+
+    def force_let(self, param=None, elastic=True, tamper=None, capped=False, squeeze=None):
+        """the LET exchange in lockstep; tamper(rank, pos_recv, mp_recv) may damage what a rank received (guard tests);
+        capped: the form without a host round trip in the middle (after a first evaluation in the exact form)"""
+        runs, G = self.runs, self.G
+        cb, S = runs[0].csz_bytes, int(runs[0].lay.let_counts)
+        if capped and self._prevM is not None and self._force_let_capped(param, elastic, squeeze):
+            return
         for _ in range(6):
             for r in runs:
                 r.eng.dist_let_local_geom(r.buf, r.n_local, r.nodes_send[:cb])
@@ -544,6 +685,7 @@ class LoopbackWorld:
         else:
             raise RuntimeError("LET exchange: a tree build kept being flagged")
         M2 = M.view(G, S)
+        self._prevM = M
         sends = []
         for r in runs:
             send_n, send_p, _, _ = r._let_splits(M)
@@ -566,11 +708,11 @@ class LoopbackWorld:
                 r.eng.add_elastic(r.pos, r.acc, r.n_local, param[3:])
             r.evals += 1
 
-    def force(self, param=None, elastic=True, split=None, let=False):
+    def force(self, param=None, elastic=True, split=None, let=False, capped=False, squeeze=None):
         """split=None: the two-stage exchange (records, then multipoles) when the engines offer it; False: one node block;
-        let=True: the LET exchange"""
+        let=True: the LET exchange (capped=True: its form without a host round trip, see force_let)"""
         if let:
-            return self.force_let(param, elastic)
+            return self.force_let(param, elastic, capped=capped, squeeze=squeeze)
         runs = self.runs
         if split is None:
             split = all(hasattr(r.eng, "dist_finish_traverse") and r.csz_bytes > 0 for r in runs)

@@ -150,6 +150,9 @@ def _load():
         "nbco_dist_let_pack": [P, P, P, P],
         "nbco_dist_let_finish": [P, P, P, P, P, P, P],
         "nbco_dist_let_check": [P],
+        "nbco_dist_let_pack_capped": [P, P, P, P],
+        "nbco_dist_let_finish_capped": [P, P, P, P, P, P, P],
+        "nbco_dist_let_settle": [P, I],
         "nbco_dist_turnaround": [P, P, LL, P, D, D, I],
         "nbco_aux_stream": [P, C.POINTER(C.c_void_p)],
         "nbco_debug_violations": [P, C.POINTER(LL)],
@@ -381,6 +384,17 @@ class Engine:
 
     def dist_let_check(self):
         self._chk(self.lib.nbco_dist_let_check(self.ctx))
+
+    # the exchange with segments sized ahead of the counts (nbco_dist_let_pack_capped): caps_* are host int64 tensors of 2 world values
+    def dist_let_pack_capped(self, caps_out_host, pos_send, mpole_send):
+        self._chk(self.lib.nbco_dist_let_pack_capped(self.ctx, _ptr(caps_out_host), _ptr(pos_send), _ptr(mpole_send)))
+
+    def dist_let_finish_capped(self, caps_in_host, pos_recv, mpole_recv, buf_local, a_local, param=None):
+        self._chk(self.lib.nbco_dist_let_finish_capped(self.ctx, _ptr(caps_in_host), _ptr(pos_recv), _ptr(mpole_recv), _ptr(buf_local), _ptr(a_local),
+                                                       _ptr(param)))
+
+    def dist_let_settle(self, ok):
+        self._chk(self.lib.nbco_dist_let_settle(self.ctx, int(bool(ok))))
 
     def aux_stream(self):
         """raw hipStream_t of the context's second stream (see nbco_aux_stream)"""

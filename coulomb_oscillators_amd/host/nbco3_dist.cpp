@@ -5,7 +5,7 @@
 // of the global kd-tree (rank r's particles are rows [r N/G, (r+1) N/G)).
 //
 //   nbco3_dist -gpus G [-n N] [-p order] [-ds dt] [-iters n] [-steps n] [-r radius] [-i dens] [-rebalance k] [-tree-steps k]
-//              [-o folder] [-exchange let|gather] [-partition dist|gather]
+//              [-o folder] [-exchange let|let-exact|gather] [-partition dist|gather]
 //
 // The launcher process is a SUPERVISOR, not a rank: it forks all G ranks before anything touches the GPU, never makes a HIP or
 // RCCL call itself, waits for the ranks, and when one of them exits with a failure (or is killed) it kills the others -- which
@@ -55,7 +55,7 @@ struct Args
 	int gpus = 1, n = 1 << 20, order = 3, iters = 30001, steps = 200, rebalance = 16, tree_steps = 1;
 	int fail_rank = -1, fail_iter = 0;   // test hook (NBCO3_DIST_FAIL=rank:iteration): that rank exits with status 9 before that iteration
 	int hang_rank = -1;                  // test hook (NBCO3_DIST_HANG=rank): that rank sleeps for ever instead of running
-	bool let = true, dist_partition = true;
+	bool let = true, capped = true, dist_partition = true;
 	float dt = 5.e-4f, radius = 1.f, dens = 1.f, xi = 2.e-6f;
 	std::string out = "out";
 };
@@ -75,7 +75,13 @@ struct Rank
 	bool let = true, dist_partition = true;
 	// LET exchange: count blocks (device + host), record buffers sized for the worst case (everything needed by everyone)
 	long long *counts_send = nullptr, *counts_all_dev = nullptr;
-	std::vector<long long> counts_all;
+	long long *counts_all = nullptr;   // pinned host memory, world x let_counts
+	// capped form (nbco_dist_let_pack_capped): segments sized from the count matrix of the evaluation before, no host
+	// synchronisation in the middle of the evaluation; `capped` off = always the exact form (-exchange let-exact)
+	bool capped = true, have_prev = false;
+	std::vector<long long> prev_counts;
+	hipEvent_t ev_counts{};
+	long long capped_evals = 0, let_redos = 0;
 	char *let_pos_send = nullptr, *let_mp_send = nullptr, *let_pos_recv = nullptr, *let_mp_recv = nullptr;
 	// re-partition without gathering the state: the library's workspace
 	char *work = nullptr;
@@ -140,12 +146,74 @@ struct Rank
 		return true;
 	}
 
+	// segment sizes of the capped exchange, from the count matrix of the evaluation before (a quarter of head room plus a
+	// constant, never more than a domain holds): records rank s sizes for rank r.  Same matrix, same table on every rank.
+	long long cap_nodes(int s, int r) const
+	{
+		if (s == r) return 0;
+		const long long c = prev_counts[(size_t)s * lay.let_counts + 2 * r];
+		return std::min<long long>(c + c / 4 + 64, lay.ntot_local);
+	}
+	long long cap_parts(int s, int r) const
+	{
+		if (s == r) return 0;
+		const long long c = prev_counts[(size_t)s * lay.let_counts + 2 * r + 1];
+		return std::min<long long>(c + c / 4 + 512, lay.n_local);
+	}
+	void keep_counts() { prev_counts.assign(counts_all, counts_all + (size_t)lay.let_counts * world); have_prev = true; }
+
+	// one attempt in the capped form; false = void, the caller repeats the evaluation in the exact form
+	bool force_let_capped()
+	{
+		const long long nl = lay.n_local;
+		const int S = lay.let_counts;
+		char *csz_send = nodes_send, *csz_all = nodes_all;
+		std::vector<long long> caps_out(2 * world), caps_in(2 * world), ps(world), pr(world), ms(world), mr(world);
+		for (int r = 0; r < world; ++r)
+		{
+			caps_out[2 * r] = ms[r] = cap_nodes(rank, r); caps_out[2 * r + 1] = ps[r] = cap_parts(rank, r);
+			caps_in[2 * r] = mr[r] = cap_nodes(r, rank); caps_in[2 * r + 1] = pr[r] = cap_parts(r, rank);
+		}
+		check(nbco_dist_let_local_geom(ctx, buf, nl, csz_send), "nbco_dist_let_local_geom");
+		NCCLCHK(ncclAllGather(csz_send, csz_all, (size_t)lay.csz_bytes, ncclChar, comm, nullptr));
+		check(nbco_dist_let_local_mpole(ctx, buf, nl), "nbco_dist_let_local_mpole");
+		check(nbco_dist_let_select(ctx, csz_all, counts_send), "nbco_dist_let_select");
+		NCCLCHK(ncclAllGather(counts_send, counts_all_dev, (size_t)S, ncclInt64, comm, nullptr));
+		HIPCHK(hipMemcpyAsync(counts_all, counts_all_dev, sizeof(long long) * (size_t)S * world, hipMemcpyDeviceToHost, nullptr));
+		HIPCHK(hipEventRecord(ev_counts, nullptr));
+		check(nbco_dist_let_pack_capped(ctx, caps_out.data(), let_pos_send, let_mp_send), "nbco_dist_let_pack_capped");
+		all_to_all(let_pos_send, let_pos_recv, ps.data(), pr.data(), 16, nullptr);
+		all_to_all(let_mp_send, let_mp_recv, ms.data(), mr.data(), (size_t)lay.let_node_bytes, nullptr);
+		check(nbco_dist_let_finish_capped(ctx, caps_in.data(), let_pos_recv, let_mp_recv, buf, buf + 6 * nl, par), "nbco_dist_let_finish_capped");
+		// the whole evaluation is queued: only now look at the counts
+		HIPCHK(hipEventSynchronize(ev_counts));
+		bool ok = true;
+		for (int s = 0; s < world && ok; ++s)
+		{
+			ok = counts_all[(size_t)s * S + 2 * world] == 0 && counts_all[(size_t)s * S + 2 * world + 1] == 0;
+			for (int r = 0; r < world && ok; ++r)
+				ok = s == r || (counts_all[(size_t)s * S + 2 * r] <= cap_nodes(s, r) && counts_all[(size_t)s * S + 2 * r + 1] <= cap_parts(s, r));
+		}
+		if (getenv("NBCO3_DIST_VOID") && capped_evals + let_redos == atoll(getenv("NBCO3_DIST_VOID"))) ok = false;   // test hook: this attempt is void
+		check(nbco_dist_let_settle(ctx, ok ? 1 : 0), "nbco_dist_let_settle");
+		if (!ok) { ++let_redos; return false; }
+		keep_counts();
+		++capped_evals;
+		return true;
+	}
+
 	// one force evaluation with the LET exchange
 	void force_let(bool elastic)
 	{
 		const long long nl = lay.n_local;
 		const int S = lay.let_counts;
 		char *csz_send = nodes_send, *csz_all = nodes_all;
+		if (capped && have_prev && force_let_capped())
+		{
+			if (elastic) check(nbco_add_elastic(ctx, buf, buf + 6 * nl, nl, par + 3), "nbco_add_elastic");
+			++evals;
+			return;
+		}
 		for (int attempt = 0;; ++attempt)
 		{
 		check(nbco_dist_let_local_geom(ctx, buf, nl, csz_send), "nbco_dist_let_local_geom");
@@ -155,7 +223,7 @@ struct Rank
 		{
 			check(nbco_dist_let_select(ctx, csz_all, counts_send), "nbco_dist_let_select");
 			NCCLCHK(ncclAllGather(counts_send, counts_all_dev, (size_t)S, ncclInt64, comm, nullptr));
-			HIPCHK(hipMemcpyAsync(counts_all.data(), counts_all_dev, sizeof(long long) * (size_t)S * world, hipMemcpyDeviceToHost, nullptr));
+			HIPCHK(hipMemcpyAsync(counts_all, counts_all_dev, sizeof(long long) * (size_t)S * world, hipMemcpyDeviceToHost, nullptr));
 			HIPCHK(hipStreamSynchronize(nullptr));   // the evaluation's one host synchronisation
 			bool overflow = false;
 			for (int s = 0; s < world; ++s) overflow = overflow || counts_all[(size_t)s * S + 2 * world] != 0;
@@ -168,7 +236,7 @@ struct Rank
 		if (!flagged) break;
 		if (attempt == 5) { std::cerr << "rank " << rank << ": a tree build keeps being flagged" << std::endl; std::exit(4); }
 		}
-		check(nbco_dist_let_pack(ctx, counts_all.data(), let_pos_send, let_mp_send), "nbco_dist_let_pack");
+		check(nbco_dist_let_pack(ctx, counts_all, let_pos_send, let_mp_send), "nbco_dist_let_pack");
 		std::vector<long long> ps(world), pr(world), ms(world), mr(world);
 		for (int r = 0; r < world; ++r)
 		{
@@ -177,7 +245,8 @@ struct Rank
 		}
 		all_to_all(let_pos_send, let_pos_recv, ps.data(), pr.data(), 16, nullptr);
 		all_to_all(let_mp_send, let_mp_recv, ms.data(), mr.data(), (size_t)lay.let_node_bytes, nullptr);
-		check(nbco_dist_let_finish(ctx, counts_all.data(), let_pos_recv, let_mp_recv, buf, buf + 6 * nl, par), "nbco_dist_let_finish");
+		check(nbco_dist_let_finish(ctx, counts_all, let_pos_recv, let_mp_recv, buf, buf + 6 * nl, par), "nbco_dist_let_finish");
+		keep_counts();
 		if (elastic) check(nbco_add_elastic(ctx, buf, buf + 6 * nl, nl, par + 3), "nbco_add_elastic");
 		++evals;
 	}
@@ -287,7 +356,9 @@ int run_rank(const Args &a, int rank, const ncclUniqueId &id)
 		const size_t S = (size_t)r.lay.let_counts, others = (size_t)(a.gpus > 1 ? a.gpus - 1 : 1);
 		HIPCHK(hipMalloc((void **)&r.counts_send, sizeof(long long) * S));
 		HIPCHK(hipMalloc((void **)&r.counts_all_dev, sizeof(long long) * S * a.gpus));
-		r.counts_all.resize(S * a.gpus);
+		HIPCHK(hipHostMalloc((void **)&r.counts_all, sizeof(long long) * S * a.gpus, hipHostMallocDefault));
+		HIPCHK(hipEventCreateWithFlags(&r.ev_counts, hipEventDisableTiming));
+		r.capped = a.capped;
 		// worst case: every other rank needs every particle and every node of this one / this one needs all of theirs
 		HIPCHK(hipMalloc((void **)&r.let_pos_send, 16 * (size_t)nl * others));
 		HIPCHK(hipMalloc((void **)&r.let_pos_recv, 16 * (size_t)nl * others));
@@ -359,7 +430,8 @@ int run_rank(const Args &a, int rank, const ncclUniqueId &id)
 		std::cout << std::endl;
 		// (not in the reference: wall time of the integration loop behind the first snapshot -- what bench.py's `cli_dist` leg reads)
 		std::cout << "Loop time: " << std::chrono::duration<double>(std::chrono::steady_clock::now() - loop_t0).count() << " s, " << a.iters - loop_first
-		          << " iterations, " << a.gpus << " ranks, partition fallbacks " << r.partition_fallbacks << std::endl;
+		          << " iterations, " << a.gpus << " ranks, partition fallbacks " << r.partition_fallbacks << ", capped evaluations " << r.capped_evals
+		          << ", repeated " << r.let_redos << std::endl;
 	}
 	nbco_destroy(r.ctx);
 	ncclCommDestroy(r.comm);
@@ -386,13 +458,13 @@ int main(int argc, char **argv)
 		else if (f == "-xi") a.xi = (float)atof(val());
 		else if (f == "-rebalance") a.rebalance = atoi(val());
 		else if (f == "-tree-steps") a.tree_steps = atoi(val());
-		else if (f == "-exchange") { const std::string v = val(); if (v != "let" && v != "gather") { std::cerr << "Error: -exchange let|gather\n"; return -1; } a.let = v == "let"; }
+		else if (f == "-exchange") { const std::string v = val(); if (v != "let" && v != "let-exact" && v != "gather") { std::cerr << "Error: -exchange let|let-exact|gather\n"; return -1; } a.let = v != "gather"; a.capped = v == "let"; }
 		else if (f == "-partition") { const std::string v = val(); if (v != "dist" && v != "gather") { std::cerr << "Error: -partition dist|gather\n"; return -1; } a.dist_partition = v == "dist"; }
 		else if (f == "-o") a.out = val();
 		else if (f == "-h" || f == "-help")
 		{
 			std::cout << "Usage: nbco3_dist -gpus G [-n N] [-p order] [-ds dt] [-iters n] [-steps n] [-r radius] [-i dens] [-xi v] [-rebalance k] [-o folder]\n"
-			             "                  [-exchange let|gather] [-partition dist|gather]\n"
+			             "                  [-exchange let|let-exact|gather] [-partition dist|gather]\n"
 			             "  kd-tree FMM simulation (the nbco3 loop) with the particles sharded by kd-domain over G GPUs of this node, one process\n"
 			             "  per GPU, RCCL all-gathers in between; G a power of two, N a multiple of G with at least 4096 particles per GPU.\n";
 			return 0;

@@ -335,6 +335,23 @@ int nbco_dist_let_pack(nbco_ctx *c, const long long *counts_all, void *pos_send,
 int nbco_dist_let_finish(nbco_ctx *c, const long long *counts_all, const void *pos_recv, const void *mpole_recv, float *buf_local,
                          float *a_local, const float *param);
 int nbco_dist_let_check(nbco_ctx *c);
+/* The same exchange without the host round trip in the middle of the evaluation (nbco_dist_let_pack needs the gathered counts
+ * on the host before anything behind it can be queued).  The caller sizes the segments from the counts of the evaluation BEFORE,
+ * with head room -- caps_out[2 r] node records and caps_out[2 r + 1] position records for receiver r (0, 0 for itself), the
+ * same numbers receiver r passes as caps_in[2 me], caps_in[2 me + 1] -- and exchanges whole segments:
+ *   nbco_dist_let_select -> all-gather of the counts, copied to the host asynchronously
+ *   nbco_dist_let_pack_capped(caps_out) -> the two all-to-alls with splits from the caps -> nbco_dist_let_finish_capped(caps_in)
+ *   [everything queued; now wait for the counts]  ok = every counts_all[s][2 r], [2 r + 1] within the segment rank s sized for
+ *   rank r, and no counts_all[s][2 world], [2 world + 1] flag  (the same matrix, hence the same verdict, on every rank)
+ *   nbco_dist_let_settle(ok)
+ * Records that do not fit a segment are dropped and free records are marked, so an attempt that is not ok has read nothing
+ * out of bounds: it is void -- the accelerations are not to be used, buf_local holds the same particles (possibly reordered) --
+ * and every rank repeats the evaluation from nbco_dist_let_local_geom, with nbco_dist_let_pack and exact sizes.  _settle also
+ * reports the receiver guard of the attempt before (the guard of the last attempt: the next _settle / _pack, or _check). */
+int nbco_dist_let_pack_capped(nbco_ctx *c, const long long *caps_out, void *pos_send, void *mpole_send);
+int nbco_dist_let_finish_capped(nbco_ctx *c, const long long *caps_in, const void *pos_recv, const void *mpole_recv, float *buf_local,
+                                float *a_local, const float *param);
+int nbco_dist_let_settle(nbco_ctx *c, int ok);
 /* Between the force evaluation of one leapfrog step of a sharded run and that of the next (any of the three forms above; the
  * accelerations a_local = buf_local + 6 n_local are those nbco_dist_*finish* wrote, WITHOUT the elastic term): one pass over the
  * domain's state that does  a -= k o x (elastic != 0), v += a dt scale / 2  [end of this step]  and  v += a dt scale / 2,

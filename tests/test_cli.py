@@ -253,6 +253,36 @@ def test_dist_host_falls_back_to_the_gathered_partition_on_pivot_ties(nbco3, tmp
 
 
 @pytest.mark.gpu
+def test_dist_host_capped_exchange_equals_the_exact_one(nbco3, tmp_path):
+    """`-exchange let` (default) runs every evaluation after the first with nbco_dist_let_pack_capped / _finish_capped / _settle --
+    no host synchronisation in the middle of an evaluation -- and `-exchange let-exact` never does: same snapshots bit for bit.
+    With NBCO3_DIST_VOID=2 the third capped attempt is declared void (as if a count had outgrown its segment) and repeated in the
+    exact form: still the same snapshots, through tree reuse as well."""
+    import re
+    tool = os.path.join(HOST, "nbco3_dist")
+    base = [tool, "-gpus", "1", "-n", "32768", "-p", "4", "-iters", "9", "-steps", "9", "-rebalance", "4", "-tree-steps", "2"]
+    snaps = {}
+    for name, extra, env in (("capped", (), {}), ("exact", ("-exchange", "let-exact"), {}), ("void", (), {"NBCO3_DIST_VOID": "2"})):
+        out = tmp_path / name
+        out.mkdir()
+        r = subprocess.run(base + ["-o", str(out), *extra], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-2000:]
+        m = re.search(r"capped evaluations (\d+), repeated (\d+)", r.stdout)
+        assert m, r.stdout[-300:]
+        capped, repeated = int(m.group(1)), int(m.group(2))
+        if name == "capped":
+            assert capped == 10 and repeated == 0     # 1 + 10 evaluations, the first one exact
+        elif name == "exact":
+            assert capped == 0 and repeated == 0
+        else:
+            assert capped == 9 and repeated == 1
+        snaps[name] = np.fromfile(out / "out9_0.000500.bin", dtype=np.float32)
+    assert np.isfinite(snaps["capped"]).all()
+    np.testing.assert_array_equal(snaps["capped"], snaps["exact"])
+    np.testing.assert_array_equal(snaps["void"], snaps["exact"])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode", [(), ("-exchange", "gather", "-partition", "gather"), ("-exchange", "let", "-partition", "gather")])
 def test_dist_host_one_rank_over_rccl(nbco3, engine, oracle32, tmp_path, mode):
     """`nbco3_dist -gpus 1`: the C++ multi-GPU host (one process per GPU, RCCL all-gathers on a stream of their own, the

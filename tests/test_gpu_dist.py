@@ -578,6 +578,119 @@ def test_flagged_build_restarts_the_let_evaluation(oracle32):
     assert misses[0] >= 1 and misses[1] == 0
 
 
+def _leapfrog_let(world, par, dt, steps, nl, **kw):
+    """kick-drift-kick with the LET exchange in lockstep (first force included)"""
+    world.force(par, elastic=True, let=True, **kw)
+    for _ in range(steps):
+        for r in world.runs:
+            r.eng.step(r.vel, r.acc, 0.5 * dt, nl); r.eng.step(r.pos, r.vel, dt, nl)
+        world.force(par, elastic=True, let=True, **kw)
+        for r in world.runs:
+            r.eng.step(r.vel, r.acc, 0.5 * dt, nl)
+
+
+@pytest.mark.parametrize("n,G,p,kind,opts", [(32768, 2, 6, "reference", {}), (65536, 4, 4, "clumps", {}), (1 << 17, 8, 5, "reference", {}),
+                                             (32768, 4, 6, "uniform", {"far_fp64": 1}), (1 << 17, 4, 6, "reference", {"tree_steps": 3}),
+                                             (65536, 4, 6, "reference", {"p2p_mutual": 1})])
+def test_capped_let_exchange_equals_the_exact_one(oracle32, n, G, p, kind, opts):
+    """nbco_dist_let_pack_capped / _finish_capped / _settle: segments sized from the evaluation before, free records marked, no host
+    round trip in the middle -- same state as the exact exchange bit for bit over a run of steps, every evaluation after the
+    first stood in the capped form, the guard is silent"""
+    import torch
+    pos, vel = make_state(oracle32, n, kind)
+    par = torch.from_numpy(oracle32.params(n)).cuda()
+    steps, dt, nl = 5, 5e-4, n // G
+    o = dict(fmm_order=p, unsort=0, tree_steps=1)
+    o.update(opts)
+    out = []
+    for capped in (False, True):
+        w = loopback(n, G, pos, vel, **o)
+        _leapfrog_let(w, par, dt, steps, nl, capped=capped)
+        for r in w.runs:
+            r.eng.dist_let_check()
+        torch.cuda.synchronize()
+        out.append(torch.cat([r.buf for r in w.runs]))
+        if capped:
+            assert w.let_capped_evals == steps and w.let_redos == 0
+            for r in w.runs:
+                assert r.exchange_bytes() < r.allgather_bytes()
+    assert torch.isfinite(out[0]).all()
+    assert torch.equal(out[0], out[1])
+
+
+@pytest.mark.parametrize("what", ["nodes", "particles", "both"])
+@pytest.mark.parametrize("tree_steps", [1, 3])
+def test_capped_let_attempt_that_overflows_is_void_and_repeated(oracle32, what, tree_steps):
+    """segments too small for what was selected: records are dropped (nothing is written out of a segment), the gathered counts say
+    so on every rank, nbco_dist_let_settle(0) declares the attempt void, the evaluation is repeated in the exact form -- same
+    state as a run that never overflowed; the guard words of the void attempt (it DID miss sources) are dropped, not reported"""
+    import torch
+    n, G, p, steps, dt = 65536, 4, 5, 6, 5e-4
+    pos, vel = make_state(oracle32, n, "reference")
+    par = torch.from_numpy(oracle32.params(n)).cuda()
+    nl = n // G
+    calls = [0]
+
+    def squeeze(capn, capp):
+        calls[0] += 1
+        if calls[0] in (2, 4):   # (attempt 3 follows a repeated evaluation, attempt 5 another)
+            if what in ("nodes", "both"):
+                capn[1, 2] = 3
+                capn[3, 0] //= 2
+            if what in ("particles", "both"):
+                capp[2, 1] = 17
+                capp[0, 3] //= 3
+
+    out = []
+    for capped in (False, True):
+        w = loopback(n, G, pos, vel, fmm_order=p, unsort=0, tree_steps=tree_steps)
+        _leapfrog_let(w, par, dt, steps, nl, **(dict(capped=True, squeeze=squeeze) if capped else {}))
+        for r in w.runs:
+            r.eng.dist_let_check()
+        torch.cuda.synchronize()
+        out.append(torch.cat([r.buf for r in w.runs]))
+        if capped:
+            assert w.let_redos == 2 and w.let_capped_evals == steps - 2
+    assert torch.equal(out[0], out[1])
+
+
+def test_capped_let_attempt_with_a_flagged_build_is_repeated(oracle32):
+    """capped form: a flagged build (the warm select misses after the positions were stretched by 30 %) is only seen once the whole
+    evaluation is queued -- it ran on a tree that is not the reference's.  The flag travels with the counts, every rank declares
+    the attempt void and repeats it (the flagged rank with a cold build): same result as with cold builds, which are never flagged"""
+    import os
+    import torch
+    from coulomb_oscillators_amd import Engine, LoopbackWorld
+    n, G, p = 1 << 17, 2, 4
+    pos, vel = make_state(oracle32, n, "reference")
+    par = torch.from_numpy(oracle32.params(n)).cuda()
+    nl = n // G
+    out, misses, redos = [], [], []
+    for warm in ("1", "0"):
+        os.environ["NBCO_SEL_WARM"] = warm
+        try:
+            engines = [Engine(fmm_order=p, unsort=0, tree_steps=1) for _ in range(G)]
+        finally:
+            del os.environ["NBCO_SEL_WARM"]
+        world = LoopbackWorld(engines, n)
+        world.partition([torch.from_numpy(pos[r * nl:(r + 1) * nl]).cuda() for r in range(G)], [torch.from_numpy(vel[r * nl:(r + 1) * nl]).cuda() for r in range(G)])
+        world.force(par, elastic=False, let=True, capped=True)
+        world.force(par, elastic=False, let=True, capped=True)
+        for r in world.runs:
+            r.pos.mul_(1.3)
+        world.force(par, elastic=False, let=True, capped=True)
+        world.force(par, elastic=False, let=True, capped=True)
+        for r in world.runs:
+            r.eng.dist_let_check()
+        torch.cuda.synchronize()
+        out.append(torch.cat([r.buf for r in world.runs]))
+        misses.append(sum(int(r.eng.kd_info().warm_misses) for r in world.runs))
+        redos.append(world.let_redos)
+    assert torch.equal(out[0], out[1])
+    assert misses[0] >= 1 and misses[1] == 0
+    assert redos[0] >= 1 and redos[1] == 0
+
+
 @pytest.mark.parametrize("tree_steps,recut", [(1, 0), (3, 0), (1, 4)])
 def test_sharded_turnaround_equals_step_kernels(oracle32, tree_steps, recut):
     """nbco_dist_turnaround (one pass between two force evaluations of a sharded leapfrog run: elastic term, both half kicks, drift,
