@@ -212,6 +212,13 @@ class NumpyLetEngine(NumpySplitEngine):
         M = M.numpy().reshape(G, 2 * G + 2)
         pr, mr = pos_recv.numpy(), mp_recv.numpy()
         assert pr.shape[0] == M[:, 2 * me + 1].sum() and mr.shape[0] == M[:, 2 * me].sum()
+        # records from rank s occupy the s-th segment
+        seg = np.concatenate([np.full(M[s_, 2 * me + 1], s_) for s_ in range(G)]) if pr.shape[0] else np.zeros(0, dtype=int)
+        np.testing.assert_array_equal(pr[:, 3].copy().view(np.int32) // nl, seg)
+        self._finish_records(pr, mr, buf, a_local, param)
+
+    def _finish_records(self, pr, mr, buf, a_local, param):
+        G, nl, me = self.lay.world, self.lay.n_local, self.lay.rank
         src = np.full((G * nl, 3), np.nan, dtype=np.float32)
         src[me * nl:(me + 1) * nl] = self._own
         seen = np.zeros(G * nl, dtype=int)
@@ -220,15 +227,62 @@ class NumpyLetEngine(NumpySplitEngine):
             np.add.at(seen, ids, 1)
             src[ids] = xyz
         assert (seen == 1).all()
-        # records from rank s occupy the s-th segment
-        seg = np.concatenate([np.full(M[s_, 2 * me + 1], s_) for s_ in range(G)]) if pr.shape[0] else np.zeros(0, dtype=int)
-        np.testing.assert_array_equal(pr[:, 3].copy().view(np.int32) // nl, seg)
         own = buf.numpy()[:3 * nl].reshape(nl, 3)
         dx = own.astype(np.float64)[:, None, :] - src.astype(np.float64)[None, :, :]
         r2 = (dx * dx).sum(-1) + self.eps2
         acc = (dx / r2[..., None] ** 1.5).sum(1)
         scale = float(param[0]) if param is not None else 1.0
         a_local.numpy()[:] = (acc * scale).astype(np.float32).reshape(-1)
+
+
+class NumpyCappedLetEngine(NumpyLetEngine):
+    """+ the capped form (nbco_dist_let_pack_capped / _finish_capped / _settle): whole segments travel, free records carry index -1,
+    the counts are only looked at when the evaluation is queued.  Rank 0 raises the build flag in its 5th selection -- a capped
+    attempt -- which every rank must declare void and repeat in the exact form."""
+    VOID_ROUND = 5
+
+    def dist_layout(self, n_global, world, rank):
+        lay = super().dist_layout(n_global, world, rank)
+        lay.ntot_local = lay.n_local
+        return lay
+
+    def dist_let_select(self, csz_all, counts_send):
+        super().dist_let_select(csz_all, counts_send)
+        if self.lay.rank == 0 and self.rounds == self.VOID_ROUND:
+            counts_send.numpy()[2 * self.lay.world + 1] = 1
+
+    def dist_let_pack_capped(self, caps_out, pos_send, mp_send):
+        self.calls.append("packc")
+        G, nl, me = self.lay.world, self.lay.n_local, self.lay.rank
+        caps = caps_out.numpy().reshape(G, 2)
+        assert caps[me].tolist() == [0, 0]
+        ps, ms = pos_send.numpy(), mp_send.numpy()
+        assert (ps.shape[0], ms.shape[0]) == (caps[:, 1].sum(), caps[:, 0].sum())
+        free = np.array([-1], dtype=np.int32).view(np.float32)[0]
+        ps[:], ms[:] = 0, 0
+        ps[:, 3], ms[:, 0] = free, free
+        idx = (me * nl + np.arange(nl)).astype(np.int32).view(np.float32)
+        op = on = 0
+        for r in range(G):
+            k = self._k(r)
+            if r != me:
+                assert k <= caps[r, 1] and nl - k <= caps[r, 0]   # (the double's counts never change: a segment always holds them)
+                ps[op:op + k, :3], ps[op:op + k, 3] = self._own[:k], idx[:k]
+                ms[on:on + nl - k, 0], ms[on:on + nl - k, 1:] = idx[k:], self._own[k:]
+            op, on = op + caps[r, 1], on + caps[r, 0]
+
+    def dist_let_finish_capped(self, caps_in, pos_recv, mp_recv, buf, a_local, param=None):
+        self.calls.append("finishc")
+        G, me = self.lay.world, self.lay.rank
+        caps = caps_in.numpy().reshape(G, 2)
+        pr, mr = pos_recv.numpy(), mp_recv.numpy()
+        assert (pr.shape[0], mr.shape[0]) == (caps[:, 1].sum(), caps[:, 0].sum()) and caps[me].tolist() == [0, 0]
+        pr = pr[pr[:, 3].copy().view(np.int32) >= 0]
+        mr = mr[mr[:, 0].copy().view(np.int32) >= 0]
+        self._finish_records(pr, mr, buf, a_local, param)
+
+    def dist_let_settle(self, ok):
+        self.calls.append("settle%d" % int(ok))
 
 
 class _Step:
@@ -319,7 +373,7 @@ def _drive(run, par, steps, dt):
     return torch.cat([run.pos.view(-1, 3), run.vel.view(-1, 3), run.acc.view(-1, 3)], dim=1).numpy()
 
 
-def _worker(rank, world, port, n, steps, dt, rebalance, outdir, split=False, let=False, repart=False):
+def _worker(rank, world, port, n, steps, dt, rebalance, outdir, split=False, let=False, repart=False, capped=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -327,9 +381,9 @@ def _worker(rank, world, port, n, steps, dt, rebalance, outdir, split=False, let
     try:
         pos, vel, par = _system(n)
         nl = n // world
-        eng = NumpyRepartEngine() if repart else (NumpyLetEngine() if let else (NumpySplitEngine() if split else NumpyDomainEngine()))
+        eng = NumpyRepartEngine() if repart else (NumpyCappedLetEngine() if capped else NumpyLetEngine() if let else (NumpySplitEngine() if split else NumpyDomainEngine()))
         run = DomainRun(eng, n, TorchComm(), device=torch.device("cpu"), rebalance=rebalance)
-        assert (run.world, run.rank, run.n_local) == (world, rank, nl) and run.split == split and run.let == let and run.dpart == repart
+        assert (run.world, run.rank, run.n_local) == (world, rank, nl) and run.split == split and run.let == let and run.dpart == repart and run.capped == capped
         if let:
             assert run.exchange_bytes() == run.allgather_bytes()   # (nothing evaluated yet)
         run.partition(torch.from_numpy(pos[rank * nl:(rank + 1) * nl]).reshape(-1), torch.from_numpy(vel[rank * nl:(rank + 1) * nl]).reshape(-1))
@@ -354,9 +408,11 @@ def _free_port():
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world,split,let,repart", [(2, False, False, False), (4, False, False, False), (2, True, False, False), (4, True, False, False),
-                                                    (2, True, True, False), (4, True, True, False), (2, True, False, True), (4, True, False, True)])
-def test_domain_run_over_gloo_matches_single_process(world, split, let, repart):
+@pytest.mark.parametrize("world,split,let,repart,capped", [(2, False, False, False, False), (4, False, False, False, False), (2, True, False, False, False),
+                                                           (4, True, False, False, False), (2, True, True, False, False), (4, True, True, False, False),
+                                                           (2, True, False, True, False), (4, True, False, True, False), (2, True, True, False, True),
+                                                           (4, True, True, False, True)])
+def test_domain_run_over_gloo_matches_single_process(world, split, let, repart, capped):
     import torch.multiprocessing as mp
     n, steps, dt, rebalance = 512, 5, 1e-2, 2
     pos, vel, par = _system(n)
@@ -364,7 +420,7 @@ def test_domain_run_over_gloo_matches_single_process(world, split, let, repart):
     one.partition(torch.from_numpy(pos).reshape(-1), torch.from_numpy(vel).reshape(-1))
     ref = _drive(one, torch.from_numpy(par), steps, dt)
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, _free_port(), n, steps, dt, rebalance, d, split, let, repart), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), n, steps, dt, rebalance, d, split, let, repart, capped), nprocs=world, join=True)
         got = np.concatenate([np.load(os.path.join(d, "rank%d.npy" % r)) for r in range(world)])
         calls = [open(os.path.join(d, "calls%d.txt" % r)).read().split() for r in range(world)]
         scal = [np.load(os.path.join(d, "scal%d.npy" % r)) for r in range(world)]
@@ -380,11 +436,22 @@ def test_domain_run_over_gloo_matches_single_process(world, split, let, repart):
     # protocol: partition first, then local/finish pairs, a re-partition after every `rebalance` evaluations
     want = ["partition"]
     ev = 0
+    rounds = 0
     for _ in range(steps + 1):
         if ev >= rebalance:
             want.append("partition")
             ev = 0
-        if let:
+        if capped and len(want) > 1:
+            # every evaluation after the first is attempted in the capped form; the attempt in which rank 0 raised its flag is void
+            # on EVERY rank and repeated in the exact form
+            rounds += 1
+            void = rounds == NumpyCappedLetEngine.VOID_ROUND
+            want += ["geom", "mpole", "select", "packc", "finishc", "settle%d" % (0 if void else 1)]
+            if void:
+                rounds += 1
+                want += ["geom", "mpole", "select", "pack", "finish"]
+        elif let:
+            rounds += 2
             # (every rank repeats the selection in the round in which rank 1 reported overflow: its first evaluation)
             want += ["geom", "mpole", "select"] + (["select"] if len(want) == 1 else []) + ["pack", "finish"]
         else:
