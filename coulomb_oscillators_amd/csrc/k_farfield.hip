@@ -397,10 +397,12 @@ __global__ __launch_bounds__(kBlock) void l2p_gen_kernel(const float4 *__restric
 	a_out[3 * o] = (float)(fx * scale); a_out[3 * o + 1] = (float)(fy * scale); a_out[3 * o + 2] = (float)(fz * scale);
 }
 
+#include "farfield_wide.hpp"   // orders 9, 10 (8 in double): a workgroup per node, a lane per component
+
 static int grid_for(long long n) { return (int)((n + kBlock - 1) / kBlock); }
 
 template <int P, typename T>
-static int run_upward(nbco_ctx *c, const float4 *pos, float *center, T *mpole, int *mult, const int *index, int L, int write_geom)
+static int run_upward_gen(nbco_ctx *c, const float4 *pos, float *center, T *mpole, int *mult, const int *index, int L, int write_geom)
 {
 	const int nleaf = 1 << L, beg = nleaf - 1;
 	hipLaunchKernelGGL((p2m_gen_kernel<P, T>), dim3(grid_for(nleaf)), dim3(kBlock), 0, c->stream, pos, (const float *)center, (const int *)mult, index,
@@ -423,7 +425,7 @@ static int run_upward(nbco_ctx *c, const float4 *pos, float *center, T *mpole, i
 
 // levels ltop .. 0 of a tree whose level ltop + 1 is already in place (the levels above the kd-domains)
 template <int P, typename T>
-static int run_m2m_top(nbco_ctx *c, float *center, T *mpole, int *mult, int ltop, int write_geom)
+static int run_m2m_top_gen(nbco_ctx *c, float *center, T *mpole, int *mult, int ltop, int write_geom)
 {
 	constexpr int offM = P * (P + 1) * (P + 2) / 6, offS = offM > 0 ? offM : 1;
 	if ((1 << ltop) > kTopNodes || (size_t)(1 << ltop) * (offS * sizeof(T) + 16) > 60 * 1024)
@@ -435,7 +437,7 @@ static int run_m2m_top(nbco_ctx *c, float *center, T *mpole, int *mult, int ltop
 }
 
 template <int P, typename T>
-static int run_downward(nbco_ctx *c, const float *center, T *local, int L, int dom_d, int dom_g)
+static int run_downward_gen(nbco_ctx *c, const float *center, T *local, int L, int dom_d, int dom_g)
 {
 	constexpr int offL = (P + 1) * (P + 1);
 	int top = kTopNodes;
@@ -466,6 +468,58 @@ static int run_downward(nbco_ctx *c, const float *center, T *local, int L, int d
 	}
 	NBCO_HIP(hipGetLastError());
 	return NBCO_OK;
+}
+
+// ---- the wide forms (farfield_wide.hpp): a workgroup per leaf / node, one launch per level (the levels are short: every
+// node's components work side by side); the generated bodies of these orders are not even instantiated
+// (the form depends on the level's HEIGHT above the leaves only -- the four lowest internal levels take the nest -- so a node is
+// shifted by the same arithmetic in every launch shape: single GPU, a domain's subtree, the levels above the domains)
+template <int P, typename T>
+static void launch_m2m_wide(nbco_ctx *c, float *center, T *mpole, int *mult, int l, int height, int write_geom)
+{
+	if (height <= 4) hipLaunchKernelGGL((m2m_wide_kernel<P, T, false>), dim3(1 << l), dim3(kWide), 0, c->stream, center, mpole, mult, l, write_geom);
+	else hipLaunchKernelGGL((m2m_wide_kernel<P, T, true>), dim3(1 << l), dim3(kWide), 0, c->stream, center, mpole, mult, l, write_geom);
+}
+template <int P, typename T>
+static int run_upward(nbco_ctx *c, const float4 *pos, float *center, T *mpole, int *mult, const int *index, int L, int write_geom)
+{
+	if constexpr (use_wide<P, T>())
+	{
+		const int nleaf = 1 << L;
+		hipLaunchKernelGGL((p2m_wide_kernel<P, T>), dim3(nleaf), dim3(kWide), 0, c->stream, pos, (const float *)center, (const int *)mult, index, mpole,
+		                   nleaf - 1);
+		for (int l = L - 1; l >= 0; --l) launch_m2m_wide<P, T>(c, center, mpole, mult, l, L - l, write_geom);
+		NBCO_HIP(hipGetLastError());
+		return NBCO_OK;
+	}
+	else return run_upward_gen<P, T>(c, pos, center, mpole, mult, index, L, write_geom);
+}
+template <int P, typename T>
+static int run_m2m_top(nbco_ctx *c, float *center, T *mpole, int *mult, int ltop, int L, int write_geom)
+{
+	if constexpr (use_wide<P, T>())
+	{
+		for (int l = ltop; l >= 0; --l) launch_m2m_wide<P, T>(c, center, mpole, mult, l, L - l, write_geom);
+		NBCO_HIP(hipGetLastError());
+		return NBCO_OK;
+	}
+	else return run_m2m_top_gen<P, T>(c, center, mpole, mult, ltop, write_geom);
+}
+template <int P, typename T>
+static int run_downward(nbco_ctx *c, const float *center, T *local, int L, int dom_d, int dom_g)
+{
+	if constexpr (use_wide<P, T>())
+	{
+		for (int lc = 2; lc <= L; ++lc)
+		{
+			// below the domain level only the own subtree's nodes are needed
+			const int first = lc >= dom_d ? dom_g << (lc - dom_d) : 0, count = lc >= dom_d ? 1 << (lc - dom_d) : 1 << lc;
+			hipLaunchKernelGGL((l2l_wide_kernel<P, T>), dim3(count), dim3(kWide), 0, c->stream, center, local, lc, first);
+		}
+		NBCO_HIP(hipGetLastError());
+		return NBCO_OK;
+	}
+	else return run_downward_gen<P, T>(c, center, local, L, dom_d, dom_g);
 }
 
 template <int P, typename T>
@@ -539,15 +593,15 @@ int launch_kd_centres_top(nbco_ctx *c, float *center, int *mult, int ltop, const
 	return NBCO_OK;
 }
 
-int launch_m2m_top_gen(nbco_ctx *c, int P, float *center, void *mpole, int *mult, int ltop, int write_geom, int f64)
+int launch_m2m_top_gen(nbco_ctx *c, int P, float *center, void *mpole, int *mult, int ltop, int L, int write_geom, int f64)
 {
 	if (f64)
 	{
-#define CALL(PP) run_m2m_top<PP, double>(c, center, (double *)mpole, mult, ltop, write_geom)
+#define CALL(PP) run_m2m_top<PP, double>(c, center, (double *)mpole, mult, ltop, L, write_geom)
 		NBCO_DISPATCH_P(P, CALL)
 #undef CALL
 	}
-#define CALL(PP) run_m2m_top<PP, float>(c, center, (float *)mpole, mult, ltop, write_geom)
+#define CALL(PP) run_m2m_top<PP, float>(c, center, (float *)mpole, mult, ltop, L, write_geom)
 	NBCO_DISPATCH_P(P, CALL)
 #undef CALL
 }

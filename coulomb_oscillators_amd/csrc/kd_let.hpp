@@ -552,7 +552,7 @@ static int dist_finish_rest(nbco_ctx *c, const char *mp_blocks, size_t mp_stride
 					                   offM, g.ntot, tv.mpole, const_cast<unsigned char *>(have.node));
 			}
 		}
-		if (d > 0) NBCO_TRY(launch_m2m_top_gen(c, P, tv.center, tv.mpole, tv.mult, d - 1, 0, f64 ? 1 : 0));
+		if (d > 0) NBCO_TRY(launch_m2m_top_gen(c, P, tv.center, tv.mpole, tv.mult, d - 1, L, 0, f64 ? 1 : 0));
 		NBCO_HIP(hipGetLastError());
 		return NBCO_OK;
 	};

@@ -363,7 +363,8 @@ int kd_select_level(nbco_ctx *c, int l, long long n, const float4 *pos_in, const
 int launch_upward_gen(nbco_ctx *c, int P, const float4 *pos, float *center, void *mpole, int *mult, const int *index, int L, int write_geom, int f64 = 0);
 int launch_kd_centres(nbco_ctx *c, float *center, int *mult, int L, const float *lbound, const float *rbound, float4 *csz);
 int launch_downward_gen(nbco_ctx *c, int P, const float *center, void *local, int L, int dom_d, int dom_g, int f64 = 0);
-int launch_m2m_top_gen(nbco_ctx *c, int P, float *center, void *mpole, int *mult, int ltop, int write_geom, int f64 = 0);
+// (L: depth of the whole tree -- the high orders pick their loop form by a level's height above the leaves)
+int launch_m2m_top_gen(nbco_ctx *c, int P, float *center, void *mpole, int *mult, int ltop, int L, int write_geom, int f64 = 0);
 int launch_kd_centres_top(nbco_ctx *c, float *center, int *mult, int ltop, const float *lbound, const float *rbound, float4 *csz);
 int launch_l2p_gen(nbco_ctx *c, int P, const float4 *pos, const float *center, const void *local, const float4 *near, const int *chunk_off,
                    const int *index, int mlt_max, const int *unsort, int scatter, const float *param, float *a, int have_near, long long n, int L,
