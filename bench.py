@@ -72,6 +72,8 @@ def parse(argv=None):
     ap.add_argument("--late-from", type=int, default=1000,
                     help="extra leg `late_phase`: the same K steps timed again after this many steps of the simulation (0 = skip)")
     ap.add_argument("--profile-all", action="store_true", help="record HIP events around every phase (perturbs value)")
+    ap.add_argument("--init-state", metavar="FILE.npy", default=None,
+                    help="diagnostics: start from a state written by --dump-state (one GPU) instead of the Gaussian ball, e.g. a late phase")
     ap.add_argument("--engine-opt", action="append", default=[], metavar="KEY=VALUE",
                     help="diagnostics: an nbco_opts field for the engine, e.g. p2p_mutual=0 (one-directional near-field kernel) or m2l_first=1")
     return ap.parse_args(argv)
@@ -423,6 +425,10 @@ def main():
         # every rank draws n_local particles of the same Gaussian ball from its own stream; sharded run: their union is the
         # N = world * n_local system, the kd-domains are cut by the first partition
         buf = gaussian_ball(n_local, 0 if slabbed else rank)
+        if args.init_state:
+            st = np.load(args.init_state).astype(np.float32).reshape(3, -1, 3)
+            assert st.shape[1] == n_local and world == 1, "--init-state: one GPU, the particle count of the dump"
+            buf = np.ascontiguousarray(st)
         d0 = torch.from_numpy(buf).cuda()
         d = d0.clone()
         prm = torch.from_numpy(coulomb_params(n_sys)).cuda()
@@ -630,7 +636,17 @@ def main():
         il = eng.kd_info()
         late = {"steps_from": done + todo + 2, "steps": args.steps, "tree_steps": args.tree_steps, "ms_per_step": 1e3 * el / args.steps,
                 "value": n * args.steps / el, "unit": "particle-steps/s", "directed_pairs_per_eval": int(il.directed_p2p), "p2p_pairs": int(il.p2p_pairs),
-                "warm_builds": int(il.warm_builds), "warm_misses": int(il.warm_misses)}
+                "m2l_pairs": int(il.m2l_pairs), "warm_builds": int(il.warm_builds), "warm_misses": int(il.warm_misses)}
+        # where those steps spend their time: a few more of them with HIP events around every phase (outside the timed stretch)
+        eng.profile(True)
+        eng.profile_reset()
+        run_steps(4)
+        torch.cuda.synchronize()
+        eng.profile(False)
+        late["phase_ms_per_step"] = {k: v[0] / 4 for k, v in eng.profile_get().items() if v[1]}
+        dp = late["directed_pairs_per_eval"]
+        if late["phase_ms_per_step"].get("p2p"):
+            late["near_field_frac"] = dp * FLOP_PER_PAIR / (late["phase_ms_per_step"]["p2p"] * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS
 
     # the metric reads "N = 1M ... at 1/2/4/8 GPUs": ONE system of --particles cut into `world` kd-domains (strong scaling),
     # next to the headline value, which keeps --particles per GPU (weak scaling)

@@ -371,6 +371,9 @@ __global__ __launch_bounds__(kBlock) void l2p_gen_kernel(const float4 *__restric
 		float nx = 0.f, ny = 0.f, nz = 0.f;
 		int ck0 = chunk_off[lf], ck1 = chunk_off[lf + 1];
 		if (!NBCO_CHECKED_OK(ck0 >= 0 && ck0 <= ck1 && j >= 0 && j < mlt_max, NBCO_CHK_L2P)) ck1 = ck0;
+		// (eight partial sums requested per wait: late in a run a leaf stretched by an ejected particle has a thousand work units, and
+		// one load per round trip made this loop -- not the pair kernel -- the tail of the step.  Same additions in the same order.)
+#pragma unroll 8
 		for (int ck = ck0; ck < ck1; ++ck)
 		{
 			const float4 nr = near[(size_t)ck * mlt_max + j];
@@ -383,7 +386,7 @@ __global__ __launch_bounds__(kBlock) void l2p_gen_kernel(const float4 *__restric
 			int2 sr = sec_range[lf];
 			if (!NBCO_CHECKED_OK(sr.x >= 0 && sr.x <= sr.y, NBCO_CHK_L2P)) sr.y = sr.x;
 			if (sr.y > react_cap) sr.y = max(sr.x, react_cap);   // (the host repeats an evaluation whose list outgrew the records)
-#pragma unroll 4
+#pragma unroll 8
 			for (int e = sr.x; e < sr.y; ++e)
 			{
 				const float4 rr = react[(size_t)e * react_stride + j];
@@ -445,7 +448,18 @@ static int run_downward_gen(nbco_ctx *c, const float *center, T *local, int L, i
 	int ltop = 1;
 	while (ltop + 1 <= L && (1 << (ltop + 1)) <= top) ++ltop;
 	if (ltop >= 2)
-		hipLaunchKernelGGL((l2l_top_kernel<P, T>), dim3(1), dim3(kTopNodes), (size_t)(1 << ltop) * offL * sizeof(T), c->stream, center, local, ltop);
+	{
+		// The levels with at most 256 nodes, one launch per level, a one-wave workgroup per node with a lane per component
+		// (farfield_wide.hpp; ~30 registers and 3 KB of LDS).  They used to be ONE workgroup of 256 threads x 128 registers with 50 KB
+		// of LDS walking the levels (l2l_top_kernel): beside the near-field kernel, which holds 480 of a SIMD's 512 registers and
+		// most of the LDS, such a workgroup waits until two near-field workgroups of one CU retire together -- 30-90 us in the
+		// benchmark's first steps, and 1.0 ms of a 3.0 ms step once the lists have grown (`profiles/r03q_late_timeline_l2l_top_starved.txt`): the whole
+		// far-field chain behind it, and with it L2P, waited for the near-field kernel's tail.  A thin workgroup always fits.
+		constexpr int offD = P * (P + 1) * (P + 2) / 6;
+		const int threads = 64 * ((std::max(offD, offL) + 63) / 64);
+		for (int lc = 2; lc <= ltop; ++lc)
+			hipLaunchKernelGGL((l2l_wide_kernel<P, T>), dim3(1 << lc), dim3(threads), 0, c->stream, center, local, lc, 0);
+	}
 	// the lowest levels in one launch, a workgroup per subtree (<= 256 leaves, parents' tuples in <= 60 KB of LDS)
 	int lroot = L;
 	if (ltop >= 2)

@@ -457,6 +457,7 @@ __global__ __launch_bounds__(kBlock) void oct_l2p_kernel(OctView<T> t, const flo
 		const int per = (desc_off[c + 1] - desc_off[c] + kOctChunk - 1) / kOctChunk;
 		const int ck0 = chunk_off[c] + g * per;
 		float nx = 0.f, ny = 0.f, nz = 0.f;
+#pragma unroll 8
 		for (int ck = ck0; ck < ck0 + per; ++ck)
 		{
 			const float4 nr = near[(size_t)ck * tpl + j];

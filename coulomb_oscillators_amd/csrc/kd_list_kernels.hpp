@@ -105,7 +105,7 @@ struct MutualLists
 template <bool DESC>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void list_segsort_kernel(const int *__restrict__ start, int ntargets, uint64_t *in, uint64_t *out, int shift,
                                                               const int *__restrict__ leaf_index, const int *__restrict__ leaf_mult,
-                                                              int2 *__restrict__ desc, MutualLists mu)
+                                                              int2 *__restrict__ desc, MutualLists mu, int long_from)
 {
 	__shared__ unsigned digit_off[kBlock / 64][256];   // long ranges only: per-wave digit offsets of the radix passes
 	const uint64_t smask = (1ull << shift) - 1;
@@ -208,6 +208,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 	{
 		// wave-uniform by construction; telling the compiler so keeps the loops scalar
 		const int s = __builtin_amdgcn_readfirstlane(start[t]), cnt = __builtin_amdgcn_readfirstlane(start[t + 1]) - s;
+		if (long_from > 0 && cnt > long_from) continue;   // (list_longsort_kernel, launched behind this one, takes the long ranges)
 		if (cnt <= 64) rank_in_registers(std::integral_constant<int, 1>{}, t, s, cnt);
 		else if (cnt <= 128) rank_in_registers(std::integral_constant<int, 2>{}, t, s, cnt);
 		else if (cnt <= 192) rank_in_registers(std::integral_constant<int, 3>{}, t, s, cnt);
@@ -274,6 +275,111 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 				nq += __popcll(__ballot(i < cnt && sv < t));
 			}
 			if (DESC && mu.desc4) finish_target(t, s, cnt, nf, nq, lane);
+		}
+	}
+}
+
+// ---- long ranges of the P2P list --------------------------------------------------------------------------------------------
+// A thousand steps into the benchmark's run a few leaves have been stretched by ejected particles and are partners of most of
+// the tree: 140 targets hold a quarter of all entries, the longest 16 000 (`profiles/r03o_late_lists.txt`).  One wave per
+// target -- list_segsort_kernel's mapping -- then means the whole sort waits for the one wave with the longest range (0.54 of
+// a 3.0 ms step).  When the previous evaluation's lists say that long ranges are to be expected the host launches this kernel
+// behind the sort and tells the sort to leave ranges above `long_from` entries alone.  A workgroup collects the long targets
+// a hash assigns to it and sorts them one by one with all its threads.  The sources of one target are distinct, so an entry's
+// place in the sorted range is the number of set bits below its source in a bitmap of the range's sources (trees of up to
+// 2^16 leaves): two passes over the range with nothing carried from one entry to the next.  Same output as the sort's own
+// long-range path, entry for entry.
+constexpr int kLongBlock = 256, kLongWords = 2048;
+__global__ __launch_bounds__(kLongBlock) void list_longsort_kernel(const int *__restrict__ start, int ntargets, const uint64_t *__restrict__ in,
+                                                                    uint64_t *__restrict__ out, int shift, const int *__restrict__ leaf_index,
+                                                                    const int *__restrict__ leaf_mult, int2 *__restrict__ desc, MutualLists mu, int long_from)
+{
+	__shared__ unsigned words[kLongWords], pref[kLongWords];   // bitmap of the sources; set bits in front of every word
+	__shared__ unsigned wsum[kLongBlock / 64];
+	__shared__ int todo[kLongBlock], ntodo;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const uint64_t smask = (1ull << shift) - 1;
+	const int lowbit = mu.desc4 ? 32 : 0;
+	const int nw = 1 << (shift - 5);                             // words in use (shift <= 16, checked by the host)
+	const int per = (nw + kLongBlock - 1) / kLongBlock;          // consecutive words per thread in the prefix pass
+	// every workgroup looks at all targets and keeps the long ones a hash of their number assigns to it: stretched leaves are
+	// neighbours in the tree, a workgroup that took a contiguous share would get all of them
+	for (int t0 = 0; t0 < ntargets; t0 += kLongBlock)
+	{
+		if (tid == 0) ntodo = 0;
+		__syncthreads();
+		const int mine = t0 + tid;
+		if (mine < ntargets && start[mine + 1] - start[mine] > long_from && (((unsigned)mine * 2654435761u) >> 12) % gridDim.x == blockIdx.x)
+			todo[atomicAdd(&ntodo, 1)] = mine;
+		__syncthreads();
+		const int n = ntodo;
+		for (int e = 0; e < n; ++e)
+		{
+			const int t = todo[e], s = start[t], cnt = start[t + 1] - s;
+			for (int w = tid; w < nw; w += kLongBlock) words[w] = 0u;
+			__syncthreads();
+#pragma unroll 4
+			for (int i = tid; i < cnt; i += kLongBlock)
+			{
+				const unsigned sv = (unsigned)((in[s + i] >> lowbit) & smask);
+				atomicOr(&words[sv >> 5], 1u << (sv & 31u));
+			}
+			__syncthreads();
+			// set bits in front of every word: per thread a run of `per` words, then a scan over the threads
+			unsigned sum = 0;
+			for (int q = 0; q < per; ++q)
+			{
+				const int w = tid * per + q;
+				if (w < nw) { pref[w] = sum; sum += (unsigned)__popc(words[w]); }
+			}
+			const unsigned incl = wave_scan_add(sum);
+			if (lane == 63) wsum[wv] = incl;
+			__syncthreads();
+			unsigned base = incl - sum;
+			for (int q = 0; q < wv; ++q) base += wsum[q];
+			for (int q = 0; q < per; ++q)
+			{
+				const int w = tid * per + q;
+				if (w < nw) pref[w] += base;
+			}
+			__syncthreads();
+			auto below = [&](unsigned sv) {
+				const unsigned w = sv >> 5;
+				return (int)(pref[w] + (unsigned)__popc(words[w] & ((1u << (sv & 31u)) - 1u)));
+			};
+#pragma unroll 2
+			for (int i = tid; i < cnt; i += kLongBlock)
+			{
+				const uint64_t key = in[s + i];
+				const int sv = (int)((key >> lowbit) & smask), slot = s + below((unsigned)sv);
+				if (!NBCO_CHECKED_OK(sv >= 0 && sv < ntargets && slot >= s && slot < s + cnt, NBCO_CHK_SORT)) continue;
+				if (mu.desc4)
+				{
+					out[slot] = ((uint64_t)t << shift) | (uint64_t)sv;
+					const int code = (sv == t || sv < mu.self0 || sv >= mu.self0 + mu.nself) ? 0 : (sv > t ? 1 : 2);
+					mu.desc4[slot] = make_int4(leaf_index[sv], leaf_mult[sv], (int)(uint32_t)key, code);
+				}
+				else
+				{
+					out[slot] = key;
+					desc[slot] = make_int2(leaf_index[sv], leaf_mult[sv]);
+				}
+			}
+			if (mu.desc4)
+			{
+				// work units of the mutual near field: list_segsort_kernel's finish_target
+				const int nf = below((unsigned)min(max(mu.self0, 0), (1 << shift) - 1)), nq = below((unsigned)t);
+				const int o = mu.chunk_off[t], nu = mu.chunk_off[t + 1] - o;
+				const int w = nf + (cnt - nq), share = nu > 0 ? (w + nu - 1) / nu : 0;
+				const int ind = leaf_index[t], mlt = leaf_mult[t];
+				for (int i = tid; i < nu; i += kLongBlock)
+				{
+					const int jb = min(i * share, w), je = min((i + 1) * share, w);
+					mu.chunk[o + i] = make_int4(ind, s + (jb < nf ? jb : jb - nf + nq), s + (je <= nf ? je : je - nf + nq), mlt);
+				}
+				if (tid == 0) mu.sec_range[t] = make_int2(s + nf, s + nq);
+			}
+			__syncthreads();
 		}
 	}
 }

@@ -203,21 +203,40 @@ __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab
 		// are issued before any of their results is used, and before the barrier that publishes the block's reservations, so
 		// they share that round trip.  (They count even when a region turns out to be full: traverse_finish_kernel clears
 		// the per-target counts of an overflowed traversal.)
-		auto slots = [&](int q, int2 np, bool ok) {
-			int2 r = make_int2(-1, -1);
-			if (q == 1 && ok)
+		// Lanes of a wave that count the SAME target share one atomic: the group of the first such lane is served by that lane
+		// (count = the group's size, every member takes the returned base plus its place in the group), everybody else goes
+		// alone.  In the benchmark's first steps neighbouring pairs rarely share a target; a thousand steps in, a leaf stretched
+		// by an ejected particle is a partner of ten thousand pairs in a row -- all lanes of wave after wave on one address, each
+		// atomic retiring ~27 ns after the one before (the four widest launches took 77-280 us each, `profiles/r03o_late_kernels_before.txt`).
+		// Still issued before any result is used: a request keeps {serving lane, place, pending result of the serving lane}.
+		const int lane = threadIdx.x & 63;
+		const int m2l_at = (int)(cnt_m2l - cnt_p2p);   // (one allocation: [cnt_p2p | fill_p2p | cnt_m2l | fill_m2l])
+		struct Req { int from, place; unsigned pend; };
+		auto request = [&](int key, bool on) {
+			Req r{lane, 0, 0u};
+			const uint64_t todo = __ballot(on);
+			int size = 1;
+			if (todo)   // wave-uniform
 			{
-				if (dm.d == 0 || dom_touch(dm, np.x)) r.x = (int)atomicAdd(&cnt_p2p[np.x - lbeg], 1u);
-				if (dm.d == 0 || dom_touch(dm, np.y)) r.y = (int)atomicAdd(&cnt_p2p[np.y - lbeg], 1u);
+				const int first = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)todo) - 1);
+				const int v = __builtin_amdgcn_readlane(key, first);
+				const uint64_t same = __ballot(on && key == v);
+				if (on && key == v) { r.from = first; r.place = __popcll(same & ((1ull << lane) - 1ull)); size = __popcll(same); }
 			}
-			if (q == 2 && ok)
-			{
-				if (dm.d == 0 || dom_touch(dm, np.x)) r.x = (int)atomicAdd(&cnt_m2l[np.x], 1u);
-				if (dm.d == 0 || dom_touch(dm, np.y)) r.y = (int)atomicAdd(&cnt_m2l[np.y], 1u);
-			}
+			if (on && r.from == lane) r.pend = atomicAdd(&cnt_p2p[key], (unsigned)size);
 			return r;
 		};
-		const int2 r0 = slots(k0, p0, nch == 0 && i < nin), r1 = slots(k1, ch.a, nch > 0), r2 = slots(k2, ch.b, nch > 1), r3 = slots(k3, ch.c, nch > 2);
+		auto slots = [&](int q, int2 np, bool ok, Req &rx, Req &ry) {
+			const bool lst = ok && (q == 1 || q == 2);
+			const int kx = q == 1 ? np.x - lbeg : m2l_at + np.x, ky = q == 1 ? np.y - lbeg : m2l_at + np.y;
+			rx = request(kx, lst && (dm.d == 0 || dom_touch(dm, np.x)));
+			ry = request(ky, lst && (dm.d == 0 || dom_touch(dm, np.y)));
+			// (-1: the node belongs to another domain)
+			return make_int2(lst && (dm.d == 0 || dom_touch(dm, np.x)) ? 0 : -1, lst && (dm.d == 0 || dom_touch(dm, np.y)) ? 0 : -1);
+		};
+		Req q0x, q0y, q1x, q1y, q2x, q2y, q3x, q3y;
+		int2 r0 = slots(k0, p0, nch == 0 && i < nin, q0x, q0y), r1 = slots(k1, ch.a, nch > 0, q1x, q1y), r2 = slots(k2, ch.b, nch > 1, q2x, q2y),
+		     r3 = slots(k3, ch.c, nch > 2, q3x, q3y);
 		// The barrier publishes the block's three reservations (sh_base, LDS).  It must NOT wait for the slot atomics above, which
 		// take 2-8 us to come back in a wide launch: an LDS-only barrier (no workgroup fence, which would drain the vector-memory
 		// counter), the pairs and the next frontier are stored under that wait, the slots last.
@@ -260,6 +279,13 @@ __global__ __launch_bounds__(kBlock) void traverse_kernel(TreeView t, AdmTab tab
 			at2 = emit(k2, ch.b);
 			if (nch > 2) at3 = emit(k3, ch.c);
 		}
+		// the slots: the serving lane's result plus the place in its group (all lanes take part in the exchange)
+		auto settle = [&](const Req &rq, int &slot) {
+			const int base = __shfl((int)rq.pend, rq.from);
+			if (slot >= 0) slot = base + rq.place;
+		};
+		settle(q0x, r0.x); settle(q0y, r0.y); settle(q1x, r1.x); settle(q1y, r1.y);
+		settle(q2x, r2.x); settle(q2y, r2.y); settle(q3x, r3.x); settle(q3y, r3.y);
 		TRAV_DEP(r0.x + r1.x + r2.x + r3.x + r0.y + r1.y + r2.y + r3.y);
 		TRAV_MARK(6);
 		auto put_slots = [&](int q, long long at, int2 r) {

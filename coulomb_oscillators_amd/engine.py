@@ -45,7 +45,7 @@ class KdInfo(C.Structure):
     _fields_ = [("L", C.c_int), ("ntot", C.c_int), ("order", C.c_int), ("mlt_max", C.c_int), ("n", C.c_longlong),
                 ("p2p_pairs", C.c_longlong), ("m2l_pairs", C.c_longlong), ("directed_p2p", C.c_longlong),
                 ("rebuilt", C.c_int), ("build_mode", C.c_int), ("p2p_halves", C.c_int), ("warm_builds", C.c_longlong), ("warm_misses", C.c_longlong),
-                ("real_bytes", C.c_int)]
+                ("real_bytes", C.c_int), ("long_lists", C.c_int)]
 
 
 class OctInfo(C.Structure):

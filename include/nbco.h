@@ -174,6 +174,8 @@ typedef struct nbco_kd_info {
 	long long warm_builds;      /* builds whose median selection ran ONE histogram pass per level around the previous build's pivots */
 	long long warm_misses;      /* .. of which a window missed the median: the evaluation was repeated with the two-pass select */
 	int real_bytes;             /* element size of NBCO_KD_MPOLE / NBCO_KD_LOCAL: 4, or 8 when the tree was built with opts.far_fp64 */
+	int long_lists;             /* 1: the last evaluation sorted the long ranges of its near-field list (more than 512 entries of one
+	                               target: leaves stretched by ejected particles, late in a run) with the kernel made for them */
 } nbco_kd_info;
 int nbco_kd_get_info(nbco_ctx *c, nbco_kd_info *info);
 

@@ -94,6 +94,41 @@ def test_long_interaction_lists(engine, oracle32, radius, n, p):
     engine.set(tree_radius=1.0)
 
 
+@pytest.mark.parametrize("mutual", [0, 1])
+def test_long_ranges_take_their_own_kernel_when_the_lists_are_long(oracle32, mutual):
+    """Late in a run a few stretched leaves are partners of most of the tree.  When the PREVIOUS evaluation's list averaged more
+    than 48 entries per target, the per-target sort leaves ranges above 512 entries to list_longsort_kernel (a workgroup per long
+    range, places from a bitmap of the range's sources).  Here: a wide opening radius and three far-away particles (their
+    leaves pair with everything); the first evaluation of a context sorts the long ranges itself (the radix path), the second
+    one hands them over -- same lists, same accelerations, bit for bit, with both near-field kernels."""
+    import torch
+    from coulomb_oscillators_amd import EVAL_FMM_KDTREE, Engine
+    o = oracle32
+    n, p = 65536, 3
+    buf = o.init_reference(n)
+    buf[0, :3] = np.array([[40.0, 0, 0], [0, -55.0, 0], [0, 0, 70.0]], dtype=np.float32) * np.abs(buf[0]).max()
+    par = torch.from_numpy(o.params(n)).cuda()
+    eng = Engine(fmm_order=p, unsort=0, tree_steps=1, tree_radius=2.0, p2p_mutual=mutual)
+    d = torch.from_numpy(buf.copy()).cuda()
+    out = []
+    for k in range(3):
+        eng.compute_force(EVAL_FMM_KDTREE, d, n, par)
+        torch.cuda.synchronize()
+        info = eng.kd_info()
+        out.append((d.clone(), canon_pairs(eng.kd_array("p2p")), info.long_lists, info.directed_p2p))
+        pairs = eng.kd_array("p2p")
+    beg = (1 << info.L) - 1
+    per_target = np.bincount(np.concatenate([pairs[:, 0], pairs[:, 1]]) - beg, minlength=1 << info.L) + 1
+    assert per_target.max() > 2000 and per_target.mean() > 48 and 11 <= info.L + 1 <= 16, (per_target.max(), per_target.mean(), info.L)
+    assert [x[2] for x in out] == [0, 1, 1]          # the first evaluation has no previous list to go by
+    assert torch.isfinite(out[0][0]).all()
+    for k in (1, 2):
+        assert torch.equal(out[k][0], out[0][0])      # positions (tree order), velocities, accelerations
+        np.testing.assert_array_equal(out[k][1], out[0][1])
+        assert out[k][3] == out[0][3]
+    eng.close()
+
+
 def test_reference_test_mode_error_table_on_gpu(engine, oracle32):
     """The GPU evaluator reproduces the reference's recorded `-test` error table (main3.cu:790-811)."""
     with open(os.path.join(GOLD, "reference_recorded.json")) as f:
