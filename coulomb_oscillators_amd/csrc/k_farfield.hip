@@ -257,46 +257,7 @@ __global__ __launch_bounds__(kBlock) void l2l_gen_kernel(const float *__restrict
 	l2l_node<P, T, false>(center, local, (1 << lchild) - 1 + first + i);
 }
 
-// child levels 2 .. ltop in one workgroup; the level just finished stays in LDS as the next level's parents
-template <int P, typename T>
-__global__ __launch_bounds__(kTopNodes) void l2l_top_kernel(const float *__restrict__ center, T *local, int ltop)
-{
-	constexpr int offL = (P + 1) * (P + 1);
-	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-	T *lds = reinterpret_cast<T *>(lds_raw);   // [2^ltop][offL]
-	const int t = threadIdx.x;
-	// level-1 nodes are the first parents
-	if (t < 2)
-		for (int q = 0; q < offL; ++q) lds[(size_t)t * offL + q] = local[(size_t)(1 + t) * offL + q];
-	__syncthreads();
-	for (int lc = 2; lc <= ltop; ++lc)
-	{
-		const bool on = t < (1 << lc);
-		const int c = (1 << lc) - 1 + t, p = (c - 1) >> 1;
-		T O[offL];
-		if (on)
-		{
-			T Lp[offL];
-			const T *src = lds + (size_t)(t >> 1) * offL;
-#pragma unroll
-			for (int q = 0; q < offL; ++q) Lp[q] = src[q];
-			l2l_body<P>(Lp, (T)center[3 * c] - (T)center[3 * p], (T)center[3 * c + 1] - (T)center[3 * p + 1], (T)center[3 * c + 2] - (T)center[3 * p + 2], O);
-			T *Lc = local + (size_t)c * offL;
-#pragma unroll
-			for (int q = 1; q < offL; ++q) { O[q] += Lc[q]; Lc[q] = O[q]; }
-			O[0] = T(0);
-		}
-		__syncthreads();
-		if (on)
-		{
-			T *dst = lds + (size_t)t * offL;
-#pragma unroll
-			for (int q = 0; q < offL; ++q) dst[q] = O[q];
-		}
-		__syncthreads();
-	}
-}
-
+// (child levels 2 .. ltop ran in ONE workgroup of this shape, l2l_top_kernel, until round 3: see run_downward_gen)
 // child levels lroot + 1 .. L of the subtrees hanging off level lroot, one workgroup per subtree: the level just
 // finished stays in LDS as the next level's parents, so the whole lower part of the downward pass is one launch
 // (per-level launches cost 10-25 us each while the near-field kernel fills the chip on the other stream).
