@@ -194,7 +194,7 @@ static int build_directed_list(nbco_ctx *c, const int2 *pairs, const int2 *ranks
 		// Long ranges (leaves stretched by ejected particles, late in a run) go to a kernel of their own when the previous
 		// evaluation's list says they are to be expected: more than 48 entries per target on average (17 in the benchmark's first
 		// steps, 109 a thousand steps in).  Either way every range is sorted; the choice only moves the long ones.
-		const bool long_kernel = shift >= 11 && shift <= 16 && c->hint_np2p > 0 && 2 * c->hint_np2p > 48LL * ntargets;
+		const bool long_kernel = shift >= 11 && shift <= 16 && c->hint_np2p > 0 && 2 * c->hint_np2p > 48LL * (nself > 0 ? nself : ntargets);   // (per OWN target)
 		const int long_from = long_kernel ? 512 : 0;
 		c->info.long_lists = long_kernel ? 1 : 0;
 		hipLaunchKernelGGL(list_segsort_kernel<true>, dim3((ntargets + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, (const int *)start, ntargets,

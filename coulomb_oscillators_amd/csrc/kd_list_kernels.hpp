@@ -296,7 +296,7 @@ __global__ __launch_bounds__(kLongBlock) void list_longsort_kernel(const int *__
 {
 	__shared__ unsigned words[kLongWords], pref[kLongWords];   // bitmap of the sources; set bits in front of every word
 	__shared__ unsigned wsum[kLongBlock / 64];
-	__shared__ int todo[kLongBlock], ntodo;
+	__shared__ int todo[kLongBlock * 8], ntodo;   // (room for every target of a round)
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const uint64_t smask = (1ull << shift) - 1;
 	const int lowbit = mu.desc4 ? 32 : 0;
@@ -304,13 +304,20 @@ __global__ __launch_bounds__(kLongBlock) void list_longsort_kernel(const int *__
 	const int per = (nw + kLongBlock - 1) / kLongBlock;          // consecutive words per thread in the prefix pass
 	// every workgroup looks at all targets and keeps the long ones a hash of their number assigns to it: stretched leaves are
 	// neighbours in the tree, a workgroup that took a contiguous share would get all of them
-	for (int t0 = 0; t0 < ntargets; t0 += kLongBlock)
+	constexpr int kPerThread = 8;   // targets per thread and round (the list has room for all of a round's)
+	for (int t0 = 0; t0 < ntargets; t0 += kLongBlock * kPerThread)
 	{
 		if (tid == 0) ntodo = 0;
 		__syncthreads();
-		const int mine = t0 + tid;
-		if (mine < ntargets && start[mine + 1] - start[mine] > long_from && (((unsigned)mine * 2654435761u) >> 12) % gridDim.x == blockIdx.x)
-			todo[atomicAdd(&ntodo, 1)] = mine;
+#pragma unroll
+		for (int q = 0; q < kPerThread; ++q)
+		{
+			const int mine = t0 + q * kLongBlock + tid;
+			if (mine < ntargets && start[mine + 1] - start[mine] > long_from && (((unsigned)mine * 2654435761u) >> 12) % gridDim.x == blockIdx.x)
+			{
+				todo[atomicAdd(&ntodo, 1)] = mine;
+			}
+		}
 		__syncthreads();
 		const int n = ntodo;
 		for (int e = 0; e < n; ++e)
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(kLongBlock) void list_longsort_kernel(const int *__
 			const int t = todo[e], s = start[t], cnt = start[t + 1] - s;
 			for (int w = tid; w < nw; w += kLongBlock) words[w] = 0u;
 			__syncthreads();
-#pragma unroll 4
+#pragma unroll 8
 			for (int i = tid; i < cnt; i += kLongBlock)
 			{
 				const unsigned sv = (unsigned)((in[s + i] >> lowbit) & smask);
@@ -347,7 +354,7 @@ __global__ __launch_bounds__(kLongBlock) void list_longsort_kernel(const int *__
 				const unsigned w = sv >> 5;
 				return (int)(pref[w] + (unsigned)__popc(words[w] & ((1u << (sv & 31u)) - 1u)));
 			};
-#pragma unroll 2
+#pragma unroll 8
 			for (int i = tid; i < cnt; i += kLongBlock)
 			{
 				const uint64_t key = in[s + i];
