@@ -408,7 +408,6 @@ static int run_downward_gen(nbco_ctx *c, const float *center, T *local, int L, i
 	while (top > 4 && (size_t)top * offL * sizeof(T) > 60 * 1024) top >>= 1;
 	int ltop = 1;
 	while (ltop + 1 <= L && (1 << (ltop + 1)) <= top) ++ltop;
-	if (ltop >= 2)
 	{
 		// The levels with at most 256 nodes, one launch per level, a one-wave workgroup per node with a lane per component
 		// (farfield_wide.hpp; ~30 registers and 3 KB of LDS).  They used to be ONE workgroup of 256 threads x 128 registers with 50 KB
@@ -416,24 +415,27 @@ static int run_downward_gen(nbco_ctx *c, const float *center, T *local, int L, i
 		// most of the LDS, such a workgroup waits until two near-field workgroups of one CU retire together -- 30-90 us in the
 		// benchmark's first steps, and 1.0 ms of a 3.0 ms step once the lists have grown (`profiles/r03q_late_timeline_l2l_top_starved.txt`): the whole
 		// far-field chain behind it, and with it L2P, waited for the near-field kernel's tail.  A thin workgroup always fits.
-		constexpr int offD = P * (P + 1) * (P + 2) / 6;
-		const int threads = 64 * ((std::max(offD, offL) + 63) / 64);
-		for (int lc = 2; lc <= ltop; ++lc)
-			hipLaunchKernelGGL((l2l_wide_kernel<P, T>), dim3(1 << lc), dim3(threads), 0, c->stream, center, local, lc, 0);
 	}
-	// the lowest levels in one launch, a workgroup per subtree (<= 256 leaves, parents' tuples in <= 60 KB of LDS)
+	// The lowest levels in one launch, a workgroup per subtree of at most 128 leaves (two waves, the parents' tuples in LDS); the
+	// levels between run as thin workgroups as well.  (Subtrees of 256 leaves -- trees of 2^16 leaves and more -- meant
+	// workgroups of four 128-register waves: 37 us at N = 1M became 175-200 us at N = 2M beside the near-field kernel.)
+	// The arithmetic of a level depends on the level alone (wide form up to wtop, generated body below), whatever the launch shape.
+	constexpr int offD = P * (P + 1) * (P + 2) / 6;
+	const int threads = 64 * ((std::max(offD, offL) + 63) / 64);
+	const int wtop = ltop >= 2 ? std::max(ltop, L - 7) : 1;
 	int lroot = L;
 	if (ltop >= 2)
 	{
-		lroot = std::max(ltop, L - 8);
+		lroot = wtop;
 		while (lroot < L && (size_t)(1 << (L - lroot - 1)) * offL * sizeof(T) > 60 * 1024) ++lroot;
 		if (lroot < dom_d) lroot = L;   // never with <= 8 domains; keep the per-level path for that case
 	}
-	for (int lc = ltop + 1; lc <= lroot; ++lc)
+	for (int lc = 2; lc <= lroot; ++lc)
 	{
 		// below the domain level only the own subtree's nodes are needed
 		const int first = lc >= dom_d ? dom_g << (lc - dom_d) : 0, count = lc >= dom_d ? 1 << (lc - dom_d) : 1 << lc;
-		hipLaunchKernelGGL((l2l_gen_kernel<P, T>), dim3(grid_for(count)), dim3(kBlock), 0, c->stream, center, local, lc, first, count);
+		if (lc <= wtop) hipLaunchKernelGGL((l2l_wide_kernel<P, T>), dim3(count), dim3(threads), 0, c->stream, center, local, lc, first);
+		else hipLaunchKernelGGL((l2l_gen_kernel<P, T>), dim3(grid_for(count)), dim3(kBlock), 0, c->stream, center, local, lc, first, count);
 	}
 	if (lroot < L)
 	{
