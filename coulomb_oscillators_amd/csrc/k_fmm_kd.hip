@@ -344,12 +344,12 @@ static int kd_build_upward(nbco_ctx *c, const float *p, long long n, int L, cons
 			NBCO_TRY(kd_build_top(c, tv, pos, pos_alt, unsort, unsort_alt, n, l0, use_select, true, warm));
 			// the rest of every level-l0 subtree inside one workgroup's LDS
 			hipLaunchKernelGGL(kd_subtree_kernel, dim3(kd_cnt(l0)), dim3(kSubT), 0, st, tv, (const float4 *)pos, (const int *)unsort, pos_alt, unsort_alt, n, l0,
-			                   use_select ? 1 : 0, c->sel_three_pass ? 0 : 1, c->counters.as<int>() + 110);
+			                   use_select ? 1 : 0, c->sel_three_pass ? 0 : 1, c->counters.as<int>() + 110, c->top_sd, c->top_root1);
 #ifdef NBCO_SUBTREE_PROF
 			// the kernel only reads its inputs: a second launch right behind the first one repeats it with warm instruction caches
 			if (std::getenv("NBCO_SUBTREE_TWICE"))
 				hipLaunchKernelGGL(kd_subtree_kernel, dim3(kd_cnt(l0)), dim3(kSubT), 0, st, tv, (const float4 *)pos, (const int *)unsort, pos_alt, unsort_alt, n, l0,
-				                   use_select ? 1 : 0, c->sel_three_pass ? 0 : 1, c->counters.as<int>() + 110);
+				                   use_select ? 1 : 0, c->sel_three_pass ? 0 : 1, c->counters.as<int>() + 110, c->top_sd, c->top_root1);
 #endif
 			std::swap(pos, pos_alt);
 			std::swap(unsort, unsort_alt);

@@ -497,7 +497,8 @@ __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__re
                                                                const int *__restrict__ sd_l, SelNode *__restrict__ nodes,
                                                                uint32_t *__restrict__ tielist, long long n, int l, float *__restrict__ lbound,
                                                                float *__restrict__ rbound, int *__restrict__ splitdim, int *__restrict__ index,
-                                                               int *__restrict__ flag, const uint32_t *__restrict__ hist, int drop)
+                                                               int *__restrict__ flag, const uint32_t *__restrict__ hist, int drop,
+                                                               const int *__restrict__ top_sd, int top_root1)
 {
 	constexpr int CHUNK = EPT * BLOCK;
 	static_assert(CHUNK < 65536, "packed 16-bit block counters");
@@ -530,7 +531,14 @@ __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__re
 		if (j <= j1)
 		{
 			const int node = (int)(m - 1 + j), left = 2 * node + 1;
-			if (t < 32) { if (t < l) v = (uint32_t)splitdim[(((int)(m + j)) >> (t + 1)) - 1]; }
+			if (t < 32)
+			{
+				// ancestors inside this tree, then -- the local build of a kd-domain -- the domain root's ancestors in the global
+				// tree: the stable-sort chain's keys reach back to the global root (3 = none)
+				v = 3u;
+				if (t < l) v = (uint32_t)splitdim[(((int)(m + j)) >> (t + 1)) - 1];
+				else if (top_sd) { const int up = top_root1 >> (t - l + 1); if (up > 0) v = (uint32_t)top_sd[up - 1]; }
+			}
 			else if (t == kMetaSd) v = (uint32_t)sd_l[j];
 			else if (t < kMetaRb) v = __float_as_uint(lbound[3 * node + (t - kMetaLb)]);
 			else if (t < kMetaOld) v = __float_as_uint(rbound[3 * node + (t - kMetaRb)]);
@@ -554,9 +562,10 @@ __global__ __launch_bounds__(BLOCK) void sel_partition_kernel(const float4 *__re
 	{
 		const int a1 = (int)meta[threadIdx.x][kMetaSd];
 		int a2 = -1, a3 = -1;
-		for (int t = 0; t < l && t < 32; ++t)
+		for (int t = 0; t < 32; ++t)
 		{
 			const int a = (int)meta[threadIdx.x][t];
+			if (a > 2) break;   // (above the global root)
 			if (a == a1 || a == a2) continue;
 			if (a2 < 0) a2 = a;
 			else { a3 = a; break; }
@@ -796,7 +805,7 @@ static void select_level_launch(nbco_ctx *c, int l, long long n, const float4 *p
 		hipLaunchKernelGGL((sel_hist_warm_kernel<BLOCK, EPT>), dim3(wchunks), dim3(BLOCK), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound,
 		                   n, l, warm_drop);
 		hipLaunchKernelGGL((sel_partition_kernel<BLOCK, 2, true, EPT>), dim3(wchunks), dim3(BLOCK), 0, st, pos_in, unsort_in, pos_out, unsort_out, sd_l, nodes, ties, n, l,
-		                   lbound, rbound, splitdim, index, flag, (const uint32_t *)hist, warm_drop);
+		                   lbound, rbound, splitdim, index, flag, (const uint32_t *)hist, warm_drop, c->top_sd, c->top_root1);
 		return;
 	}
 	hipLaunchKernelGGL((sel_hist_kernel<0, BLOCK, NP == 2>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l);
@@ -804,7 +813,7 @@ static void select_level_launch(nbco_ctx *c, int l, long long n, const float4 *p
 	if (NP >= 3)
 		hipLaunchKernelGGL((sel_hist_kernel<2, BLOCK, false>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, sd_l, hist, nodes, (const float *)lbound, (const float *)rbound, n, l);
 	hipLaunchKernelGGL((sel_partition_kernel<BLOCK, NP>), dim3(gchunks), dim3(BLOCK), 0, st, pos_in, unsort_in, pos_out, unsort_out, sd_l, nodes, ties, n, l,
-	                   lbound, rbound, splitdim, index, flag, (const uint32_t *)hist, 10);
+	                   lbound, rbound, splitdim, index, flag, (const uint32_t *)hist, 10, c->top_sd, c->top_root1);
 }
 
 int kd_select_level(nbco_ctx *c, int l, long long n, const float4 *pos_in, const int *unsort_in, float4 *pos_out, int *unsort_out,

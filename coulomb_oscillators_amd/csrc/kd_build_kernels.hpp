@@ -375,7 +375,7 @@ extern "C" int nbco_debug_trav_prof(long long *out432)
 
 __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const float4 *__restrict__ pos_in, const int *__restrict__ unsort_in,
                                                            float4 *__restrict__ pos_out, int *__restrict__ unsort_out, long long n, int l0,
-                                                           int canon, int two_pass, int *__restrict__ flag)
+                                                           int canon, int two_pass, int *__restrict__ flag, const int *__restrict__ top_sd, int top_root1)
 {
 	__shared__ __attribute__((aligned(16))) uint64_t keys[kSubS];
 	__shared__ int prio[3];
@@ -418,12 +418,18 @@ __global__ __launch_bounds__(kSubT) void kd_subtree_kernel(TreeView t, const flo
 		// head of every launch.)
 		const int root = kd_beg(l0) + (int)j0;
 		const int up = (root + 1) >> (tid + 1);                       // 1-based heap number of that ancestor, 0: above the root
-		const int mine = (tid < 31 && up > 0) ? t.splitdim[up - 1] : -1;
+		// (the local build of a kd-domain: behind the ancestors inside this tree come the domain root's ancestors in the global tree)
+		int mine = -1;
+		if (tid < 31)
+		{
+			if (up > 0) mine = t.splitdim[up - 1];
+			else if (top_sd) { const int upg = top_root1 >> (tid - l0 + 1); if (upg > 0) mine = top_sd[upg - 1]; }
+		}
 		const int a = t.splitdim[root];
 		const float l0f = t.lbound[3 * root], l1f = t.lbound[3 * root + 1], l2f = t.lbound[3 * root + 2];
 		const float r0f = t.rbound[3 * root], r1f = t.rbound[3 * root + 1], r2f = t.rbound[3 * root + 2];
 		int b0 = -1, b1 = -1, b2 = -1;
-		for (int k = 0; k < l0 && k < 31; ++k)
+		for (int k = 0; k < 31; ++k)
 		{
 			const int ax = __shfl(mine, k);
 			if (ax < 0 || ax == b0 || ax == b1 || b2 >= 0) continue;

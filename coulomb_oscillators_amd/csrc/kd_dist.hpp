@@ -243,6 +243,15 @@ int kd_dist_local(nbco_ctx *c, float *buf_local, long long n_local, void *nodes_
 			}
 			c->dist.let_selected = c->dist.let_packed = c->dist.traversed = c->dist.local_done = false;
 		}
+		// the stable-sort chain's tie-breaking keys reach back to the GLOBAL root: the build takes the split axes above the domain
+		// root from the top tree (found at N = 2^24, where pivots with equal split coordinates are common: without them 531 leaves of
+		// one domain held other particles than the single-GPU tree's, `tests/test_gpu_dist.py::test_config_four_...`)
+		struct TopAxes
+		{
+			nbco_ctx *c;
+			TopAxes(nbco_ctx *c_, const int *sd, int root1) : c(c_) { c->top_sd = sd; c->top_root1 = root1; }
+			~TopAxes() { c->top_sd = nullptr; c->top_root1 = 1; }
+		} top_axes(c, d > 0 ? top.splitdim : nullptr, (1 << d) + lay.rank);
 		NBCO_TRY(kd_build_upward(c, buf_local, n_local, lay.L_local, root6, rebuild, 1));
 		while (rebuild && !c->force_sort_build && let_stage != 1)
 		{

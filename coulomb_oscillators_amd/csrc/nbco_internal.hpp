@@ -146,6 +146,10 @@ struct nbco_ctx
 	hipEvent_t ev_flags = nullptr;
 	long long hint_np2p = 0, hint_nm2l = 0;   // list sizes of the previous evaluation (launch-size hints only)
 	int flags_begin();
+	// local build of a kd-domain: the split axes of the domain root's ancestors in the GLOBAL tree (the top tree of the partition
+	// step, device array) and the root's 1-based heap number there; nullptr / 1: the tree's root is the global root
+	const int *top_sd = nullptr;
+	int top_root1 = 1;
 	int flags_seq = 0;   // sequence number of the traversal whose results h_flags[0..3] hold (h_flags[4], written last)
 	int wait_flags();    // until the traversal enqueued last has reported: spins on the pinned word, no interrupt-driven wake-up
 	DevBuf scan_tmp_aux;

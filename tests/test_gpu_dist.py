@@ -776,6 +776,42 @@ def test_distributed_repartition_at_8m_particles(oracle32):
     assert sum(r.partition_bytes for r in b.runs) < sum(r.partition_bytes for r in a.runs)
 
 
+def test_config_four_at_its_own_size_in_lockstep(oracle32):
+    """BASELINE config 4 ("FMM-3D kd-tree p=6, N=16M, domain-decomposed 8 x MI355X") at its own size on the one card: N = 2^24
+    particles of the reference's ball, eight kd-domains of 2^21 driven in lockstep -- distributed re-partition (three histogram
+    passes at this size), local builds with trees of 2^18 leaves, LET exchange in the exact and then in the capped form.  Tree
+    order, velocities and accelerations equal the single-GPU evaluation of the same 16M system bit for bit, and every domain
+    receives a small fraction of what the all-gather would move."""
+    import torch
+    n, G, p = 1 << 24, 8, 6
+    pos, vel = make_state(oracle32, n, "reference")
+    par = torch.from_numpy(oracle32.params(n)).cuda()
+    opts = dict(fmm_order=p, unsort=0, tree_steps=1)
+    e1, ref = single_gpu(n, pos, vel, par, **opts)
+    info = e1.kd_info()
+    assert info.L == 19 and info.n == n
+    ref = ref.clone()
+    e1.close()
+    assert bool(torch.isfinite(ref).all())
+    world = loopback(n, G, pos, vel, **opts)
+    assert all(r.dpart and r.partition_fallbacks == 0 for r in world.runs)
+    for capped in (False, True):
+        world.force(par, elastic=False, let=True, capped=capped)
+        for r in world.runs:
+            r.eng.dist_let_check()
+        torch.cuda.synchronize()
+        got = torch.cat([r.buf.view(3, -1, 3) for r in world.runs], dim=1).reshape(-1)
+        assert torch.equal(got[:6 * n], ref[:6 * n]), "tree order of positions / velocities differs (capped=%s)" % capped
+        assert torch.equal(got[6 * n:], ref[6 * n:]), "accelerations differ from the single-GPU evaluation (capped=%s)" % capped
+    assert world.let_capped_evals == 1 and world.let_redos == 0
+    ratio = sum(r.allgather_bytes() for r in world.runs) / sum(r.exchange_bytes() for r in world.runs)
+    print("config 4 in lockstep: LET exchange moves %.1fx fewer bytes than the all-gather (%.1f MB per domain and evaluation)"
+          % (ratio, np.mean([r.exchange_bytes() for r in world.runs]) / 1e6))
+    assert ratio > 10
+    for r in world.runs:
+        r.eng.close()
+
+
 @pytest.mark.parametrize("let", [False, True])
 def test_sharded_far_fp64_equals_single_gpu(oracle32, let):
     """opts.far_fp64 in the sharded evaluation (G = 4): the exchanged multipole blocks / LET node records are doubles, and the
