@@ -41,6 +41,29 @@ __device__ __forceinline__ void wave_lds_sync()
 		tz = fmaf(dz, ri3, tz);                                            \
 	}
 
+// Two sources per lane and step in PACKED fp32 instructions (v_pk_add / v_pk_fma / v_pk_mul_f32: two fp32 operations per lane
+// and issue slot).  A wave of plain v_fma_f32 reaches 0.64-0.68 of the nominal fp32 peak on this part and pulls the clock down
+// to 1.9 GHz; v_pk_fma_f32 reaches 0.955 at 2.39 GHz (`tools/valu_probe.py` pk_*, `profiles/r03z_valu_probe_pk.txt`) -- the
+// nominal peak IS the packed rate.  The tile keeps x, y and z of its sources in three rows, so one ds_read_b128 per coordinate
+// delivers four sources as two aligned register pairs; 11 packed instructions and two v_rsq_f32 per two pairs instead of 22 + 2.
+// Per pair the arithmetic is what P2P_PAIR does, bit for bit; a tile's even and odd sources are summed apart and then added.
+typedef float p2p_v2f __attribute__((ext_vector_type(2)));
+#define P2P_PAIR2(XS, YS, ZS)                                                                                          \
+	{                                                                                                                  \
+		const p2p_v2f dx = pix - (XS), dy = piy - (YS), dz = piz - (ZS);                                               \
+		const p2p_v2f r2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dz, dz, eps2v))); \
+		p2p_v2f ri;                                                                                                    \
+		ri.x = __builtin_amdgcn_rsqf(r2.x);                                                                            \
+		ri.y = __builtin_amdgcn_rsqf(r2.y);                                                                            \
+		const p2p_v2f ri3 = ri * ri * ri;                                                                              \
+		tx2 = __builtin_elementwise_fma(dx, ri3, tx2);                                                                 \
+		ty2 = __builtin_elementwise_fma(dy, ri3, ty2);                                                                 \
+		tz2 = __builtin_elementwise_fma(dz, ri3, tz2);                                                                 \
+	}
+#ifndef NBCO_P2P_PACKED
+#define NBCO_P2P_PACKED 1
+#endif
+
 #ifndef NBCO_P2P_WAVES
 #define NBCO_P2P_WAVES 4
 #endif
@@ -110,7 +133,11 @@ __global__ __launch_bounds__(64 * kP2PWaves) NBCO_P2P_ATTR void p2p_kernel(const
 				for (int et = 0; et < ntile; ++et)
 					for (int jc = 0; jc < nchunk; ++jc)
 					{
+#if NBCO_P2P_PACKED
+						tile[b][g][li] = cur.x; tile[b][g][TPL + li] = cur.y; tile[b][g][2 * TPL + li] = cur.z;   // rows x | y | z
+#else
 						tile[b][g][3 * li] = cur.x; tile[b][g][3 * li + 1] = cur.y; tile[b][g][3 * li + 2] = cur.z;
+#endif
 						int jn = jc + 1, en = et;
 						if (jn == nchunk) { jn = 0; ++en; }
 						if (en < ntile) cur = fetch(en, jn);
@@ -126,6 +153,18 @@ __global__ __launch_bounds__(64 * kP2PWaves) NBCO_P2P_ATTR void p2p_kernel(const
 						// a tile's contributions are summed on their own and then added to the running total: the rounding error
 						// of a long fp32 sum grows with its length, and a lane sees thousands of sources per chunk when the leaves
 						// are large (the reference's CPU path also accumulates per leaf pair first)
+#if NBCO_P2P_PACKED
+						p2p_v2f tx2 = {0.f, 0.f}, ty2 = {0.f, 0.f}, tz2 = {0.f, 0.f};
+						const p2p_v2f pix = {pi.x, pi.x}, piy = {pi.y, pi.y}, piz = {pi.z, pi.z}, eps2v = {eps2, eps2};
+#pragma unroll 2
+						for (int q4 = 0; q4 < TPL / 4; ++q4)
+						{
+							const float4 X = t4[q4], Y = t4[TPL / 4 + q4], Z = t4[TPL / 2 + q4];
+							P2P_PAIR2((p2p_v2f{X.x, X.y}), (p2p_v2f{Y.x, Y.y}), (p2p_v2f{Z.x, Z.y}))
+							P2P_PAIR2((p2p_v2f{X.z, X.w}), (p2p_v2f{Y.z, Y.w}), (p2p_v2f{Z.z, Z.w}))
+						}
+						ax += tx2.x + tx2.y; ay += ty2.x + ty2.y; az += tz2.x + tz2.y;
+#else
 						float tx = 0.f, ty = 0.f, tz = 0.f;
 #pragma unroll 2
 						for (int q4 = 0; q4 < TPL / 4; ++q4)
@@ -137,6 +176,7 @@ __global__ __launch_bounds__(64 * kP2PWaves) NBCO_P2P_ATTR void p2p_kernel(const
 							P2P_PAIR(C.y, C.z, C.w)
 						}
 						ax += tx; ay += ty; az += tz;
+#endif
 						wave_lds_sync();
 						b ^= 1;
 					}

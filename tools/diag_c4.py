@@ -1,5 +1,5 @@
 """diagnostics: where a lockstep run of G kd-domains differs from the single-GPU evaluation of the same system
-    python tools/diag_c4.py <log2 n> <G> [kind]"""
+    python tools/diag_c4.py <log2 n> <G> [kind] [engine option=value ...]"""
 import sys
 
 import numpy as np
@@ -14,10 +14,12 @@ from test_gpu_dist import loopback, make_state, single_gpu
 def main():
     n, G = 1 << int(sys.argv[1]), int(sys.argv[2])
     kind = sys.argv[3] if len(sys.argv) > 3 else "reference"
+    extra = dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in sys.argv[4:])
     o = Oracle(np.float32)
     pos, vel = make_state(o, n, kind)
     par = torch.from_numpy(o.params(n)).cuda()
     opts = dict(fmm_order=6, unsort=0, tree_steps=1)
+    opts.update(extra)
     e1, ref = single_gpu(n, pos, vel, par, **opts)
     info = e1.kd_info()
     print("single: L", info.L, "build_mode", info.build_mode, "pairs", info.p2p_pairs, info.m2l_pairs)

@@ -50,6 +50,17 @@ add("mov", [f"v_mov_b32 v{16 + k}, v1" for k in range(48)])
 add("sub_dpp", [f"v_sub_f32_dpp v{16 + k}, v1, v2 row_ror:{1 + k % 15} row_mask:0xf bank_mask:0xf" for k in range(48)], flop=48)
 add("mov_dpp", [f"v_mov_b32_dpp v{16 + k}, v1 row_ror:{1 + k % 15} row_mask:0xf bank_mask:0xf" for k in range(48)])
 add("fmac_dpp", [f"v_fmac_f32_dpp v{16 + 4 * (k % 24)}, v1, v2 row_ror:{1 + k % 15} row_mask:0xf bank_mask:0xf" for k in range(48)], flop=96)
+# packed fp32 (two fp32 operations per lane and instruction, operands in aligned register pairs): does a wave issue it as fast as
+# the plain form -- twice the arithmetic per issue slot -- or at half the rate?
+add("pk_fma", [f"v_pk_fma_f32 v[{16 + 2 * (k % 24)}:{17 + 2 * (k % 24)}], v[{16 + 2 * (k % 24)}:{17 + 2 * (k % 24)}], v[2:3], v[4:5]" for k in range(48)], flop=192)
+add("pk_mul", [f"v_pk_mul_f32 v[{16 + 2 * (k % 24)}:{17 + 2 * (k % 24)}], v[2:3], v[4:5]" for k in range(48)], flop=96)
+add("pk_add", [f"v_pk_add_f32 v[{16 + 2 * (k % 24)}:{17 + 2 * (k % 24)}], v[2:3], v[4:5]" for k in range(48)], flop=96)
+# .. and next to the transcendental unit: 12 packed fma (= 24 fma) per rsq pair
+_pkmix = []
+for g in range(4):
+    _pkmix += [f"v_pk_fma_f32 v[{16 + 2 * ((6 * g + k) % 24)}:{17 + 2 * ((6 * g + k) % 24)}], v[{16 + 2 * ((6 * g + k) % 24)}:{17 + 2 * ((6 * g + k) % 24)}], v[2:3], v[4:5]" for k in range(6)]
+    _pkmix += [f"v_rsq_f32 v{120 + 2 * g}, v6", f"v_rsq_f32 v{121 + 2 * g}, v7"]
+add("pk_fma6_rsq2", _pkmix, flop=96)
 # transcendental
 add("rsq", [f"v_rsq_f32 v{16 + k}, v{1 + k % 3}" for k in range(48)])
 # 12 fma : 1 rsq
