@@ -8,7 +8,7 @@
 // ds_read_b128 broadcasts (three reads per four sources), each source feeding IB pair evaluations.  The j range is split over gridDim.y so that every CU holds
 // several workgroups (>= 2 waves per SIMD are needed to saturate VALU issue on CDNA4); partial
 // sums are combined in a fixed order by a second tiny kernel, so results are bit-reproducible.
-// Per pair and lane: 3 sub, 3 fma (r^2), v_rsq_f32, 2 mul, 3 fma = 13 VALU issues.
+// Per TWO pairs and lane: 3 v_pk_add, 3 v_pk_fma (r^2), 2 v_rsq_f32, 2 v_pk_mul, 3 v_pk_fma = 13 VALU issues.
 #include "nbco_internal.hpp"
 
 namespace {
@@ -24,17 +24,34 @@ constexpr int kTile = 256;            // sources per LDS tile
 		float r2 = fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, eps2)));         \
 		float ri = __builtin_amdgcn_rsqf(r2);                              \
 		float ri3 = ri * ri * ri;                                          \
-		ax[k] = fmaf(dx, ri3, ax[k]);                                      \
-		ay[k] = fmaf(dy, ri3, ay[k]);                                      \
-		az[k] = fmaf(dz, ri3, az[k]);                                      \
+		ax2[k].x = fmaf(dx, ri3, ax2[k].x);                                \
+		ay2[k].x = fmaf(dy, ri3, ay2[k].x);                                \
+		az2[k].x = fmaf(dz, ri3, az2[k].x);                                \
+	}
+// Two SOURCES per packed fp32 instruction (v_pk_add / v_pk_fma / v_pk_mul_f32: the nominal fp32 peak of this part is the packed
+// rate -- tools/valu_probe.py pk_*).  The tile keeps x, y and z in three rows, so one ds_read_b128 per coordinate
+// delivers four sources as two aligned register pairs; a target's coordinates sit in both halves of a pair (set up once per
+// lane).  Per pair the arithmetic is the scalar form's; a target's even and odd sources are summed apart between two folds.
+typedef float dir_v2f __attribute__((ext_vector_type(2)));
+#define NBCO_PAIR2(XS, YS, ZS)                                                                                         \
+	_Pragma("unroll") for (int k = 0; k < IB; ++k)                                                                     \
+	{                                                                                                                  \
+		const dir_v2f dx = xi2[k] - (XS), dy = yi2[k] - (YS), dz = zi2[k] - (ZS);                                      \
+		const dir_v2f r2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dz, dz, eps2v))); \
+		dir_v2f ri;                                                                                                    \
+		ri.x = __builtin_amdgcn_rsqf(r2.x);                                                                            \
+		ri.y = __builtin_amdgcn_rsqf(r2.y);                                                                            \
+		const dir_v2f ri3 = ri * ri * ri;                                                                              \
+		ax2[k] = __builtin_elementwise_fma(dx, ri3, ax2[k]);                                                           \
+		ay2[k] = __builtin_elementwise_fma(dy, ri3, ay2[k]);                                                           \
+		az2[k] = __builtin_elementwise_fma(dz, ri3, az2[k]);                                                           \
 	}
 
 template <bool KAHAN>
 __global__ __launch_bounds__(kBlock) void direct_tiles(const float4 *__restrict__ pos, float4 *__restrict__ part, long long n,
                                                        float eps2, int tiles_per_split)
 {
-	// source tile as packed xyz triplets: four sources are fetched with three ds_read_b128
-	// (12 LDS cycles per 4 sources; a float4-per-source tile would be narrowed to ds_read_b96 = 8 each)
+	// source tile as three rows x | y | z: four sources are fetched with three ds_read_b128, each delivering two aligned pairs
 	__shared__ __attribute__((aligned(16))) float tile[2][3 * kTile];
 	const int tid = threadIdx.x;
 	const long long i0 = (long long)blockIdx.x * (kBlock * IB) + tid;
@@ -50,6 +67,10 @@ __global__ __launch_bounds__(kBlock) void direct_tiles(const float4 *__restrict_
 		sx[k] = sy[k] = sz[k] = 0.f;
 		cx[k] = cy[k] = cz[k] = 0.f;
 	}
+	dir_v2f xi2[IB], yi2[IB], zi2[IB];
+#pragma unroll
+	for (int k = 0; k < IB; ++k) { xi2[k] = dir_v2f{xi[k], xi[k]}; yi2[k] = dir_v2f{yi[k], yi[k]}; zi2[k] = dir_v2f{zi[k], zi[k]}; }
+	const dir_v2f eps2v = {eps2, eps2};
 
 	const long long ntiles = (n + kTile - 1) / kTile;
 	const long long t_beg = (long long)blockIdx.y * tiles_per_split;
@@ -60,7 +81,7 @@ __global__ __launch_bounds__(kBlock) void direct_tiles(const float4 *__restrict_
 	{
 		long long j = t_beg * kTile + tid;
 		float4 q = pos[j < n ? j : n - 1];
-		tile[0][3 * tid] = q.x; tile[0][3 * tid + 1] = q.y; tile[0][3 * tid + 2] = q.z;
+		tile[0][tid] = q.x; tile[0][kTile + tid] = q.y; tile[0][2 * kTile + tid] = q.z;
 	}
 	__syncthreads();
 
@@ -78,9 +99,9 @@ __global__ __launch_bounds__(kBlock) void direct_tiles(const float4 *__restrict_
 		long long rem = n - t * kTile;
 		const int jcount = rem < kTile ? (int)rem : kTile;
 
-		float ax[IB], ay[IB], az[IB];
+		dir_v2f ax2[IB], ay2[IB], az2[IB];   // .x: even sources (and the tail's single ones), .y: odd sources
 #pragma unroll
-		for (int k = 0; k < IB; ++k) ax[k] = ay[k] = az[k] = 0.f;
+		for (int k = 0; k < IB; ++k) ax2[k] = ay2[k] = az2[k] = dir_v2f{0.f, 0.f};
 
 		const float4 *t4 = reinterpret_cast<const float4 *>(tile[cur]);
 		const int quads = jcount >> 2;
@@ -92,24 +113,22 @@ __global__ __launch_bounds__(kBlock) void direct_tiles(const float4 *__restrict_
 			for (int k = 0; k < IB; ++k)
 			{
 				float y, s;
-				y = ax[k] - cx[k]; s = sx[k] + y; cx[k] = (s - sx[k]) - y; sx[k] = s; ax[k] = 0.f;
-				y = ay[k] - cy[k]; s = sy[k] + y; cy[k] = (s - sy[k]) - y; sy[k] = s; ay[k] = 0.f;
-				y = az[k] - cz[k]; s = sz[k] + y; cz[k] = (s - sz[k]) - y; sz[k] = s; az[k] = 0.f;
+				y = (ax2[k].x + ax2[k].y) - cx[k]; s = sx[k] + y; cx[k] = (s - sx[k]) - y; sx[k] = s; ax2[k] = dir_v2f{0.f, 0.f};
+				y = (ay2[k].x + ay2[k].y) - cy[k]; s = sy[k] + y; cy[k] = (s - sy[k]) - y; sy[k] = s; ay2[k] = dir_v2f{0.f, 0.f};
+				y = (az2[k].x + az2[k].y) - cz[k]; s = sz[k] + y; cz[k] = (s - sz[k]) - y; sz[k] = s; az2[k] = dir_v2f{0.f, 0.f};
 			}
 		};
 #pragma unroll 2
 		for (int q = 0; q < quads; ++q)
 		{
-			const float4 A = t4[3 * q], B = t4[3 * q + 1], C = t4[3 * q + 2];
-			NBCO_PAIR(A.x, A.y, A.z)
-			NBCO_PAIR(A.w, B.x, B.y)
-			NBCO_PAIR(B.z, B.w, C.x)
-			NBCO_PAIR(C.y, C.z, C.w)
+			const float4 X = t4[q], Y = t4[kTile / 4 + q], Z = t4[kTile / 2 + q];
+			NBCO_PAIR2((dir_v2f{X.x, X.y}), (dir_v2f{Y.x, Y.y}), (dir_v2f{Z.x, Z.y}))
+			NBCO_PAIR2((dir_v2f{X.z, X.w}), (dir_v2f{Y.z, Y.w}), (dir_v2f{Z.z, Z.w}))
 			if (KAHAN && (q & 3) == 3) fold();
 		}
 		for (int j = quads << 2; j < jcount; ++j)
 		{
-			const float px = tile[cur][3 * j], py = tile[cur][3 * j + 1], pz = tile[cur][3 * j + 2];
+			const float px = tile[cur][j], py = tile[cur][kTile + j], pz = tile[cur][2 * kTile + j];
 			NBCO_PAIR(px, py, pz)
 		}
 		// fold the tile sums into the running sums (two-level summation; compensated for direct3)
@@ -119,13 +138,13 @@ __global__ __launch_bounds__(kBlock) void direct_tiles(const float4 *__restrict_
 			if (KAHAN)
 			{
 				float y, s;
-				y = ax[k] - cx[k]; s = sx[k] + y; cx[k] = (s - sx[k]) - y; sx[k] = s;
-				y = ay[k] - cy[k]; s = sy[k] + y; cy[k] = (s - sy[k]) - y; sy[k] = s;
-				y = az[k] - cz[k]; s = sz[k] + y; cz[k] = (s - sz[k]) - y; sz[k] = s;
+				y = (ax2[k].x + ax2[k].y) - cx[k]; s = sx[k] + y; cx[k] = (s - sx[k]) - y; sx[k] = s;
+				y = (ay2[k].x + ay2[k].y) - cy[k]; s = sy[k] + y; cy[k] = (s - sy[k]) - y; sy[k] = s;
+				y = (az2[k].x + az2[k].y) - cz[k]; s = sz[k] + y; cz[k] = (s - sz[k]) - y; sz[k] = s;
 			}
-			else { sx[k] += ax[k]; sy[k] += ay[k]; sz[k] += az[k]; }
+			else { sx[k] += ax2[k].x + ax2[k].y; sy[k] += ay2[k].x + ay2[k].y; sz[k] += az2[k].x + az2[k].y; }
 		}
-		if (has_next) { tile[cur ^ 1][3 * tid] = nxt.x; tile[cur ^ 1][3 * tid + 1] = nxt.y; tile[cur ^ 1][3 * tid + 2] = nxt.z; }
+		if (has_next) { tile[cur ^ 1][tid] = nxt.x; tile[cur ^ 1][kTile + tid] = nxt.y; tile[cur ^ 1][2 * kTile + tid] = nxt.z; }
 		__syncthreads();
 	}
 

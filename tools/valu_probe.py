@@ -61,6 +61,31 @@ for g in range(4):
     _pkmix += [f"v_pk_fma_f32 v[{16 + 2 * ((6 * g + k) % 24)}:{17 + 2 * ((6 * g + k) % 24)}], v[{16 + 2 * ((6 * g + k) % 24)}:{17 + 2 * ((6 * g + k) % 24)}], v[2:3], v[4:5]" for k in range(6)]
     _pkmix += [f"v_rsq_f32 v{120 + 2 * g}, v6", f"v_rsq_f32 v{121 + 2 * g}, v7"]
 add("pk_fma6_rsq2", _pkmix, flop=96)
+# the packed pair body of p2p_kernel on register operands: per step two pairs = 3 pk_add, 3 pk_fma (r^2), 2 v_rsq, 2 pk_mul, 3 pk_fma;
+# `sets` independent steps interleaved instruction by instruction
+def pk_pair_steps(sets):
+    # registers per set: d (6: 3 pairs), r (2), c (2); accumulators shared v[8:13]; target pairs v[2:3] v[4:5] v[6:7]; sources v[14:19]; eps s/v[20:21]
+    out = []
+    base = [24 + 10 * k for k in range(sets)]
+    def ins(f):
+        for b in base:
+            out.append(f(b))
+    ins(lambda b: f"v_pk_add_f32 v[{b}:{b+1}], v[2:3], v[14:15] neg_lo:[0,1] neg_hi:[0,1]")
+    ins(lambda b: f"v_pk_add_f32 v[{b+2}:{b+3}], v[4:5], v[16:17] neg_lo:[0,1] neg_hi:[0,1]")
+    ins(lambda b: f"v_pk_add_f32 v[{b+4}:{b+5}], v[6:7], v[18:19] neg_lo:[0,1] neg_hi:[0,1]")
+    ins(lambda b: f"v_pk_fma_f32 v[{b+6}:{b+7}], v[{b+4}:{b+5}], v[{b+4}:{b+5}], v[20:21]")
+    ins(lambda b: f"v_pk_fma_f32 v[{b+6}:{b+7}], v[{b+2}:{b+3}], v[{b+2}:{b+3}], v[{b+6}:{b+7}]")
+    ins(lambda b: f"v_pk_fma_f32 v[{b+6}:{b+7}], v[{b}:{b+1}], v[{b}:{b+1}], v[{b+6}:{b+7}]")
+    ins(lambda b: f"v_rsq_f32 v{b+6}, v{b+6}")
+    ins(lambda b: f"v_rsq_f32 v{b+7}, v{b+7}")
+    ins(lambda b: f"v_pk_mul_f32 v[{b+8}:{b+9}], v[{b+6}:{b+7}], v[{b+6}:{b+7}]")
+    ins(lambda b: f"v_pk_mul_f32 v[{b+8}:{b+9}], v[{b+8}:{b+9}], v[{b+6}:{b+7}]")
+    ins(lambda b: f"v_pk_fma_f32 v[8:9], v[{b}:{b+1}], v[{b+8}:{b+9}], v[8:9]")
+    ins(lambda b: f"v_pk_fma_f32 v[10:11], v[{b+2}:{b+3}], v[{b+8}:{b+9}], v[10:11]")
+    ins(lambda b: f"v_pk_fma_f32 v[12:13], v[{b+4}:{b+5}], v[{b+8}:{b+9}], v[12:13]")
+    return out
+for _sets in (1, 2, 4):
+    add(f"pk_pair_x{_sets}", pk_pair_steps(_sets), flop=40 * _sets, pairs=2 * _sets)
 # transcendental
 add("rsq", [f"v_rsq_f32 v{16 + k}, v{1 + k % 3}" for k in range(48)])
 # 12 fma : 1 rsq
