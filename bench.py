@@ -162,7 +162,9 @@ def measured_ceiling():
     with open(files[-1]) as f:
         res = json.load(f)["results"]
     out = {}
-    for key, variants in (("pair", ("pair", "pair4")), ("mutual", ("mutual_dpp",))):
+    # (the packed body is what p2p_kernel runs since round 3; summaries from before hold the scalar body only)
+    packed = any(r["variant"] in ("pair_pk", "pair4_pk") for r in res)
+    for key, variants in (("pair", ("pair_pk", "pair4_pk") if packed else ("pair", "pair4")), ("mutual", ("mutual_dpp",))):
         for mode in ("sustained", "burst"):
             v = [r["frac_of_157.3"] for r in res if r["variant"] in variants and r.get("mode", "sustained") == mode]
             out["%s_%s" % (key, mode)] = max(v) if v else None

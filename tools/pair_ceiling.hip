@@ -14,6 +14,7 @@
 //   fma+rsq  12 v_fma : 1 v_rsq, independent (does the transcendental unit overlap the FMA pipe?)
 //   pair     the 13-instruction body, 8 sources per iteration, one target per lane (production shape)
 //   pair4    the same with 4 targets per lane (direct_tiles shape: more independent chains per wave)
+//   pair_pk, pair4_pk   the packed form of that body (two sources per v_pk_* instruction): what the kernels run since round 3
 //   mutual   Newton-III form: r^-3 once per unordered pair, +d*w to the lane's target and -d*w to the source's
 //            accumulator held in registers (16 instructions per 2 directed pairs; the cross-lane traffic a real
 //            mutual kernel needs is NOT included: this is its upper bound)
@@ -139,6 +140,57 @@ __global__ __launch_bounds__(256) void k_pair(const float *in, float *out, Stamp
 	float s = 0;
 #pragma unroll
 	for (int t = 0; t < TGT; ++t) s += ax[t] + ay[t] + az[t];
+	out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+	if ((threadIdx.x & 63) == 0) st[blockIdx.x * 4 + (threadIdx.x >> 6)].cyc = t1 - t0;
+}
+
+// The packed form of the pair body (two sources per v_pk_* instruction; what p2p_kernel and direct_tiles run since round 3)
+typedef float v2f __attribute__((ext_vector_type(2)));
+#define PAIR2(PX, PY, PZ, SX, SY, SZ, AX, AY, AZ)                                                                       \
+	{                                                                                                                  \
+		const v2f dx = (PX) - (SX), dy = (PY) - (SY), dz = (PZ) - (SZ);                                                \
+		const v2f r2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dz, dz, e2))); \
+		v2f ri;                                                                                                        \
+		ri.x = __builtin_amdgcn_rsqf(r2.x);                                                                            \
+		ri.y = __builtin_amdgcn_rsqf(r2.y);                                                                            \
+		const v2f ri3 = ri * ri * ri;                                                                                  \
+		AX = __builtin_elementwise_fma(dx, ri3, AX); AY = __builtin_elementwise_fma(dy, ri3, AY); AZ = __builtin_elementwise_fma(dz, ri3, AZ); \
+	}
+template <int TGT>
+__global__ __launch_bounds__(256) void k_pair_pk(const float *in, float *out, Stamp *st, int iters, float eps2)
+{
+	static_assert(kSrc % 2 == 0, "sources in pairs");
+	v2f sx[kSrc / 2], sy[kSrc / 2], sz[kSrc / 2];
+	v2f px[TGT], py[TGT], pz[TGT], ax[TGT], ay[TGT], az[TGT];
+	const v2f e2 = {eps2, eps2};
+	const int lane = threadIdx.x & 63;
+#pragma unroll
+	for (int k = 0; k < kSrc / 2; ++k)
+	{
+		sx[k] = v2f{in[128 + 6 * k], in[131 + 6 * k]}; sy[k] = v2f{in[129 + 6 * k], in[132 + 6 * k]}; sz[k] = v2f{in[130 + 6 * k], in[133 + 6 * k]};
+	}
+#pragma unroll
+	for (int t = 0; t < TGT; ++t)
+	{
+		const float a = in[lane] + t, b = in[64 + lane] - t, c = in[lane] * 0.5f + t;
+		px[t] = v2f{a, a}; py[t] = v2f{b, b}; pz[t] = v2f{c, c};
+		ax[t] = ay[t] = az[t] = v2f{0.f, 0.f};
+	}
+	const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+	for (int it = 0; it < iters; ++it)
+	{
+#pragma unroll
+		for (int k = 0; k < kSrc / 2; ++k)
+		{
+			OPAQUE(sx[k].x); OPAQUE(sx[k].y); OPAQUE(sy[k].x); OPAQUE(sy[k].y); OPAQUE(sz[k].x); OPAQUE(sz[k].y);
+#pragma unroll
+			for (int t = 0; t < TGT; ++t) PAIR2(px[t], py[t], pz[t], sx[k], sy[k], sz[k], ax[t], ay[t], az[t])
+		}
+	}
+	const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+	float s = 0;
+#pragma unroll
+	for (int t = 0; t < TGT; ++t) s += ax[t].x + ax[t].y + ay[t].x + ay[t].y + az[t].x + az[t].y;
 	out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 	if ((threadIdx.x & 63) == 0) st[blockIdx.x * 4 + (threadIdx.x >> 6)].cyc = t1 - t0;
 }
@@ -303,6 +355,8 @@ int main(int argc, char **argv)
 		run("fma+rsq", w, 4, "(12 fma + 1 rsq)", 20000, [&](int g, int it) { hipLaunchKernelGGL(k_mix, dim3(g), dim3(256), 0, 0, in, out, st, it); });
 		run("pair", w, kSrc, "pairs", 20000, [&](int g, int it) { hipLaunchKernelGGL(k_pair<1>, dim3(g), dim3(256), 0, 0, in, out, st, it, eps2); });
 		run("pair4", w, 4 * kSrc, "pairs", 5000, [&](int g, int it) { hipLaunchKernelGGL(k_pair<4>, dim3(g), dim3(256), 0, 0, in, out, st, it, eps2); });
+		run("pair_pk", w, kSrc, "pairs", 20000, [&](int g, int it) { hipLaunchKernelGGL(k_pair_pk<1>, dim3(g), dim3(256), 0, 0, in, out, st, it, eps2); });
+		run("pair4_pk", w, 4 * kSrc, "pairs", 5000, [&](int g, int it) { hipLaunchKernelGGL(k_pair_pk<4>, dim3(g), dim3(256), 0, 0, in, out, st, it, eps2); });
 		run("mutual", w, 2 * kSrc, "pairs", 20000, [&](int g, int it) { hipLaunchKernelGGL(k_mutual, dim3(g), dim3(256), 0, 0, in, out, st, it, eps2); });
 		run("mutual_dpp", w, 2 * 16, "pairs", 10000, [&](int g, int it) { hipLaunchKernelGGL(k_mutual_dpp, dim3(g), dim3(256), 0, 0, in, out, st, it, eps2); });
 	}
