@@ -454,6 +454,10 @@ def main():
         def start():
             """state := the initial state; accelerations (main3.cu:836-839)"""
             d.copy_(d0)
+            if args.tree_steps > 1:
+                # the context still holds the tree of the END of the repeat before: a new state starts a new rebuild schedule
+                eng.set(tree_steps=1)
+                eng.set(tree_steps=args.tree_steps)
             if sharded:
                 # The re-partition without gathering the state and the LET exchange are the two stages no single-card rehearsal can
                 # run over RCCL between several cards: should one fail on every rank alike, the run agrees on that, carries on with

@@ -217,7 +217,8 @@ int nbco_set_opts(nbco_ctx *c, const nbco_opts *o)
 	if ((hipStream_t)o->stream != c->stream) NBCO_HIP(hipStreamSynchronize(c->stream));
 	if (o->list_factor != c->o.list_factor) c->list_growth = 1;
 	bool topo = o->fmm_order != c->o.fmm_order || o->dens_inhom != c->o.dens_inhom || o->tree_L != c->o.tree_L
-	            || o->unsort != c->o.unsort || o->p2p_mutual != c->o.p2p_mutual || o->track_order != c->o.track_order;
+	            || o->unsort != c->o.unsort || o->p2p_mutual != c->o.p2p_mutual || o->track_order != c->o.track_order
+	            || o->tree_steps != c->o.tree_steps;   // (a new rebuild schedule starts with a rebuild)
 	c->o = *o;
 	c->stream = (hipStream_t)o->stream;
 	if (topo) { c->tree_valid = false; c->eval_counter = 0; }

@@ -66,7 +66,10 @@ typedef struct nbco_opts {
 	int   tree_L;       /* constants.cuh:44 tree_L (0 = derive from n and order) */
 	int   tree_steps;   /* constants.cuh:45 tree_steps: rebuild the kd-tree every this many
 	                       evaluations when unsort == 0.  1 = every evaluation, which is what the
-	                       reference's CPU driver does (fmm_cart3_kdtree.cuh:1773-1929). */
+	                       reference's CPU driver does (fmm_cart3_kdtree.cuh:1773-1929).  Setting a different
+	                       value (nbco_set_opts) starts a new schedule: the next evaluation rebuilds -- which
+	                       is also how a caller that puts a NEW state into an old context gets rid of the
+	                       tree of the state before. */
 	int   m2l_first;    /* 0: leaf-leaf pairs go to P2P before the admissibility test (reference CPU
 	                       traversal, fmm_cart3_kdtree.cuh:586-598); 1: admissibility first
 	                       (reference GPU traversal <true>, :520-534) */
