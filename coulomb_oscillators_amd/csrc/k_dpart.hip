@@ -8,12 +8,14 @@
 // = rank * n_local + i, the index nbco_dist_partition's gathered order gives them), the children's boxes follow evalBox's
 // rule, and the local array is partitioned in place.  After log2(G) levels the particles are grouped by destination rank and
 // one all-to-all moves [pos | vel] of exactly the particles that change owner (plus the local copy of those that stay).
-// The result -- top boxes, split axes and the particle SET of every domain -- equals nbco_dist_partition's.
+// The result -- top boxes, split axes, the particles of every domain AND THEIR ORDER (source rank, then index in the source's
+// state: the order of the gathered state) -- equals nbco_dist_partition's.
 //
 // The library never communicates: nbco_dist_repartition_begin / _next run the local stages and tell the caller which
 // collective to run on which part of the caller's workspace before the next call (a small state machine, nbco_dist_step).
 #include "nbco_internal.hpp"
 #include "kd_common.hpp"
+#include <rocprim/rocprim.hpp>
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
@@ -336,14 +338,26 @@ __global__ void dp_counts_kernel(const int *__restrict__ seg, int world, int *__
 	if (g < world) counts[g] = seg[g + 1] - seg[g];
 }
 
-// records {x, y, z, vx, vy, vz} in the order of P (grouped by destination rank)
-__global__ __launch_bounds__(kB) void dp_send_kernel(const float4 *__restrict__ P, const float *__restrict__ vel, long long n, float *__restrict__ out)
+// destination rank of every particle by its LOCAL INDEX (P is grouped by destination: seg[g] .. seg[g + 1]), the key of the
+// stable one-pass sort that puts every destination's particles back into the order of the local state
+__global__ __launch_bounds__(kB) void dp_dest_kernel(const float4 *__restrict__ P, const int *__restrict__ seg, int world, long long n, uint32_t *__restrict__ dest)
 {
 	for (long long i = (long long)blockIdx.x * kB + threadIdx.x; i < n; i += (long long)gridDim.x * kB)
 	{
-		const float4 p = P[i];
-		const long long o = __float_as_int(p.w);
-		out[6 * i] = p.x; out[6 * i + 1] = p.y; out[6 * i + 2] = p.z;
+		int g = 0;
+		while (g + 1 < world && seg[g + 1] <= i) ++g;
+		dest[__float_as_int(load_particle(P, i).w)] = (uint32_t)g;
+	}
+}
+// records {x, y, z, vx, vy, vz}: slot i holds the particle order[i] of the local state (grouped by destination rank, by local
+// index inside a group)
+__global__ __launch_bounds__(kB) void dp_send_kernel(const uint32_t *__restrict__ order, const float *__restrict__ pos, const float *__restrict__ vel, long long n,
+                                                     float *__restrict__ out)
+{
+	for (long long i = (long long)blockIdx.x * kB + threadIdx.x; i < n; i += (long long)gridDim.x * kB)
+	{
+		const long long o = order[i];
+		out[6 * i] = pos[3 * o]; out[6 * i + 1] = pos[3 * o + 1]; out[6 * i + 2] = pos[3 * o + 2];
 		out[6 * i + 3] = vel[3 * o]; out[6 * i + 4] = vel[3 * o + 1]; out[6 * i + 5] = vel[3 * o + 2];
 	}
 }
@@ -506,7 +520,26 @@ static int dpart_advance(nbco_ctx *c, nbco_dist_step *out)
 		long long in = 0;
 		for (int g = 0; g < G; ++g) { s.rows_send[g] = M[(size_t)s.rank * G + g]; s.rows_recv[g] = M[(size_t)g * G + s.rank]; in += s.rows_recv[g]; }
 		if (in != nl) { s.stage = ST_IDLE; return c->fail(NBCO_ERR_HIP, "internal error: nbco_dist_repartition produced unbalanced domains"); }
-		hipLaunchKernelGGL(dp_send_kernel, dim3(256), dim3(kB), 0, st, (const float4 *)P, (const float *)(s.state + 3 * nl), nl, sendbuf);
+		// The scatter passes leave a destination's particles in the order their workgroups happened to finish.  The receiver's
+		// local build takes the local index as the last key of its stable-sort chain, so the order has to be the gathered
+		// partition's (source rank, then index in the source's state): one stable radix pass over the destination ranks, taken in
+		// the order of the local state.
+		{
+			NBCO_TRY(c->reserve(c->idx, sizeof(uint32_t) * (size_t)nl));
+			NBCO_TRY(c->reserve(c->idx_alt, sizeof(uint32_t) * (size_t)nl));
+			NBCO_TRY(c->reserve(c->keys, sizeof(uint64_t) * (size_t)nl));
+			uint32_t *dest = c->idx.as<uint32_t>(), *dest_sorted = c->idx_alt.as<uint32_t>(), *order = c->keys.as<uint32_t>();
+			hipLaunchKernelGGL(dp_dest_kernel, dim3(256), dim3(kB), 0, st, (const float4 *)P, (const int *)seg, G, nl, dest);
+			NBCO_HIP(hipGetLastError());
+			const unsigned bits = (unsigned)std::max(d, 1);
+			rocprim::counting_iterator<uint32_t> iota(0u);
+			size_t bytes = 0;
+			NBCO_HIP(rocprim::radix_sort_pairs(nullptr, bytes, dest, dest_sorted, iota, order, (size_t)nl, 0u, bits, st));
+			NBCO_TRY(c->reserve(c->sort_tmp, bytes));
+			bytes = c->sort_tmp.bytes;
+			NBCO_HIP(rocprim::radix_sort_pairs(c->sort_tmp.ptr, bytes, dest, dest_sorted, iota, order, (size_t)nl, 0u, bits, st));
+			hipLaunchKernelGGL(dp_send_kernel, dim3(256), dim3(kB), 0, st, (const uint32_t *)order, (const float *)s.state, (const float *)(s.state + 3 * nl), nl, sendbuf);
+		}
 		NBCO_HIP(hipGetLastError());
 		s.stage = ST_MOVE;
 		NBCO_TRY(step(NBCO_COLL_ALLTOALL, L.coll_send + L.coll_recv, L.coll_send + L.coll_recv + L.send, nl));

@@ -195,9 +195,23 @@ int kd_dist_partition(nbco_ctx *c, const float *state_all, long long n_global, i
 		NBCO_HIP(hipMemcpyAsync(&flag, c->counters.as<int>() + 110, sizeof(int), hipMemcpyDeviceToHost, st));
 		NBCO_HIP(hipStreamSynchronize(st));
 		if (flag && use_select) { c->escalate_build(); continue; }
-		// the domain's slice of the partitioned state
-		hipLaunchKernelGGL(unpack4_kernel, dim3(grid1d(nl)), dim3(kBlock), 0, st, (const float4 *)(pos + (size_t)rank * nl), state_local, nl);
-		NBCO_TRY(launch_gather3(c, state_local + 3 * nl, state_all + 3 * n, unsort + (size_t)rank * nl, nl, false));
+		// the domain's slice of the partitioned state, IN THE ORDER OF THE GATHERED STATE: the selection levels leave a node's
+		// particles in the order their workgroups happened to finish, and the local build takes the local index as the last key of
+		// its stable-sort chain (pivot ties on every axis of the chain: a node near the domain root whose ancestors all split
+		// along its own axis) -- with the gathered order restored that key is the single-GPU tree's, whatever the launch order
+		// was (`tools/soak_dist.py` found domains that differed between two runs of the same input)
+		{
+			uint32_t *own = reinterpret_cast<uint32_t *>(unsort + (size_t)rank * nl), *sorted = c->idx.as<uint32_t>();
+			int bits = 1;
+			while ((1LL << bits) < n) ++bits;
+			size_t bytes = 0;
+			NBCO_HIP(rocprim::radix_sort_keys(nullptr, bytes, own, sorted, (size_t)nl, 0u, (unsigned)bits, st));
+			NBCO_TRY(c->reserve(c->sort_tmp, bytes));
+			bytes = c->sort_tmp.bytes;
+			NBCO_HIP(rocprim::radix_sort_keys(c->sort_tmp.ptr, bytes, own, sorted, (size_t)nl, 0u, (unsigned)bits, st));
+			NBCO_TRY(launch_gather3(c, state_local, state_all, reinterpret_cast<const int *>(sorted), nl, false));
+			NBCO_TRY(launch_gather3(c, state_local + 3 * nl, state_all + 3 * n, reinterpret_cast<const int *>(sorted), nl, false));
+		}
 		NBCO_HIP(hipGetLastError());
 		break;
 	}

@@ -253,6 +253,54 @@ def _rows(t, n):
     return a[np.lexsort(a.T[::-1])]
 
 
+def _in_input_order(dom_pos, pos):
+    """every domain holds its particles in the order of the input (the gathered state)"""
+    key = {row.tobytes(): i for i, row in enumerate(np.ascontiguousarray(pos))}
+    if len(key) != len(pos):
+        return   # (coincident particles: no unique input index)
+    for d in dom_pos:
+        idx = np.fromiter((key[row.tobytes()] for row in np.ascontiguousarray(d)), dtype=np.int64, count=len(d))
+        assert np.all(np.diff(idx) > 0), "a domain's particles are not in the order of the gathered state"
+
+
+@pytest.mark.parametrize("gather", [True, None])
+def test_pivot_ties_under_a_one_axis_chain_follow_the_input_order(oracle32, gather):
+    """A rod along z: the top splits and the first local ones all cut z, so the stable-sort chain of those nodes holds no other
+    axis, and two particles with the pivot's z are told apart by the LAST key alone -- the index in the input, which for a
+    domain's local build is the index in its local state.  Both partitions therefore hand every domain its particles in the
+    order of the gathered state (the selection levels and the scatter passes leave them in launch order): the sharded tree
+    equals the single-GPU tree bit for bit, on every run."""
+    import torch
+    n, G, p = 32768, 4, 4
+    rng = np.random.default_rng(77)
+    pos = (rng.random((n, 3), dtype=np.float32) * np.array([0.01, 0.01, 1.0], dtype=np.float32)).astype(np.float32)
+    vel = rng.standard_normal((n, 3)).astype(np.float32)
+    order = np.argsort(pos[:, 2], kind="stable")
+    # the medians of every node of global levels 0 .. 6 (cuts along z all of them: the box is 100 : 1): the last particle of the left
+    # half gets the z of the first one of the right half, their x and y differ
+    for l in range(0, 7):
+        for j in range(1 << l):
+            s, e = (n * j) >> l, (n * (j + 1)) >> l
+            m = (s + e) // 2
+            pos[order[m - 1], 2] = pos[order[m], 2]
+    par = torch.from_numpy(oracle32.params(n)).cuda()
+    opts = dict(fmm_order=p, unsort=0, tree_steps=1, p2p_mutual=0)
+    e1, ref = single_gpu(n, pos, vel, par, **opts)
+    sd = e1.kd_array("splitdim")
+    assert (sd[:127] == 2).all(), "the test's premise: levels 0 .. 6 split along z"
+    for rep in range(3):
+        world = loopback(n, G, pos, vel, gather_partition=gather, **opts)
+        assert all(bool(r.dpart) == (gather is None) for r in world.runs)
+        _in_input_order(torch.cat([r.pos for r in world.runs]).cpu().numpy().reshape(G, n // G, 3), pos)
+        world.force(par, elastic=False)
+        torch.cuda.synchronize()
+        assert torch.equal(torch.cat([r.pos for r in world.runs]), ref[:3 * n]), "tree order of the positions differs"
+        assert torch.equal(torch.cat([r.vel for r in world.runs]), ref[3 * n:6 * n])
+        assert torch.equal(torch.cat([r.acc for r in world.runs]), ref[6 * n:])
+        for r in world.runs:
+            r.eng.close()
+
+
 @pytest.mark.parametrize("n,G,kind", [(32768, 2, "reference"), (65536, 8, "clumps"), (40000, 4, "uniform"), (1 << 20, 8, "reference"), (32768, 1, "uniform"),
                                       (131072, 16, "reference")])
 def test_distributed_repartition_equals_gathered_partition(oracle32, n, G, kind):
@@ -269,6 +317,9 @@ def test_distributed_repartition_equals_gathered_partition(oracle32, n, G, kind)
     for ra, rb in zip(a.runs, b.runs):
         np.testing.assert_array_equal(_rows(ra.buf, nl), _rows(rb.buf, nl))
         assert rb.partition_bytes is not None
+        # ... in the same order, the gathered state's (the local index is the last key of the local build's sort chain)
+        assert torch.equal(ra.buf[:6 * nl], rb.buf[:6 * nl])
+    _in_input_order(torch.cat([r.pos for r in a.runs]).cpu().numpy().reshape(G, nl, 3), pos)
     if G > 1:
         assert sum(r.partition_bytes for r in b.runs) < sum(r.partition_bytes for r in a.runs)
     a.force(par, elastic=False)
@@ -283,6 +334,7 @@ def test_distributed_repartition_equals_gathered_partition(oracle32, n, G, kind)
         w.partition([r.pos for r in w.runs], [r.vel for r in w.runs])
     for ra, rb in zip(a.runs, b.runs):
         np.testing.assert_array_equal(_rows(ra.buf, nl), _rows(rb.buf, nl))
+        assert torch.equal(ra.buf[:6 * nl], rb.buf[:6 * nl])
     if G > 1:
         assert sum(r.partition_bytes for r in b.runs) < 0.5 * sum(r.partition_bytes for r in a.runs)
 
