@@ -267,7 +267,9 @@ int nbco_dist_local(nbco_ctx *c, float *buf_local, long long n_local, void *node
 /* The same re-partition WITHOUT gathering the state (no rank ever holds more than its own n_local particles): per level the
  * exact medians by a radix select whose histograms are summed across the ranks, pivot ties ordered by the stable-sort chain's
  * remaining keys, evalBox for the children, local partition; then one all-to-all of [pos | vel] by destination.  Top boxes,
- * split axes and the particle set of every domain equal nbco_dist_partition's (the order inside a domain is arbitrary in both).
+ * split axes, the particles of every domain and their ORDER equal nbco_dist_partition's: both deliver a domain in the order of the
+ * gathered state (source rank, then index in the source's state) -- the local build takes the local index as the last key of its
+ * stable-sort chain, as the single-GPU build takes the index in its input.
  * The library never communicates: _begin / _next run the local stages and describe, in *next, the collective the caller runs
  * on its workspace (device memory, _workspace bytes) before calling _next again, until op == NBCO_COLL_DONE:
  *   ALLREDUCE_MIN_I32 / ALLREDUCE_SUM_I32   in place, `count` int32 at work + send_off
