@@ -22,7 +22,11 @@ def world(G, n, pos, vel, warm, gather_partition, **opts):
 
 
 bad = 0
-for G, n, steps, rebalance, dt, p, mutual in [(4, 1 << 18, 600, 8, 5e-4, 4, 0), (8, 1 << 19, 300, 16, 5e-4, 6, 0), (2, 1 << 17, 400, 5, 5e-3, 3, 0), (4, 1 << 18, 200, 8, 5e-4, 5, 1)]:
+CASES = [(4, 1 << 18, 600, 8, 5e-4, 4, 0), (8, 1 << 19, 300, 16, 5e-4, 6, 0), (2, 1 << 17, 400, 5, 5e-3, 3, 0), (4, 1 << 18, 200, 8, 5e-4, 5, 1)]
+if "--long" in sys.argv:   # (frequent cuts, many domains, a long run: what the order of a domain after the cut has to survive)
+    CASES = [(8, 1 << 20, 400, 8, 5e-4, 6, 0), (4, 1 << 18, 1500, 4, 2e-3, 4, 0), (16, 1 << 19, 200, 4, 1e-3, 3, 0), (4, 1 << 18, 600, 1, 5e-4, 4, 0),
+             (2, 1 << 20, 300, 8, 5e-4, 6, 0)]
+for G, n, steps, rebalance, dt, p, mutual in CASES:
     buf = gaussian_ball(n, 5); par = torch.from_numpy(coulomb_params(n)).cuda()
     opts = dict(fmm_order=p, unsort=0, tree_steps=1, p2p_mutual=mutual, list_factor=8, list_grow=1)
     wa = world(G, n, buf[0], buf[1], True, None, **opts)
