@@ -64,6 +64,9 @@ typedef float p2p_v2f __attribute__((ext_vector_type(2)));
 #define NBCO_P2P_PACKED 1
 #endif
 
+#ifndef NBCO_P2P_UNROLL
+#define NBCO_P2P_UNROLL 2   // source quads per trip of the tile loop
+#endif
 #ifndef NBCO_P2P_WAVES
 #define NBCO_P2P_WAVES 4
 #endif
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(64 * kP2PWaves) NBCO_P2P_ATTR void p2p_kernel(const
 #if NBCO_P2P_PACKED
 						p2p_v2f tx2 = {0.f, 0.f}, ty2 = {0.f, 0.f}, tz2 = {0.f, 0.f};
 						const p2p_v2f pix = {pi.x, pi.x}, piy = {pi.y, pi.y}, piz = {pi.z, pi.z}, eps2v = {eps2, eps2};
-#pragma unroll 2
+#pragma unroll NBCO_P2P_UNROLL
 						for (int q4 = 0; q4 < TPL / 4; ++q4)
 						{
 							const float4 X = t4[q4], Y = t4[TPL / 4 + q4], Z = t4[TPL / 2 + q4];
